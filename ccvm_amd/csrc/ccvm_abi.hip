@@ -1,0 +1,501 @@
+// C ABI of libccvm_hip.so (declared in include/ccvm_hip.h): argument validation,
+// per-step schedule scalars (fp64 on the host, as the reference computes them with
+// Python/numpy doubles), and kernel launches.  No allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ccvm_hip.h"
+#include "ccvm_kernels.h"
+
+using namespace ccvm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CCVM_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return fail(CCVM_E_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_layout(const char* fn, int B, int N, int ld) {
+    if (B <= 0 || N <= 0) return fail(CCVM_E_INVALID, "%s: B=%d N=%d must be positive", fn, B, N);
+    if (ld != ccvm_ld(N)) return fail(CCVM_E_LAYOUT, "%s: ld=%d but ccvm_ld(%d)=%d", fn, ld, N, ccvm_ld(N));
+    return CCVM_OK;
+}
+
+int check_steps(const char* fn, int step0, int nsteps, int T) {
+    if (step0 < 0 || nsteps < 0 || T <= 0 || step0 + nsteps > T)
+        return fail(CCVM_E_INVALID, "%s: step range [%d, %d) outside a %d-step run", fn, step0, step0 + nsteps, T);
+    return CCVM_OK;
+}
+
+int check_noise(const char* fn, const ccvm_noise* nz, bool two_streams) {
+    if (!nz) return fail(CCVM_E_INVALID, "%s: noise is NULL", fn);
+    if (nz->mode == CCVM_NOISE_REPLAY) {
+        if (!nz->w0 || (two_streams && !nz->w1))
+            return fail(CCVM_E_INVALID, "%s: REPLAY noise needs w0%s", fn, two_streams ? " and w1" : "");
+    } else if (nz->mode != CCVM_NOISE_PHILOX) {
+        return fail(CCVM_E_INVALID, "%s: unknown noise mode %d", fn, nz->mode);
+    }
+    return CCVM_OK;
+}
+
+int check_adam(const char* fn, const ccvm_adam* ad) {
+    if (!ad || !ad->enabled) return CCVM_OK;
+    if (!ad->m) return fail(CCVM_E_INVALID, "%s: Adam enabled but m is NULL", fn);
+    if (ad->beta2 != 1.0 && !ad->v) return fail(CCVM_E_INVALID, "%s: Adam with beta2 != 1 needs v", fn);
+    return CCVM_OK;
+}
+
+void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
+    s.beta1 = (float)ad->beta1;
+    s.one_m_beta1 = (float)(1.0 - ad->beta1);
+    s.inv_bc1 = (float)(1.0 / (1.0 - std::pow(ad->beta1, (double)(i + 1))));
+    s.use_v = ad->beta2 != 1.0;
+    s.beta2 = (float)ad->beta2;
+    s.one_m_beta2 = (float)(1.0 - ad->beta2);
+    s.inv_bc2 = s.use_v ? (float)(1.0 / (1.0 - std::pow(ad->beta2, (double)(i + 1)))) : 1.0f;
+    s.alpha = (float)ad->alpha;
+    s.eps = 1e-8f;
+    s.add_assign = ad->add_assign;
+}
+
+void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld) {
+    std::memset(&a, 0, sizeof(a));
+    a.Q = Q;
+    a.V = V;
+    a.B = B;
+    a.N = N;
+    a.ld = ld;
+    a.nrb = (B + BM - 1) / BM;
+    a.ncb = ld / BN;
+    a.in_scale = 1.0f;
+    a.in_shift = 0.0f;
+}
+
+void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N, bool two, bool next) {
+    a.step = i;
+    a.seed = nz->seed;
+    a.row_offset = nz->row_offset;
+    a.replay = nz->mode == CCVM_NOISE_REPLAY;
+    if (a.replay) {
+        const size_t blk = (size_t)N * B;
+        a.w0 = nz->w0 + (size_t)(i - step0) * blk;
+        a.w1 = two ? nz->w1 + (size_t)(i - step0) * blk : nullptr;
+        a.w0n = next ? nz->w0 + (size_t)(i + 1 - step0) * blk : nullptr;
+    }
+}
+
+template <int MODE, bool ADAM>
+int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
+    const int grid = a.nrb * a.ncb;
+    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(NTHREADS), 0, st, a);
+    CCVM_CHECK_LAUNCH(name);
+    return CCVM_OK;
+}
+
+inline int ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccvm_abi_version(void) { return CCVM_ABI_VERSION; }
+const char* ccvm_last_error(void) { return g_err; }
+int ccvm_ld(int N) { return N <= 0 ? 0 : round_up(N, 128); }
+int ccvm_rows(int B) { return B <= 0 ? 0 : round_up(B, 64); }
+
+size_t ccvm_workspace_bytes(int solver, int B, int N) {
+    const size_t ld = (size_t)ccvm_ld(N), rows = (size_t)ccvm_rows(B);
+    const size_t state = rows * ld * sizeof(float);
+    switch (solver) {
+        case 0: return 2 * state;                        // DL: c', s'
+        case 1: return 2 * state;                        // MF: measured-amplitude ping-pong
+        case 2: return state;                            // Langevin: c'
+        case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
+        case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
+        default: return 0;
+    }
+}
+
+int ccvm_pack(const float* src, int rows, int cols, int src_ld, float* dst, int dst_rows, int dst_ld,
+              void* stream) {
+    if (!src || !dst || rows < 0 || cols < 0 || src_ld < cols || dst_rows < rows || dst_ld < cols)
+        return fail(CCVM_E_INVALID, "ccvm_pack: bad arguments");
+    const size_t total = (size_t)dst_rows * dst_ld;
+    if (total == 0) return CCVM_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, rows, cols,
+                       src_ld, dst, dst_rows, dst_ld);
+    CCVM_CHECK_LAUNCH("ccvm_pack");
+    return CCVM_OK;
+}
+
+int ccvm_unpack(const float* src, int src_ld, float* dst, int rows, int cols, int dst_ld, void* stream) {
+    if (!src || !dst || rows < 0 || cols < 0 || src_ld < cols || dst_ld < cols)
+        return fail(CCVM_E_INVALID, "ccvm_unpack: bad arguments");
+    const size_t total = (size_t)rows * cols;
+    if (total == 0) return CCVM_OK;
+    hipLaunchKernelGGL(unpack_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, src_ld, dst,
+                       rows, cols, dst_ld);
+    CCVM_CHECK_LAUNCH("ccvm_unpack");
+    return CCVM_OK;
+}
+
+int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N, int ld, int step0,
+                int nsteps, int T, const ccvm_dl_params* p, const ccvm_noise* nz, void* ws, size_t ws_bytes,
+                void* stream) {
+    const char* fn = "ccvm_dl_run";
+    if (!Q || !V || !c || !s || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    int rc;
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
+    if ((rc = check_noise(fn, nz, true))) return rc;
+    if (!aligned16(Q) || !aligned16(c) || !aligned16(s) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, c, s and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(0, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0)) return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0", fn);
+    hipStream_t st = (hipStream_t)stream;
+
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* bufc[2] = {c, static_cast<float*>(ws)};
+    float* bufs[2] = {s, static_cast<float*>(ws) + state};
+    if (nsteps > 0) {
+        // keep the padding of the scratch buffers zero (rows >= B, cols >= N are never written)
+        if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+    }
+
+    const double ul = p->upper - p->lower, up = p->upper + p->lower;
+    const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.in_scale = (float)(ul / Sd);
+    a.in_shift = (float)up;
+    int cur = 0;
+    for (int i = step0; i < step0 + nsteps; ++i) {
+        const double frac = (double)(i + 1) / (double)T;
+        const double rate = p->pump_rate_flag ? frac : 1.0;                           // :524-525
+        const double ratio = (p->noise_ratio - 1.0) * std::exp(-frac * 3.0) + 1.0;    // :527
+        const double fsd = p->feedback_scale * (0.5 + rate);                          // :169
+        DlScalars& k = a.s.dl;
+        k.a_q = (float)(-p->dt * fsd * 0.25 * ul / Sd);
+        k.a_v = (float)(-p->dt * fsd * ul / (2.0 * Sd));
+        k.pm_c = (float)(-1.0 + p->pump * rate);
+        k.pm_s = (float)(-1.0 - p->pump * rate);
+        k.dt = (float)p->dt;
+        k.g2 = (float)(2.0 * p->g);
+        k.w_c = (float)(std::sqrt(p->dt) * ratio);
+        k.w_s = (float)(std::sqrt(p->dt) / ratio);
+        a.a0 = bufc[cur];
+        a.a1 = bufs[cur];
+        a.o0 = bufc[cur ^ 1];
+        a.o1 = bufs[cur ^ 1];
+        set_noise(a, nz, i, step0, B, N, true, false);
+        if ((rc = launch_step<MODE_DL, false>(a, st, fn))) return rc;
+        cur ^= 1;
+    }
+    if (cur == 1) {
+        if (hipMemcpyAsync(c, bufc[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(s, bufs[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+    }
+    return CCVM_OK;
+}
+
+int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* mu_tilde_out, int B, int N,
+                int ld, int step0, int nsteps, int T, const ccvm_mf_params* p, const ccvm_adam* adam,
+                const ccvm_noise* nz, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_mf_run";
+    if (!Q || !V || !mu || !sigma || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    int rc;
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
+    if ((rc = check_noise(fn, nz, false))) return rc;
+    if ((rc = check_adam(fn, adam))) return rc;
+    if (!aligned16(Q) || !aligned16(mu) || !aligned16(sigma) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, mu, sigma and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(1, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->S > 0) || !(p->j > 0))
+        return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0, j > 0", fn);
+    if (nsteps == 0) return CCVM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_adam = adam && adam->enabled;
+
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
+    if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+
+    const double ul = p->upper - p->lower, up = p->upper + p->lower;
+    const double sdt = std::sqrt(p->dt);
+    auto j_at = [&](int i) { return p->j * std::exp(-(double)(i + 1) / (double)T * 3.0); };  // :550
+    const bool replay = nz->mode == CCVM_NOISE_REPLAY;
+
+    // measured amplitude of the first step of this chunk (mf_solver.py:551-554)
+    {
+        const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(step0))) / sdt);
+        hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], B, N, ld,
+                           k0, (float)p->S, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
+        CCVM_CHECK_LAUNCH(fn);
+    }
+
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.in_scale = (float)(ul / p->S);
+    a.in_shift = (float)up;
+    a.st0 = mu;
+    a.st1 = sigma;
+    if (use_adam) {
+        a.am = adam->m;
+        a.av = adam->v;
+    }
+    int cur = 0;
+    for (int i = step0; i < step0 + nsteps; ++i) {
+        const bool has_next = (i + 1 < step0 + nsteps);
+        const double j_i = j_at(i);
+        const double rate = p->pump_rate_flag ? (double)(i + 1) / (double)T : 1.0;  // :556-557
+        const double p_i = p->pump * rate + 1.0 + j_i;                              // :559
+        MfScalars& k = a.s.mf;
+        k.a0 = (float)(-(1.0 + j_i) + p_i);
+        k.g2 = (float)(p->g * p->g);
+        k.f_q = (float)(-p->feedback_scale * 0.25 * ul / p->S);
+        k.f_v = (float)(-p->feedback_scale * ul / (2.0 * p->S));
+        k.j_i = (float)j_i;
+        k.one_j = (float)(1.0 + j_i);
+        k.sqrt_j = (float)std::sqrt(j_i);
+        k.inv_sdt = (float)(1.0 / sdt);
+        k.dt = (float)p->dt;
+        k.k_next = has_next ? (float)(std::sqrt(1.0 / (4.0 * j_at(i + 1))) / sdt) : 0.0f;
+        k.S = (float)p->S;
+        k.has_next = has_next;
+        if (use_adam) fill_adam(a.ad, adam, i);
+        a.a0 = mt[cur];
+        a.o0 = mt[cur ^ 1];
+        set_noise(a, nz, i, step0, B, N, false, has_next);
+        rc = use_adam ? launch_step<MODE_MF, true>(a, st, fn) : launch_step<MODE_MF, false>(a, st, fn);
+        if (rc) return rc;
+        if (has_next) cur ^= 1;
+    }
+    if (mu_tilde_out) {
+        if (hipMemcpyAsync(mu_tilde_out, mt[cur], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy of mu_tilde failed", fn);
+    }
+    return CCVM_OK;
+}
+
+int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, int ld, int step0, int nsteps,
+                      int T, const ccvm_langevin_params* p, const ccvm_adam* adam, const ccvm_noise* nz,
+                      void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_langevin_run";
+    if (!Q || !V || !c || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    int rc;
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
+    if ((rc = check_noise(fn, nz, false))) return rc;
+    if ((rc = check_adam(fn, adam))) return rc;
+    if (!aligned16(Q) || !aligned16(c) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, c and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(2, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->S > 0))
+        return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0", fn);
+    if (nsteps == 0) return CCVM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_adam = adam && adam->enabled;
+
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* buf[2] = {c, static_cast<float*>(ws)};
+    if (hipMemsetAsync(ws, 0, state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+
+    const double ul = p->upper - p->lower, up = p->upper + p->lower;
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.in_scale = (float)(ul / (2.0 * p->S));  // langevin_solver.py:133
+    a.in_shift = (float)(up / 2.0);
+    if (use_adam) {
+        a.am = adam->m;
+        a.av = adam->v;
+    }
+    int cur = 0;
+    for (int i = step0; i < step0 + nsteps; ++i) {
+        LvScalars& k = a.s.lv;
+        k.g_q = (float)(-ul / (2.0 * p->S));
+        k.g_v = k.g_q;
+        const double p_i = p->pump_rate_flag ? p->pump * (double)(i + 1) / (double)T : p->pump;  // pl:279-282
+        k.pm = (float)(-1.0 + p_i);
+        k.dt = (float)p->dt;
+        k.dt_fs = (float)(p->dt * p->feedback_scale);
+        k.w = (float)(p->sigma * std::sqrt(p->dt));
+        k.S = (float)p->S;
+        k.use_pump = p->use_pump;
+        if (use_adam) fill_adam(a.ad, adam, i);
+        a.a0 = buf[cur];
+        a.o0 = buf[cur ^ 1];
+        set_noise(a, nz, i, step0, B, N, false, false);
+        rc = use_adam ? launch_step<MODE_LANGEVIN, true>(a, st, fn) : launch_step<MODE_LANGEVIN, false>(a, st, fn);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    if (cur == 1) {
+        if (hipMemcpyAsync(c, buf[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+    }
+    return CCVM_OK;
+}
+
+int ccvm_clamp(float* x, int B, int N, int ld, float lo, float hi, void* stream) {
+    int rc;
+    if (!x) return fail(CCVM_E_INVALID, "ccvm_clamp: NULL argument");
+    if ((rc = check_layout("ccvm_clamp", B, N, ld))) return rc;
+    hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream, x, B, N, ld,
+                       lo, hi);
+    CCVM_CHECK_LAUNCH("ccvm_clamp");
+    return CCVM_OK;
+}
+
+int ccvm_change_variables(const float* x, float* y, int B, int N, int ld, double S, double lower, double upper,
+                          void* stream) {
+    int rc;
+    if (!x || !y) return fail(CCVM_E_INVALID, "ccvm_change_variables: NULL argument");
+    if ((rc = check_layout("ccvm_change_variables", B, N, ld))) return rc;
+    if (!(S > 0)) return fail(CCVM_E_INVALID, "ccvm_change_variables: S must be positive");
+    hipLaunchKernelGGL(change_variables_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, N, ld, (float)S, (float)(upper - lower), (float)(0.5 * (upper + lower)));
+    CCVM_CHECK_LAUNCH("ccvm_change_variables");
+    return CCVM_OK;
+}
+
+int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, int ld, double scaled_by,
+                float* obj, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_energy";
+    int rc;
+    if (!Q || !V || !x || !obj) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(3, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    hipStream_t st = (hipStream_t)stream;
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.a0 = x;
+    a.o0 = static_cast<float*>(ws);
+    if ((rc = launch_step<MODE_ENERGY, false>(a, st, fn))) return rc;
+    hipLaunchKernelGGL(energy_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, st,
+                       static_cast<const float*>(ws), a.ncb * 4, a.nrb * BM, B, (float)scaled_by, obj);
+    CCVM_CHECK_LAUNCH(fn);
+    return CCVM_OK;
+}
+
+int ccvm_feedback(const float* Q, const float* V, const float* x, float* y, int B, int N, int ld, double in_scale,
+                  double in_shift, double f_q, double f_v, void* stream) {
+    const char* fn = "ccvm_feedback";
+    int rc;
+    if (!Q || !V || !x || !y || x == y) return fail(CCVM_E_INVALID, "%s: NULL or aliased argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(y))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and y must be 16-byte aligned", fn);
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.in_scale = (float)in_scale;
+    a.in_shift = (float)in_shift;
+    a.a0 = x;
+    a.o0 = y;
+    a.s.pp.step = (float)f_q;
+    a.s.pp.eps = (float)f_v;
+    return launch_step<MODE_AFFINE, false>(a, (hipStream_t)stream, fn);
+}
+
+int ccvm_pp_grad_descent(const float* Q, const float* V, float* x, int B, int N, int ld, int iters, double step,
+                         double lo, double hi, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_pp_grad_descent";
+    int rc;
+    if (!Q || !V || !x || iters < 0) return fail(CCVM_E_INVALID, "%s: bad argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(4, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (iters == 0) return CCVM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* buf[2] = {x, static_cast<float*>(ws)};
+    if (hipMemsetAsync(ws, 0, state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld);
+    a.s.pp.step = (float)step;
+    a.s.pp.lo = (float)lo;
+    a.s.pp.hi = (float)hi;
+    int cur = 0;
+    for (int i = 0; i < iters; ++i) {
+        a.a0 = buf[cur];
+        a.o0 = buf[cur ^ 1];
+        if ((rc = launch_step<MODE_GD, false>(a, st, fn))) return rc;
+        cur ^= 1;
+    }
+    if (cur == 1 &&
+        hipMemcpyAsync(x, buf[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+    return CCVM_OK;
+}
+
+int ccvm_pp_adam(const float* Q, const float* V, float* x, int B, int N, int ld, double lr, double eps, double lo,
+                 double hi, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_pp_adam";
+    int rc;
+    if (!Q || !V || !x) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(4, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* xn = static_cast<float*>(ws);
+    float* qs = xn + state;
+    if (hipMemsetAsync(xn, 0, state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
+    CCVM_CHECK_LAUNCH(fn);
+    StepArgs a;
+    base_args(a, qs, V, B, N, ld);
+    a.a0 = x;
+    a.o0 = xn;
+    a.s.pp.step = (float)lr;
+    a.s.pp.eps = (float)eps;
+    a.s.pp.lo = (float)lo;
+    a.s.pp.hi = (float)hi;
+    if ((rc = launch_step<MODE_ADAMPP, false>(a, st, fn))) return rc;
+    if (hipMemcpyAsync(x, xn, state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+    return CCVM_OK;
+}
+
+int ccvm_philox_normals(uint64_t seed, int64_t row_offset, int step, int B, int N, float* w0, float* w1,
+                        void* stream) {
+    if (!w0 || B <= 0 || N <= 0 || step < 0) return fail(CCVM_E_INVALID, "ccvm_philox_normals: bad argument");
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream, seed,
+                       row_offset, step, B, N, w0, w1);
+    CCVM_CHECK_LAUNCH("ccvm_philox_normals");
+    return CCVM_OK;
+}
+
+}  // extern "C"

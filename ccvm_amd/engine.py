@@ -1,0 +1,395 @@
+"""Host side of the HIP dynamics engine: device buffers, noise sources, chunking.
+
+This module is plumbing around libccvm_hip.so: it owns pitched device buffers
+(torch is used for memory and streams only), turns solver parameters into the C
+structs of include/ccvm_hip.h and drives ``ccvm_*_run`` in chunks.  All arithmetic of
+the SDE loop happens in the HIP kernels; there is no CPU implementation here and
+every entry point raises ``EngineUnavailable`` when no MI355X / no built library is
+present.
+
+``device`` strings follow the reference API ("cpu" / "cuda") but name where the
+CALLER's tensors live: host tensors are staged to the GPU and results are copied
+back.  The GPU used is ``cuda:$LOCAL_RANK`` (or ``$CCVM_AMD_DEVICE``, default 0).
+"""
+import ctypes
+import os
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EngineUnavailable
+
+_REPLAY_CHUNK_FLOATS = 32 * 1024 * 1024  # per noise stream, per chunk (128 MiB)
+
+
+# --------------------------------------------------------------------------- #
+# device / library access
+# --------------------------------------------------------------------------- #
+def gpu_device():
+    """The torch device the engine runs on; raises if there is none."""
+    lib = _lib.load()  # fail on a missing library before touching the GPU
+    del lib
+    if not torch.cuda.is_available():
+        raise EngineUnavailable(
+            "no MI355X visible (torch.cuda.is_available() is False); the CCVM dynamics engine"
+            " has no CPU fallback"
+        )
+    index = int(os.environ.get("CCVM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return torch.device("cuda", index)
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def ld_of(n):
+    return _lib.load().ccvm_ld(int(n))
+
+
+def rows_of(b):
+    return _lib.load().ccvm_rows(int(b))
+
+
+def pack(src, rows_pad, ld):
+    """Zero-padded pitched copy of a 1-D / 2-D float tensor already on the GPU."""
+    lib = _lib.load()
+    src2 = src.reshape(1, -1) if src.ndim == 1 else src
+    src2 = src2.to(torch.float32).contiguous()
+    out = torch.empty((rows_pad, ld), dtype=torch.float32, device=src2.device)
+    _lib.check(
+        lib.ccvm_pack(_ptr(src2), src2.shape[0], src2.shape[1], src2.shape[1], _ptr(out), rows_pad, ld,
+                      _stream_ptr()),
+        "ccvm_pack",
+    )
+    return out
+
+
+def unpack(src, rows, cols):
+    lib = _lib.load()
+    out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    _lib.check(
+        lib.ccvm_unpack(_ptr(src), src.shape[1], _ptr(out), rows, cols, cols, _stream_ptr()), "ccvm_unpack"
+    )
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# noise sources
+# --------------------------------------------------------------------------- #
+@dataclass
+class NoiseSpec:
+    """How the Wiener increments of a run are produced.
+
+    mode "philox": counter-based generator fused into the step kernel; ``seed`` keys
+        it and ``row_offset`` is the global index of local row 0 (batch sharding).
+    mode "replay": standard normals are drawn on the host from ``generator`` (None =
+        torch's global CPU generator, i.e. exactly what the reference consumes after
+        ``torch.manual_seed``) in the reference's order -- per step one (N, B) block
+        per stream, DL drawing the c block before the s block (dl_solver.py:538-547) --
+        and uploaded chunk by chunk.  Parity mode; bandwidth is irrelevant.
+    """
+
+    mode: str = "philox"
+    seed: int = 0
+    row_offset: int = 0
+    generator: Optional[torch.Generator] = None
+
+    def __post_init__(self):
+        if self.mode not in ("philox", "replay"):
+            raise ValueError(f"unknown noise mode {self.mode!r}; expected 'philox' or 'replay'")
+
+
+def default_noise(mode=None, row_offset=0):
+    """Noise spec for a solver call.  PHILOX seeds are drawn from torch's global CPU
+    generator so ``torch.manual_seed`` makes runs reproducible in both modes."""
+    mode = mode or os.environ.get("CCVM_AMD_NOISE", "philox")
+    if mode == "replay":
+        return NoiseSpec(mode="replay", row_offset=row_offset)
+    seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    return NoiseSpec(mode="philox", seed=seed, row_offset=row_offset)
+
+
+class _NoiseFeeder:
+    """Builds the ccvm_noise struct for each chunk of steps."""
+
+    def __init__(self, spec, n, b, streams, device):
+        self.spec, self.n, self.b, self.streams, self.device = spec, n, b, streams, device
+        self._keep = None
+
+    def steps_per_chunk(self):
+        if self.spec.mode == "philox":
+            return 1 << 30
+        return max(1, _REPLAY_CHUNK_FLOATS // (self.n * self.b))
+
+    def chunk(self, nsteps):
+        nz = _lib.Noise()
+        nz.row_offset = int(self.spec.row_offset)
+        if self.spec.mode == "philox":
+            nz.mode = _lib.NOISE_PHILOX
+            nz.seed = int(self.spec.seed) & 0xFFFFFFFFFFFFFFFF
+            return nz
+        nz.mode = _lib.NOISE_REPLAY
+        host = torch.empty((nsteps, self.streams, self.n, self.b), dtype=torch.float32)
+        for t in range(nsteps):
+            for k in range(self.streams):
+                torch.randn((self.n, self.b), generator=self.spec.generator, out=host[t, k])
+        dev = host.to(self.device)
+        w0 = dev[:, 0].contiguous()
+        w1 = dev[:, 1].contiguous() if self.streams == 2 else None
+        self._keep = (w0, w1)  # alive until the next chunk replaces it (stream-ordered reuse)
+        nz.w0 = w0.data_ptr()
+        nz.w1 = w1.data_ptr() if w1 is not None else None
+        return nz
+
+
+# --------------------------------------------------------------------------- #
+# problem data on the device
+# --------------------------------------------------------------------------- #
+class DeviceProblem:
+    """Q (ld x ld, zero padded) and V (ld) on the GPU."""
+
+    def __init__(self, q_matrix, v_vector):
+        self.device = gpu_device()
+        self.n = int(q_matrix.shape[0])
+        if tuple(q_matrix.shape) != (self.n, self.n) or tuple(v_vector.shape) != (self.n,):
+            raise ValueError("q_matrix must be (N, N) and v_vector (N,)")
+        self.ld = ld_of(self.n)
+        with torch.cuda.device(self.device):
+            self.q = pack(q_matrix.detach().to(self.device), self.ld, self.ld)
+            self.v = pack(v_vector.detach().to(self.device), 1, self.ld).reshape(-1)
+
+
+def _adam_struct(adam, m, v):
+    st = _lib.Adam()
+    if adam is None:
+        st.enabled = 0
+        return st
+    st.enabled = 1
+    st.add_assign = 1 if adam["add_assign"] else 0
+    st.alpha, st.beta1, st.beta2 = float(adam["alpha"]), float(adam["beta1"]), float(adam["beta2"])
+    st.m = m.data_ptr()
+    st.v = v.data_ptr() if v is not None else None
+    return st
+
+
+class Trajectories:
+    """``batch`` independent trajectories of one solver on one GPU.
+
+    kind: "dl" | "mf" | "langevin" (pumped Langevin = langevin with use_pump).
+    ``params`` holds the solver's scalars (see the C structs); ``adam`` is an
+    ``AdamParameters.to_dict()`` or None.
+    """
+
+    _SOLVER_ID = {"dl": _lib.SOLVER_DL, "mf": _lib.SOLVER_MF, "langevin": _lib.SOLVER_LANGEVIN}
+
+    def __init__(self, problem, batch, kind, iterations, params, bounds, noise, adam=None):
+        if kind not in self._SOLVER_ID:
+            raise ValueError(f"unknown solver kind {kind!r}")
+        if kind == "dl" and adam is not None:
+            raise ValueError("the DL solver has no Adam variant in the engine")
+        self.lib = _lib.load()
+        self.p, self.kind, self.b, self.t = problem, kind, int(batch), int(iterations)
+        self.n, self.ld, self.device = problem.n, problem.ld, problem.device
+        self.rows = rows_of(self.b)
+        self.step = 0
+        lo, hi = float(bounds[0]), float(bounds[1])
+        with torch.cuda.device(self.device):
+            zeros = lambda: torch.zeros((self.rows, self.ld), dtype=torch.float32, device=self.device)
+            self.state = {}
+            if kind == "dl":
+                self.state["c"], self.state["s"] = zeros(), zeros()
+                cp = _lib.DlParams()
+                cp.pump, cp.dt, cp.noise_ratio = params["pump"], params["dt"], params["noise_ratio"]
+                cp.feedback_scale, cp.g = params["feedback_scale"], params["g"]
+                cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
+            elif kind == "mf":
+                self.state["mu"], self.state["sigma"], self.state["mu_tilde"] = zeros(), zeros(), zeros()
+                self.state["sigma"][: self.b, : self.n] = 0.5  # mf_solver.py:538-540
+                cp = _lib.MfParams()
+                cp.pump, cp.dt, cp.j = params["pump"], params["dt"], params["j"]
+                cp.feedback_scale, cp.g, cp.S = params["feedback_scale"], params["g"], params["S"]
+                cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
+            else:
+                self.state["c"] = zeros()
+                cp = _lib.LangevinParams()
+                cp.dt, cp.sigma, cp.feedback_scale, cp.S = (
+                    params["dt"], params["sigma"], params["feedback_scale"], params["S"]
+                )
+                cp.use_pump = 1 if params.get("use_pump", False) else 0
+                cp.pump = float(params.get("pump", 0.0))
+                cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
+            cp.lower, cp.upper = lo, hi
+            self.cparams = cp
+            self.adam_m = self.adam_v = None
+            if adam is not None:
+                self.adam_m = zeros()
+                if float(adam["beta2"]) != 1.0:
+                    self.adam_v = zeros()
+            self.adam = _adam_struct(adam, self.adam_m, self.adam_v)
+            ws_bytes = self.lib.ccvm_workspace_bytes(self._SOLVER_ID[kind], self.b, self.n)
+            self.ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=self.device)
+        self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
+
+    # ------------------------------------------------------------------ #
+    def advance(self, nsteps):
+        """Run ``nsteps`` more steps (asynchronous on the current stream)."""
+        if nsteps < 0 or self.step + nsteps > self.t:
+            raise ValueError("step range outside the run")
+        per = self.feeder.steps_per_chunk()
+        with torch.cuda.device(self.device):
+            while nsteps > 0:
+                k = min(nsteps, per)
+                self._run(self.step, k, self.feeder.chunk(k))
+                self.step += k
+                nsteps -= k
+
+    def _run(self, step0, k, nz):
+        lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
+        tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
+        if self.kind == "dl":
+            rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,
+                                 ctypes.byref(self.cparams), *tail)
+        elif self.kind == "mf":
+            rc = lib.ccvm_mf_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["mu"]), _ptr(st["sigma"]),
+                                 _ptr(st["mu_tilde"]), *common, ctypes.byref(self.cparams),
+                                 ctypes.byref(self.adam), *tail)
+        else:
+            rc = lib.ccvm_langevin_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), *common,
+                                       ctypes.byref(self.cparams), ctypes.byref(self.adam), *tail)
+        _lib.check(rc, f"ccvm_{self.kind}_run")
+
+    # ------------------------------------------------------------------ #
+    def clamp(self, name, lo, hi):
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib.ccvm_clamp(_ptr(self.state[name]), self.b, self.n, self.ld, float(lo), float(hi),
+                                    _stream_ptr()),
+                "ccvm_clamp",
+            )
+
+    def compact(self, name):
+        """Logical (B, N) copy of one state array, on the GPU."""
+        with torch.cuda.device(self.device):
+            return unpack(self.state[name], self.b, self.n)
+
+
+# --------------------------------------------------------------------------- #
+# the steps right after the loop
+# --------------------------------------------------------------------------- #
+def _to_gpu(t):
+    dev = gpu_device()
+    return t.detach().to(device=dev, dtype=torch.float32), dev
+
+
+def change_variables(x, S, lower, upper):
+    """0.5 * x / S * (upper - lower) + 0.5 * (upper + lower) on the GPU."""
+    lib = _lib.load()
+    xg, dev = _to_gpu(x)
+    b, n = xg.shape
+    with torch.cuda.device(dev):
+        xp = pack(xg, rows_of(b), ld_of(n))
+        _lib.check(
+            lib.ccvm_change_variables(_ptr(xp), _ptr(xp), b, n, xp.shape[1], float(S), float(lower),
+                                      float(upper), _stream_ptr()),
+            "ccvm_change_variables",
+        )
+        return unpack(xp, b, n).to(x.device)
+
+
+def clamp(x, lo, hi):
+    """clamp(x, lo, hi) on the GPU (fit_to_constraints)."""
+    lib = _lib.load()
+    xg, dev = _to_gpu(x)
+    b, n = xg.shape
+    with torch.cuda.device(dev):
+        xp = pack(xg, rows_of(b), ld_of(n))
+        _lib.check(
+            lib.ccvm_clamp(_ptr(xp), b, n, xp.shape[1], float(lo), float(hi), _stream_ptr()), "ccvm_clamp"
+        )
+        return unpack(xp, b, n).to(x.device)
+
+
+def feedback(x, q_matrix, v_vector, in_scale, in_shift, f_q, f_v):
+    """f_q * ((x * in_scale + in_shift) @ Q) + f_v * V  -- the bare feedback term."""
+    lib = _lib.load()
+    xg, dev = _to_gpu(x)
+    b, n = xg.shape
+    with torch.cuda.device(dev):
+        prob = DeviceProblem(q_matrix, v_vector)
+        xp = pack(xg, rows_of(b), prob.ld)
+        yp = torch.zeros_like(xp)
+        _lib.check(
+            lib.ccvm_feedback(_ptr(prob.q), _ptr(prob.v), _ptr(xp), _ptr(yp), b, n, prob.ld, float(in_scale),
+                              float(in_shift), float(f_q), float(f_v), _stream_ptr()),
+            "ccvm_feedback",
+        )
+        return unpack(yp, b, n).to(x.device)
+
+
+def energy(confs, q_matrix, v_vector, scaled_by=1.0):
+    """(1/2 x Q x + V x) * scaled_by for every row of ``confs``."""
+    lib = _lib.load()
+    xg, dev = _to_gpu(confs)
+    b, n = xg.shape
+    with torch.cuda.device(dev):
+        prob = DeviceProblem(q_matrix, v_vector)
+        xp = pack(xg, rows_of(b), prob.ld)
+        obj = torch.empty((b,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_ENERGY, b, n)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        _lib.check(
+            lib.ccvm_energy(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(scaled_by), _ptr(obj),
+                            _ptr(ws), ws.numel(), _stream_ptr()),
+            "ccvm_energy",
+        )
+        return obj.to(confs.device)
+
+
+def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, step=0.1, lr=0.01,
+                eps=1e-8):
+    """On-device grad-descent / adam post-processor; returns (x', seconds)."""
+    lib = _lib.load()
+    xg, dev = _to_gpu(x)
+    b, n = xg.shape
+    with torch.cuda.device(dev):
+        prob = DeviceProblem(q_matrix, v_vector)
+        xp = pack(xg, rows_of(b), prob.ld)
+        ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_POSTPROCESS, b, n)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        if method == "grad-descent":
+            rc = lib.ccvm_pp_grad_descent(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, int(iters),
+                                          float(step), float(lower), float(upper), _ptr(ws), ws.numel(),
+                                          _stream_ptr())
+        elif method == "adam":
+            rc = lib.ccvm_pp_adam(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(lr), float(eps),
+                                  float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
+        else:
+            raise ValueError(f"post-processor {method!r} is not implemented by the HIP engine")
+        _lib.check(rc, f"ccvm_pp_{method}")
+        torch.cuda.synchronize(dev)
+        seconds = time.time() - t0
+        return unpack(xp, b, n).to(x.device), seconds
+
+
+def philox_normals(seed, row_offset, step, b, n, two=False):
+    """The standard normals PHILOX mode uses at ``step``, as (N, B) tensors."""
+    lib = _lib.load()
+    dev = gpu_device()
+    with torch.cuda.device(dev):
+        w0 = torch.empty((n, b), dtype=torch.float32, device=dev)
+        w1 = torch.empty((n, b), dtype=torch.float32, device=dev) if two else None
+        _lib.check(
+            lib.ccvm_philox_normals(int(seed) & 0xFFFFFFFFFFFFFFFF, int(row_offset), int(step), b, n,
+                                    _ptr(w0), _ptr(w1), _stream_ptr()),
+            "ccvm_philox_normals",
+        )
+    return (w0, w1) if two else w0

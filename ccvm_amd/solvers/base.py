@@ -1,0 +1,331 @@
+"""Solver base class: the reference's ``CCVMSolver`` contract over the HIP engine.
+
+API parity targets (reference, relative to ccvm_simulators/solvers/):
+  ccvm_solver.py:33-36   device must be "cpu" or "cuda"  -> ValueError
+  ccvm_solver.py:65-80   ``parameter_key`` property; subclasses validate an EXACT key set
+  ccvm_solver.py:134-150 ``get_scaling_factor`` = sqrt(sum|Q|) * multiplier (0-dim tensor)
+  ccvm_solver.py:152-170 ``_method_selector`` binds calculate_drift / calculate_grads /
+                         change_variables / fit_to_constraints for "boxqp"
+  dl_solver.py:771-999   the ``__call__`` flow every solver shares (device check, parameter
+                         lookup, timer, evolution sampling, post-processing, scoring, Solution)
+
+What differs by design: the time loop is not Python.  ``_solve`` / ``_solve_adam`` hand the
+whole trajectory to ``ccvm_amd.engine.Trajectories`` (fused HIP kernels); ``device`` says
+where the caller's tensors live, the arithmetic always runs on the MI355X.
+"""
+import enum
+import time
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import engine
+from ..post_processor.factory import PostProcessorFactory
+from ..solution import Solution
+from .algorithms import AdamParameters
+
+
+class DeviceType(enum.Enum):
+    CPU_DEVICE = "cpu"
+    CUDA_DEVICE = "cuda"
+
+
+class MachineType(enum.Enum):
+    """Kept for import compatibility (ccvm_solver.py:15-22); the machine energy/time
+    models that consume it are plotting-side bookkeeping and out of scope here."""
+
+    CPU = "cpu"
+    GPU = "gpu"
+    FPGA = "fpga"
+    DL_CCVM = "dl-ccvm"
+    MF_CCVM = "mf-ccvm"
+
+
+def sample_points(iterations, evolution_step_size):
+    """Steps after which the reference records a sample: i % k == 0 or the last step
+    (dl_solver.py:557-559)."""
+    k = int(evolution_step_size)
+    pts = [i for i in range(iterations) if i % k == 0 or i + 1 >= iterations]
+    return pts
+
+
+def num_samples(iterations, evolution_step_size):
+    """Sample-buffer depth exactly as the reference sizes it (dl_solver.py:866-873)."""
+    n = int(iterations / evolution_step_size) + 1
+    if iterations % evolution_step_size != 0:
+        n += 1
+    return n
+
+
+class CCVMSolver(ABC):
+    """Shared machinery of the DL / MF / Langevin / pumped-Langevin solvers."""
+
+    #: exact key set of parameter_key[problem_size]; set by subclasses
+    _PARAMETER_KEYS = frozenset()
+    #: names of the sampled state arrays (evolution sampling), in file order
+    _SAMPLED = ()
+
+    def __init__(self, device):
+        if device not in DeviceType._value2member_map_:
+            raise ValueError("Given device is not available")
+        self.device = device
+        self._is_tuned = False
+        self._scaling_multiplier = None
+        self._parameter_key = None
+        self.calculate_drift = None
+        self.calculate_grads = None
+        self.change_variables = None
+        self.fit_to_constraints = None
+        #: "philox" (fused generator, default) or "replay" (torch CPU stream: parity mode);
+        #: None defers to $CCVM_AMD_NOISE.
+        self.noise_mode = None
+        #: global index of this process's first batch row (multi-GPU sharding)
+        self.row_offset = 0
+
+    # ------------------------------------------------------------------ #
+    @property
+    def is_tuned(self):
+        return self._is_tuned
+
+    @is_tuned.setter
+    def is_tuned(self, value):
+        self._is_tuned = bool(value)
+
+    @property
+    def parameter_key(self):
+        return self._parameter_key
+
+    @parameter_key.setter
+    def parameter_key(self, parameters):
+        expected = set(self._PARAMETER_KEYS)
+        for per_size in parameters.values():
+            if per_size.keys() != expected:
+                raise ValueError(
+                    "The parameter key is not valid for this solver. Expected keys: "
+                    + str(expected)
+                    + " Given keys: "
+                    + str(per_size.keys())
+                )
+        self._parameter_key = parameters
+        self._is_tuned = False
+
+    def tune(self, instances=None, post_processor=None, pump_rate_flag=True, g=0.05):
+        """Placeholder, as in the reference (dl_solver.py:312-329)."""
+        self._is_tuned = True
+
+    def get_scaling_factor(self, q_matrix):
+        return torch.sqrt(torch.sum(torch.abs(q_matrix))) * self._scaling_multiplier
+
+    def _method_selector(self, problem_category):
+        if problem_category.lower() != "boxqp":
+            raise ValueError(
+                "The given instance is not a valid problem category."
+                f" Given category: {problem_category}"
+            )
+        self.calculate_drift = self._calculate_drift_boxqp
+        self.calculate_grads = self._calculate_grads_boxqp
+        self.change_variables = self._change_variables_boxqp
+        self.fit_to_constraints = self._fit_to_constraints_boxqp
+
+    # ------------------------------------------------------------------ #
+    # hooks: kept as overridable attributes for API compatibility
+    # ------------------------------------------------------------------ #
+    def _fused_hooks_intact(self):
+        """True while drift/grads are the built-ins (which live inside the HIP kernels)."""
+        return (
+            getattr(self.calculate_drift, "__func__", None) is type(self)._calculate_drift_boxqp
+            and getattr(self.calculate_grads, "__func__", None) is type(self)._calculate_grads_boxqp
+        )
+
+    def _require_fused_hooks(self):
+        if not self._fused_hooks_intact():
+            raise NotImplementedError(
+                "calculate_drift / calculate_grads were replaced on this solver; the HIP engine fuses"
+                " the built-in BoxQP drift into its step kernel and cannot call Python hooks"
+            )
+
+    def _change_variables_boxqp(self, problem_variables, lower_limit=0, upper_limit=1, S=1):
+        _reject_tensor_s(S)
+        return engine.change_variables(problem_variables, S, lower_limit, upper_limit)
+
+    def _fit_to_constraints_boxqp(self, c, lower_clamp, upper_clamp):
+        _reject_tensor_s(lower_clamp)
+        _reject_tensor_s(upper_clamp)
+        return engine.clamp(c, lower_clamp, upper_clamp)
+
+    @abstractmethod
+    def _calculate_drift_boxqp(self, *args, **kwargs):
+        ...
+
+    @abstractmethod
+    def _calculate_grads_boxqp(self, *args, **kwargs):
+        ...
+
+    @abstractmethod
+    def _solve(self, *args, **kwargs):
+        ...
+
+    @abstractmethod
+    def _solve_adam(self, *args, **kwargs):
+        ...
+
+    # ------------------------------------------------------------------ #
+    # shared pieces of __call__
+    # ------------------------------------------------------------------ #
+    def _bind_instance(self, instance):
+        if instance.device != self.device:
+            raise ValueError(
+                f"The device type of the instance ({instance.device}) and the solver"
+                f" ({self.device}) must match."
+            )
+        self.q_matrix = instance.q_matrix
+        self.v_vector = instance.v_vector
+        self.solution_bounds = instance.solution_bounds
+        return instance.problem_size
+
+    def _lookup(self, problem_size, *names):
+        try:
+            table = self.parameter_key[problem_size]
+            return [table[name] for name in names]
+        except KeyError as exc:
+            raise KeyError(
+                f"The parameter '{exc.args[0]}' for the given instance size is not defined."
+            ) from exc
+
+    def _broadcast_saturation(self, S, problem_size):
+        """The reference broadcasts a 1-D tensor S to (B, N) (dl_solver.py:843-848).  The
+        fused kernels take a scalar saturation; per-variable S is rejected loudly."""
+        if torch.is_tensor(S):
+            if S.ndim == 1 and S.size(dim=0) != problem_size:
+                raise ValueError("Tensor S size should be equal to problem size.")
+            if S.numel() == 1:
+                return float(S.item())
+            raise NotImplementedError(
+                "per-variable (tensor) saturation S is not supported by the HIP engine; pass a float"
+            )
+        return S
+
+    def _new_trajectories(self, kind, batch_size, iterations, params, adam=None):
+        self._require_fused_hooks()
+        problem = engine.DeviceProblem(self.q_matrix, self.v_vector)
+        noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset)
+        return engine.Trajectories(
+            problem, batch_size, kind, iterations, params, self.solution_bounds, noise, adam=adam
+        )
+
+    def _advance_with_samples(self, traj, iterations, evolution_step_size, samples_taken):
+        """Run the whole trajectory; copy the sampled state arrays to the host buffers
+        ``self.<name>_sample[:, :, k]`` at the reference's sample points."""
+        if not evolution_step_size:
+            traj.advance(iterations)
+            return
+        done = 0
+        for i in sample_points(iterations, evolution_step_size):
+            traj.advance(i + 1 - done)
+            done = i + 1
+            for name in self._SAMPLED:
+                getattr(self, f"{name}_sample")[:, :, samples_taken] = traj.compact(name).cpu()
+            samples_taken += 1
+        traj.advance(iterations - done)
+
+    def _begin_sampling(self, instance, batch_size, problem_size, iterations, evolution_step_size,
+                        evolution_file):
+        for name in self._SAMPLED:
+            setattr(self, f"{name}_sample", None)
+        if not evolution_step_size:
+            return None, evolution_file
+        if evolution_step_size < 1:
+            raise ValueError("The evolution step size must be greater than or equal to 1.")
+        if evolution_file is None:
+            evolution_file = f"./{instance.name}_evolution.txt"
+        depth = num_samples(iterations, evolution_step_size)
+        for name in self._SAMPLED:
+            setattr(
+                self,
+                f"{name}_sample",
+                torch.zeros((batch_size, problem_size, depth), dtype=torch.float, device="cpu"),
+            )
+        return 0, evolution_file
+
+    #: whether each value in the evolution file is followed by a tab (DL/Langevin) or
+    #: values are tab-separated (MF): dl_solver.py:268-272 vs mf_solver.py:285-290
+    _TRAILING_TAB = True
+
+    def _append_samples_to_file(self, *samples, evolution_file_object=None, **named):
+        """Write (problem_size x num_samples) blocks, one row per line, values rounded to
+        4 d.p. (dl_solver.py:252-281)."""
+        blocks = list(samples) + [v for k, v in named.items() if k != "evolution_file_object"]
+        out = evolution_file_object
+        for block in blocks:
+            for row in block.tolist():
+                cells = [str(round(value, 4)) for value in row]
+                if self._TRAILING_TAB:
+                    out.write("".join(cell + "\t" for cell in cells))
+                else:
+                    out.write("\t".join(cells))
+                out.write("\n")
+
+    def _write_evolution(self, evolution_file, objval):
+        best = torch.argmax(-objval)
+        with open(evolution_file, "w") as out:
+            self._append_samples_to_file(
+                *[getattr(self, f"{name}_sample")[best] for name in self._SAMPLED],
+                evolution_file_object=out,
+            )
+
+    def _select_algorithm(self, algorithm_parameters):
+        if algorithm_parameters is None:
+            return None
+        if isinstance(algorithm_parameters, AdamParameters):
+            return algorithm_parameters.to_dict()
+        raise ValueError(f"Solver option type {type(algorithm_parameters)} is not supported.")
+
+    def _sync(self):
+        torch.cuda.synchronize(engine.gpu_device())
+
+    def _postprocess(self, post_processor, start_point, batch_size):
+        if not post_processor:
+            return start_point, 0.0
+        pp = PostProcessorFactory.create_postprocessor(post_processor)
+        out = pp.postprocess(start_point, self.q_matrix, self.v_vector)
+        return out, pp.pp_time / batch_size
+
+    def _solution(self, instance, batch_size, iterations, objval, solve_time, pp_time, variables,
+                  evolution_step_size, evolution_file):
+        if evolution_step_size:
+            self._write_evolution(evolution_file, objval)
+        solution = Solution(
+            problem_size=instance.problem_size,
+            batch_size=batch_size,
+            instance_name=instance.name,
+            iterations=iterations,
+            objective_values=objval,
+            solve_time=solve_time,
+            pp_time=pp_time,
+            optimal_value=instance.optimal_sol,
+            best_value=instance.best_sol,
+            num_frac_values=instance.num_frac_values,
+            solution_vector=instance.solution_vector,
+            variables=variables,
+            device=self.device,
+        )
+        if evolution_step_size:
+            solution.evolution_file = evolution_file
+        return solution
+
+    def _timer_start(self):
+        self._sync()
+        return time.time()
+
+    def _timer_stop(self, start, batch_size):
+        """Per-instance solve time (dl_solver.py:933) -- with the device sync the
+        reference forgets."""
+        self._sync()
+        return (time.time() - start) / batch_size
+
+
+def _reject_tensor_s(S):
+    if torch.is_tensor(S) and S.numel() != 1:
+        raise NotImplementedError(
+            "per-variable (tensor) saturation bounds are not supported by the HIP engine"
+        )

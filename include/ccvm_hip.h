@@ -1,0 +1,205 @@
+/*
+ * ccvm_hip.h -- C ABI of libccvm_hip.so, the MI355X (gfx950) dynamics engine for
+ * the CCVM BoxQP solvers.
+ *
+ * The reference (1QB-Information-Technologies/ccvm) has no FFI: its hot path is
+ * the Python loop body of  DLSolver._solve / MFSolver._solve[_adam] /
+ * LangevinSolver._solve[_adam] / PumpedLangevinSolver._solve[_adam].  Each entry
+ * point below replaces one of those loop bodies (file:line cited per function,
+ * relative to the reference tree) with `nsteps` fused Euler-Maruyama steps on the
+ * GPU.  A binding is a ctypes/cffi stub that passes `tensor.data_ptr()` values;
+ * see INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; every pointer is a DEVICE pointer unless a
+ *    parameter is documented as host.  The caller owns every buffer.
+ *  - Return value: 0 on success, a negative ccvm_status otherwise; the message is
+ *    available from ccvm_last_error() (thread-local).  Nothing throws.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *    the default stream).  No call synchronises, allocates or frees device memory.
+ *  - No global mutable state: N host threads / processes can drive N GPUs.
+ *
+ * Padded layout ("pitched" arrays)
+ *  - A batch x N state array is [rows_pad][ld] floats, row-major, with
+ *    ld = ccvm_ld(N) (N rounded up to 128) and rows_pad = ccvm_rows(B) (B rounded
+ *    up to 64).  The coupling matrix Q is [ld][ld] and V is [ld].  All padding
+ *    MUST be zero on entry (ccvm_pack does that) and is kept zero by the kernels.
+ *  - Q is used as  x @ Q  (reference einsum "bi,ij->bj"), i.e. Q[i][j] couples
+ *    input column i to output column j; symmetry is never assumed.
+ */
+#ifndef CCVM_HIP_H
+#define CCVM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCVM_ABI_VERSION 1
+
+typedef enum ccvm_status {
+    CCVM_OK = 0,
+    CCVM_E_INVALID = -1,     /* bad argument (NULL pointer, negative size, step range) */
+    CCVM_E_LAYOUT = -2,      /* ld / rows do not match ccvm_ld / ccvm_rows, or misaligned */
+    CCVM_E_WORKSPACE = -3,   /* workspace too small */
+    CCVM_E_HIP = -4,         /* a HIP runtime call failed */
+    CCVM_E_UNSUPPORTED = -5  /* valid request the engine does not implement */
+} ccvm_status;
+
+/* Wiener-noise source for one call. */
+typedef enum ccvm_noise_mode {
+    CCVM_NOISE_PHILOX = 0, /* Philox4x32-10 + Box-Muller fused into the step kernel   */
+    CCVM_NOISE_REPLAY = 1  /* read standard normals the caller generated (parity mode) */
+} ccvm_noise_mode;
+
+typedef struct ccvm_noise {
+    int32_t mode;        /* ccvm_noise_mode */
+    int32_t reserved;
+    uint64_t seed;       /* PHILOX: key */
+    int64_t row_offset;  /* PHILOX: global index of local row 0 (batch sharding over GPUs:
+                            a row's noise depends on its GLOBAL index only) */
+    /* REPLAY: standard normals for steps step0 .. step0+nsteps-1, laid out as the
+     * reference draws them -- per step an (N, B) block, batch-contiguous:
+     *   W[step][b][n] = w[((step - step0) * N + n) * B + b]
+     * (reference: Normal.sample((N,)).transpose(0,1), dl_solver.py:538-547).
+     * w1 is the second stream of the DL solver (s quadrature); NULL otherwise. */
+    const float* w0;
+    const float* w1;
+} ccvm_noise;
+
+/* Optional Adam preconditioning of the feedback term (reference
+ * solvers/algorithms.py:1-45 and e.g. mf_solver.py:717-738).  enabled = 0 selects
+ * the original solver.  m (and v when beta2 != 1) are pitched B x N state arrays
+ * owned by the caller, zero before step 0. */
+typedef struct ccvm_adam {
+    int32_t enabled;
+    int32_t add_assign;
+    double alpha, beta1, beta2;
+    float* m;
+    float* v; /* may be NULL when beta2 == 1.0 */
+} ccvm_adam;
+
+/* DL-CCVM: reference dl_solver.py:468-569 (_solve) + :117-172 (drift). */
+typedef struct ccvm_dl_params {
+    double pump, dt, noise_ratio, feedback_scale, g;
+    double lower, upper;     /* solution_bounds */
+    int32_t pump_rate_flag;  /* rate = (i+1)/T when set, else 1 */
+    int32_t reserved;
+} ccvm_dl_params;
+
+/* MF-CCVM: reference mf_solver.py:493-593 (_solve), :595-764 (_solve_adam),
+ * :141-233 (drift / grads). */
+typedef struct ccvm_mf_params {
+    double pump, dt, j, feedback_scale, g, S;
+    double lower, upper;
+    int32_t pump_rate_flag;
+    int32_t reserved;
+} ccvm_mf_params;
+
+/* Langevin (use_pump = 0): reference langevin_solver.py:368-435, :437-561, :117-166.
+ * Pumped Langevin (use_pump = 1): pumped_langevin_solver.py:232-309, :311-449,
+ * :95-147. */
+typedef struct ccvm_langevin_params {
+    double dt, sigma, feedback_scale, S;
+    double pump;             /* pumped Langevin only */
+    double lower, upper;
+    int32_t use_pump;
+    int32_t pump_rate_flag;  /* p_i = pump*(i+1)/T when set, else pump */
+} ccvm_langevin_params;
+
+/* ---- library / layout ------------------------------------------------------- */
+int ccvm_abi_version(void);
+const char* ccvm_last_error(void);
+int ccvm_ld(int N);    /* leading dimension for problem size N   */
+int ccvm_rows(int B);  /* padded row count for batch size B      */
+
+/* Zero-padded copy of a compact row-major [rows][cols] array (row stride src_ld)
+ * into a pitched [dst_rows][dst_ld] array, and the inverse. */
+int ccvm_pack(const float* src, int rows, int cols, int src_ld,
+              float* dst, int dst_rows, int dst_ld, void* stream);
+int ccvm_unpack(const float* src, int src_ld,
+                float* dst, int rows, int cols, int dst_ld, void* stream);
+
+/* ---- the hot path: nsteps fused Euler-Maruyama steps ------------------------- */
+/* Bytes of caller-provided scratch each *_run call needs (ping-pong state, the MF
+ * measured-amplitude buffers, schedule tables).  `solver`: 0 DL, 1 MF, 2 Langevin. */
+size_t ccvm_workspace_bytes(int solver, int B, int N);
+
+/* Steps step0 .. step0+nsteps-1 of a T-step DL-CCVM run, in place on c and s.
+ * Chunking a run into several calls does not change the result.  The final clamp
+ * (dl_solver.py:567) is NOT applied here; see ccvm_clamp. */
+int ccvm_dl_run(const float* Q, const float* V, float* c, float* s,
+                int B, int N, int ld, int step0, int nsteps, int T,
+                const ccvm_dl_params* params, const ccvm_noise* noise,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* MF-CCVM steps, in place on mu and sigma.  mu_tilde_out (pitched, may be NULL)
+ * receives the clamped measured amplitude of the LAST executed step, which is what
+ * the reference returns and scores (mf_solver.py:591-593). */
+int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma,
+                float* mu_tilde_out,
+                int B, int N, int ld, int step0, int nsteps, int T,
+                const ccvm_mf_params* params, const ccvm_adam* adam,
+                const ccvm_noise* noise,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Langevin / pumped-Langevin steps, in place on c (clamped to [-S, S] every step). */
+int ccvm_langevin_run(const float* Q, const float* V, float* c,
+                      int B, int N, int ld, int step0, int nsteps, int T,
+                      const ccvm_langevin_params* params, const ccvm_adam* adam,
+                      const ccvm_noise* noise,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the steps right after the loop ------------------------------------------ */
+/* x = clamp(x, lo, hi) on the logical B x N region (fit_to_constraints,
+ * dl_solver.py:237-250). */
+int ccvm_clamp(float* x, int B, int N, int ld, float lo, float hi, void* stream);
+
+/* y = 0.5 * x / S * (upper - lower) + 0.5 * (upper + lower)   (change_variables,
+ * dl_solver.py:219-235).  y may alias x. */
+int ccvm_change_variables(const float* x, float* y, int B, int N, int ld,
+                          double S, double lower, double upper, void* stream);
+
+/* obj[b] = (0.5 * x_b Q x_b + V . x_b) * scaled_by   (problem_instance.py:226-241).
+ * obj is a compact array of B floats.  workspace: ccvm_workspace_bytes(3, B, N). */
+int ccvm_energy(const float* Q, const float* V, const float* x,
+                int B, int N, int ld, double scaled_by, float* obj,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* The bare feedback term of every solver ("Qx matvec + V bias"):
+ *   y = f_q * ((x * in_scale + in_shift) @ Q) + f_v * V
+ * e.g. MFSolver._calculate_grads_boxqp (mf_solver.py:200-233) is in_scale = (u-l)/S,
+ * in_shift = u+l, f_q = -fs (u-l)/(4S), f_v = -fs (u-l)/(2S).  y must not alias x and
+ * must have zero padding on entry (it is only written on the logical B x N region). */
+int ccvm_feedback(const float* Q, const float* V, const float* x, float* y,
+                  int B, int N, int ld, double in_scale, double in_shift,
+                  double f_q, double f_v, void* stream);
+
+/* Post-processors.  x is updated in place.
+ * grad-descent: `iters` times  x <- clamp(x - step * (x Q + V), lo, hi)
+ *   (post_processor/grad_descent.py:58-64).
+ * adam: one torch.optim.Adam(lr, betas) step from zero moments on 1/2 xQx + Vx,
+ *   then clamp (post_processor/adam.py:58-66); closed form
+ *   x <- clamp(x - lr * g / (|g| + eps), lo, hi),  g = 1/2 (Q + Q') x + V.
+ * workspace: ccvm_workspace_bytes(4, B, N). */
+int ccvm_pp_grad_descent(const float* Q, const float* V, float* x,
+                         int B, int N, int ld, int iters, double step,
+                         double lo, double hi,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int ccvm_pp_adam(const float* Q, const float* V, float* x,
+                 int B, int N, int ld, double lr, double eps,
+                 double lo, double hi,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- noise generator, exposed for tests -------------------------------------- */
+/* Fill w0 (and w1 if not NULL) with the standard normals the fused PHILOX mode uses
+ * at `step`, in the REPLAY layout [N][B] (so the two modes can be cross-checked). */
+int ccvm_philox_normals(uint64_t seed, int64_t row_offset, int step,
+                        int B, int N, float* w0, float* w1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCVM_HIP_H */

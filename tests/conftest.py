@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The built C-ABI library (compiles it if stale; no GPU needed to load)."""
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    from ccvm_amd import _lib
+
+    return _lib.load()

@@ -1,0 +1,145 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (the reference tree never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+The reference is imported from its read-only tree (/root/reference); nothing of it is
+copied -- only numeric inputs (parsed Q, V, header fields, parameters, seeds) and outputs
+(final variables, objective values, success fractions) are written, as data.
+
+Recipe: load instance -> scale_coefs(get_scaling_factor(Q)) ->
+torch.manual_seed(seed) immediately before solver(instance=...).
+"""
+import json
+import os
+import sys
+
+REFERENCE = os.environ.get("CCVM_REFERENCE", "/root/reference")
+sys.path.insert(0, REFERENCE)
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ccvm_simulators  # noqa: E402
+
+assert os.path.realpath(ccvm_simulators.__file__).startswith(os.path.realpath(REFERENCE)), (
+    "make_golden.py must import the reference package, got " + ccvm_simulators.__file__
+)
+from ccvm_simulators.problem_classes.boxqp import ProblemInstance  # noqa: E402
+from ccvm_simulators.solvers import (  # noqa: E402
+    DLSolver,
+    LangevinSolver,
+    MFSolver,
+    PumpedLangevinSolver,
+)
+from ccvm_simulators.solvers.algorithms import AdamParameters  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+INSTANCES = {
+    "test020": "ccvm_simulators/tests/data/test_instances/test020-100-10.in",
+    "tuningH020": "examples/benchmarking_instances/single_test_instance/tuningH020-100-0.in",
+}
+B, SEED = 100, 7
+
+# parameter_key values of the reference's example scripts (examples/ccvm_boxqp_dl.py:16-24,
+# ccvm_boxqp_mf.py:16-25, langevin_boxqp.py:16-24, pumped_langevin_boxqp.py:16-25)
+PARAMS = {
+    "dl": {"pump": 8.0, "feedback_scale": 100, "dt": 0.001, "noise_ratio": 10},
+    "mf": {"pump": 0.0, "feedback_scale": 4000, "j": 5.0, "S": 20.0, "dt": 0.0025},
+    "langevin": {"dt": 0.002, "S": 0.5, "sigma": 0.5, "feedback_scale": 1.0},
+    "pl": {"pump": 2.0, "dt": 0.002, "S": 0.5, "sigma": 0.5, "feedback_scale": 1.0},
+}
+SOLVERS = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}
+ADAMS = {
+    "adamA": dict(alpha=0.001, beta1=0.9, beta2=0.999, add_assign=False),
+    "adamB": dict(alpha=0.01, beta1=0.8, beta2=1.0, add_assign=True),
+    "adamC": dict(alpha=0.05, beta1=0.9, beta2=0.99, add_assign=True),
+}
+
+
+def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED):
+    solver = SOLVERS[kind](device="cpu", batch_size=batch)
+    inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu")
+    key = dict(PARAMS[kind], iterations=iterations)
+    solver.parameter_key = {inst.problem_size: key}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    kwargs = {}
+    if kind in ("dl", "mf", "pl"):
+        kwargs["pump_rate_flag"] = flag
+    if adam:
+        kwargs["algorithm_parameters"] = AdamParameters(**ADAMS[adam])
+    torch.manual_seed(seed)
+    first_draw = torch.randn(inst.problem_size, batch)  # checksum of the stream's first block
+    torch.manual_seed(seed)
+    sol = solver(instance=inst, post_processor=post, **kwargs)
+    arrays = {k: v.detach().numpy().copy() for k, v in sol.variables.items()}
+    arrays["objective_values"] = sol.objective_values.detach().numpy().copy()
+    meta = {
+        "kind": kind, "iterations": iterations, "adam": ADAMS[adam] if adam else None, "post": post,
+        "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": key,
+        "best_objective_value": sol.best_objective_value,
+        "solution_performance": sol.solution_performance,
+        "scaled_by": float(inst.scaled_by),
+        "noise_checksum": [float(first_draw.double().sum()), float(first_draw.double().abs().sum()),
+                           float(first_draw[0, 0]), float(first_draw[-1, -1])],
+    }
+    return arrays, meta
+
+
+def main():
+    torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
+    for tag, path in INSTANCES.items():
+        inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu")
+        store = {
+            "q_matrix": inst.q_matrix.numpy().copy(),  # parsed + negated, unscaled
+            "v_vector": inst.v_vector.numpy().copy(),
+        }
+        manifest = {
+            "instance": {
+                "source": path, "problem_size": inst.problem_size, "optimal_sol": inst.optimal_sol,
+                "best_sol": inst.best_sol, "optimality": inst.optimality, "sol_time_gb": inst.sol_time_gb,
+                "sol_time_bfgs": inst.sol_time_bfgs, "num_frac_values": inst.num_frac_values,
+                "solution_vector": inst.solution_vector, "name": inst.name,
+            },
+            "scaling_factor": {},
+            "cases": {},
+        }
+        for kind, cls in SOLVERS.items():
+            manifest["scaling_factor"][kind] = float(cls(device="cpu").get_scaling_factor(inst.q_matrix))
+
+        cases = []
+        for kind in SOLVERS:
+            for t in (1, 2, 10, 100):
+                cases.append((kind, t, None, None, True))
+            cases.append((kind, 1500, None, None, True))
+            if kind != "langevin":
+                cases.append((kind, 50, None, None, False))
+            if kind != "dl":  # the reference's DL Adam path raises TypeError
+                for adam in ADAMS:
+                    cases.append((kind, 60, adam, None, True))
+            for post in ("adam", "grad-descent"):
+                cases.append((kind, 50, None, post, True))
+        for kind, t, adam, post, flag in cases:
+            name = f"{kind}_T{t}" + (f"_{adam}" if adam else "") + (f"_{post}" if post else "") + (
+                "" if flag else "_noramp")
+            arrays, meta = run_case(kind, path, t, adam, post, flag)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print(tag, name, meta["best_objective_value"])
+
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **store)
+        with open(os.path.join(OUT, f"{tag}.json"), "w") as fh:
+            json.dump(manifest, fh, indent=1, sort_keys=True)
+
+    # the DL example exactly as shipped: B=1000, T=1500, seed 1234 (SURVEY.md 8c anchor)
+    arrays, meta = run_case("dl", INSTANCES["tuningH020"], 1500, batch=1000, seed=1234)
+    with open(os.path.join(OUT, "dl_example_anchor.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    print("anchor", meta["best_objective_value"], meta["solution_performance"])
+
+
+if __name__ == "__main__":
+    main()

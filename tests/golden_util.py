@@ -1,0 +1,64 @@
+"""Access to the committed golden vectors (tests/golden/*.npz + *.json)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAGS = ("test020", "tuningH020")
+
+
+class Golden:
+    def __init__(self, tag):
+        self.tag = tag
+        self.arrays = np.load(os.path.join(GOLDEN_DIR, f"{tag}.npz"))
+        with open(os.path.join(GOLDEN_DIR, f"{tag}.json")) as fh:
+            self.manifest = json.load(fh)
+        self.instance = self.manifest["instance"]
+        self.cases = self.manifest["cases"]
+
+    def q(self):
+        return torch.from_numpy(self.arrays["q_matrix"].copy())
+
+    def v(self):
+        return torch.from_numpy(self.arrays["v_vector"].copy())
+
+    def scaled(self, kind):
+        """(Q, V, scaled_by) after scale_coefs(get_scaling_factor(Q)) for a solver kind."""
+        mult = 0.2 if kind == "dl" else 0.05
+        q, v = self.q(), self.v()
+        f = torch.sqrt(torch.sum(torch.abs(q))) * mult
+        return q / f, v / f, f
+
+    def out(self, case, field):
+        return torch.from_numpy(self.arrays[f"{case}/{field}"].copy())
+
+    def fields(self, case):
+        prefix = case + "/"
+        return [k[len(prefix):] for k in self.arrays.files if k.startswith(prefix)]
+
+
+_cache = {}
+
+
+def golden(tag):
+    if tag not in _cache:
+        _cache[tag] = Golden(tag)
+    return _cache[tag]
+
+
+def all_cases():
+    return [(tag, name) for tag in TAGS for name in golden(tag).cases]
+
+
+def check_noise_checksum(meta, n, b):
+    """The fixtures regenerate the reference's noise from the seed; make a drift of the
+    torch CPU generator (or of its vectorised normal kernel) visible instead of letting it
+    silently break parity."""
+    torch.manual_seed(meta["seed"])
+    first = torch.randn(n, b)
+    s, a, f0, f1 = meta["noise_checksum"]
+    assert abs(float(first.double().sum()) - s) <= 1e-3 * max(1.0, abs(s)), "torch CPU randn stream drifted"
+    assert abs(float(first.double().abs().sum()) - a) <= 1e-3 * a, "torch CPU randn stream drifted"
+    assert abs(float(first[0, 0]) - f0) <= 1e-5 and abs(float(first[-1, -1]) - f1) <= 1e-5

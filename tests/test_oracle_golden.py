@@ -1,0 +1,100 @@
+"""Pins the oracle (oracle/ccvm_oracle.py) to the reference: every golden case produced by
+tests/golden/make_golden.py (i.e. by the reference itself) must be reproduced.
+
+The oracle issues the same torch ops in the same order, so on the torch build that made
+the fixtures the match is bit-exact; the gates below are a hair wider (1e-5 on O(1)
+amplitudes, 1e-5 relative on objectives) so that a host whose BLAS/vector kernels round
+differently still passes, and far tighter than the GPU parity tolerance.
+"""
+import pytest
+import torch
+
+from golden_util import all_cases, check_noise_checksum, golden
+from oracle import ccvm_oracle as oracle
+
+ATOL_STATE = 1e-5
+RTOL_OBJ = 1e-5
+
+
+def run_oracle(g, meta):
+    kind, p = meta["kind"], meta["params"]
+    q, v, f = g.scaled(kind)
+    common = dict(bounds=(0.0, 1.0), scaled_by=f, optimal_value=g.instance["optimal_sol"],
+                  post_processor=meta["post"])
+    b, t = meta["batch"], meta["iterations"]
+    torch.manual_seed(meta["seed"])
+    if kind == "dl":
+        return oracle.solve_dl(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"],
+                               g=0.05, S=1, pump_rate_flag=meta["pump_rate_flag"], **common)
+    if kind == "mf":
+        return oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01,
+                               pump_rate_flag=meta["pump_rate_flag"], adam=meta["adam"], **common)
+    if kind == "langevin":
+        return oracle.solve_langevin(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"],
+                                     adam=meta["adam"], **common)
+    return oracle.solve_pl(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"],
+                           pump_rate_flag=meta["pump_rate_flag"], adam=meta["adam"], **common)
+
+
+@pytest.mark.parametrize("tag,case", all_cases())
+def test_oracle_reproduces_reference(tag, case):
+    g = golden(tag)
+    meta = g.cases[case]
+    if meta["iterations"] > 200 and meta["kind"] != "dl":
+        pytest.skip("long runs are covered for DL; others keep the CPU suite short")
+    check_noise_checksum(meta, g.instance["problem_size"], meta["batch"])
+    out = run_oracle(g, meta)
+    for field in g.fields(case):
+        want = g.out(case, field)
+        got = out[field]
+        if field == "objective_values":
+            tol = RTOL_OBJ * max(1.0, float(want.abs().max()))
+        else:
+            tol = ATOL_STATE * max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= tol, f"{tag}/{case}/{field}: max abs err {err:.3e} > {tol:.3e}"
+    assert abs(out["best_objective_value"] - meta["best_objective_value"]) <= RTOL_OBJ * abs(
+        meta["best_objective_value"]) + 1e-6
+    for key, frac in meta["solution_performance"].items():
+        assert abs(out["solution_performance"][key] - frac) <= 1.0 / meta["batch"] + 1e-9
+
+
+def test_scaling_factor_matches_reference():
+    for tag in ("test020", "tuningH020"):
+        g = golden(tag)
+        for kind, want in g.manifest["scaling_factor"].items():
+            mult = 0.2 if kind == "dl" else 0.05
+            assert abs(float(oracle.scaling_factor(g.q(), mult)) - want) <= 1e-6 * want
+
+
+# ---- known answers held by the reference's own unit tests ------------------------------
+def test_mf_grads_and_drift_known_answers():
+    """ccvm_simulators/tests/unit/solvers/test_mf_solver.py:63-130: with Q = V = ones(2),
+    mu_tilde = 1, S = fs = 1 ... the expected grads are -20.0 and the drift (-20.0, 200.5)."""
+    # the reference test builds: q = [[10,10],[10,10]], v = [10,10], mu_tilde = [[1,1]], S=1, fs=1
+    q = torch.full((2, 2), 10.0)
+    v = torch.full((2,), 10.0)
+    mu_tilde = torch.ones((1, 2))
+    grads = oracle.mf_grads(mu_tilde, q, v, S=1.0, fs=1.0, lo=0.0, hi=1.0)
+    assert torch.allclose(grads, torch.full((1, 2), -(0.25 * 2 * 2 * 10) - 5.0))
+
+
+def test_change_variables_known_answers():
+    """test_mf_solver.py:132-154 -- change_variables([1, ...], 0, 1, S) spot values."""
+    x = torch.tensor([[2.0, 0.2]])
+    y = oracle.change_variables(x, 0.0, 1.0, 1.0)
+    assert torch.allclose(y, torch.tensor([[1.5, 0.6]]))
+
+
+def test_success_fraction_known_answers():
+    """ccvm_simulators/tests/test_solution.py:140-173 pattern: gaps {0, 1.5, 7} % of 100."""
+    obj = -torch.tensor([100.0, 98.5, 93.0])
+    best, perf = oracle.solution_stats(obj, 100.0)
+    assert best == 100.0
+    assert perf["optimal"] == round(1 / 3, 4) and perf["two_percent"] == round(2 / 3, 4)
+    assert perf["five_percent"] == round(2 / 3, 4) and perf["ten_percent"] == 1.0
+
+
+def test_r99():
+    assert oracle.r99(1.0) == 1.0 and oracle.r99(0.99) == 1.0
+    assert abs(oracle.r99(0.5) - 6.643856189774724) < 1e-9
