@@ -1,0 +1,196 @@
+"""Headline benchmark: SDE row-steps/s of the DL-CCVM inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused Euler-Maruyama update of every batch row.  Workload (BASELINE.json
+`metric`): DL-CCVM, N = 1000 synthetic dense BoxQP, batch 1000 PER GPU (weak scaling: the
+8-GPU run is BASELINE config 4, batch 8000 sharded 1000/GPU), fp32, fused Philox noise.
+Ranks are independent (batch rows never interact); the only collective is one RCCL
+all-gather of the final objective values, outside the timed region like the reference's
+own timer (dl_solver.py:851/933 brackets the loop only).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (solver kind, N, batch per GPU, flops per row-step)
+    "dl_n1000_b1000": ("dl", 1000, 1000),
+    "dl_n100_b1000": ("dl", 100, 1000),
+    "mf_n500_b1000": ("mf", 500, 1000),
+    "langevin_n500_b1000": ("langevin", 500, 1000),
+    "pl_n2000_b512": ("pl", 2000, 512),
+}
+
+
+def make_trajectories(kind, n, b, total_steps, rank, seed=1):
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    q, v, _ = scaled_qv(n, kind)
+    prob = engine.DeviceProblem(q, v)
+    p = dict(EXAMPLE_PARAMS[kind])
+    noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=rank * b)
+    if kind == "dl":
+        p["g"] = 0.05
+        return engine.Trajectories(prob, b, "dl", total_steps, p, (0.0, 1.0), noise), q, v
+    if kind == "mf":
+        p["g"] = 0.01
+        return engine.Trajectories(prob, b, "mf", total_steps, p, (0.0, 1.0), noise), q, v
+    p["use_pump"] = kind == "pl"
+    return engine.Trajectories(prob, b, "langevin", total_steps, p, (0.0, 1.0), noise), q, v
+
+
+def cpu_baseline(kind, n, b, total_steps, budget_s=12.0):
+    """The oracle (torch CPU restatement of the reference loop, bit-identical to it on this
+    torch build) timed on the host cores on a bounded sample of the same workload."""
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from oracle import ccvm_oracle as oracle
+
+    assert kind == "dl"
+    q, v, _ = scaled_qv(n, kind)
+    p = EXAMPLE_PARAMS[kind]
+    torch.manual_seed(1)
+    c = torch.zeros((b, n)); s = torch.zeros((b, n))
+    run = lambda step0, k: oracle.dl_loop(q, v, b, total_steps, p["pump"], p["dt"], p["noise_ratio"],
+                                          p["feedback_scale"], 0.05, (0.0, 1.0), True, None, step0, k, c, s)
+    run(0, 2)  # warm-up (first-call overheads)
+    done, t0 = 2, time.time()
+    while time.time() - t0 < budget_s and done + 5 <= total_steps:
+        run(done, 5)
+        done += 5
+    dt = time.time() - t0
+    steps = done - 2
+    return {
+        "value": b * steps / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{steps} steps of the same workload (N={n}, batch={b}) on the host, "
+                  f"{dt / steps * 1e3:.1f} ms/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dl_n1000_b1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kind, n, b = WORKLOADS[args.workload]
+    total = args.warmup + args.steps
+    traj, q, v = make_trajectories(kind, n, b, total, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    traj.advance(args.warmup)
+    torch.cuda.synchronize(dev)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    traj.advance(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg per step launch on the launch stream
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # the step right after the loop + the one collective: gather objective values (RCCL)
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import scaled_qv
+
+    if kind == "dl":
+        traj.clamp("c", -1.0, 1.0)
+        x = engine.change_variables(traj.compact("c"), 1.0, 0.0, 1.0)
+    elif kind == "mf":
+        x = engine.change_variables(traj.compact("mu_tilde"), 20.0, 0.0, 1.0)
+    else:
+        x = engine.change_variables(traj.compact("c"), 0.5, 0.0, 1.0)
+    _, _, f = scaled_qv(n, kind)
+    obj = engine.energy(x, q, v, float(f))
+    finite = bool(torch.isfinite(obj).all().item())
+    if world > 1:
+        gathered = [torch.empty_like(obj) for _ in range(world)]
+        dist.all_gather(gathered, obj)
+        obj = torch.cat(gathered)
+    best = float((-obj).max().item())
+
+    if rank == 0:
+        na = 2 if kind == "dl" else 1
+        flops_per_launch = 2.0 * na * n * n * b
+        bytes_per_launch = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
+        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "SDE row-steps/s (Euler-Maruyama steps/s x batch), DL-CCVM N=1000 batch=1000 per GPU",
+            "value": args.steps * b * world / elapsed,
+            "unit": "row-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
+                            f"batch {b} per GPU x {world} GPU, fp32 state, fused Philox noise, "
+                            f"schedule of a {total}-step run",
+                "global_batch": b * world,
+                "parallelism": f"batch-sharded x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "ccvm::step_kernel", "avg_launch_us": kernel_ms * 1e3,
+                "hbm_algorithmic_GBps": bytes_per_launch / (kernel_ms * 1e-3) / 1e9,
+                "hbm_frac": bytes_per_launch / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            },
+            "check": {"objective_values_finite": finite, "best_objective_value": best},
+        }
+        if world == 1 and kind == "dl" and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, n, b, total)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ccvm_philox.h"
 
 namespace ccvm {
@@ -135,12 +137,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int MODE, bool ADAM>
+template <int NA>
+struct Frags {
+    f32x4 a[NA][4];  // lane (row l31, half h): k = 16h .. 16h+15 of the tile, 4 x b128
+    float b[16];     // Q[k = 16h + m][col 32w + l31]
+};
+
+constexpr int NSTAGE = 3;          // LDS ring: tile t computing (in registers), t+1 readable, t+2 being written
+constexpr int NOISE_SLOTS = 2;     // normals kept per element (DL: c,s; MF: this step, next step)
+
+// ABL: ablation bits for tools/ablate.hip (0 in the product): 1 no global loads in the loop,
+// 2 no ring writes, 4 no fragment reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier.
+template <int MODE, bool ADAM, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
+    constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
     constexpr int A_TILE = BM * LDA;
     constexpr int STAGE = NA * A_TILE + KT * BN;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int NOISE_LDS = NOISY ? NOISE_SLOTS * 16 * NTHREADS : 0;
+    // one array (guide: a second __shared__ object can de-pipeline the loop)
+    __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE + NOISE_LDS];
+    float* const lds_noise = lds + NSTAGE * STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,6 +169,33 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
     const int rb = tile / a.ncb, cb = tile - rb * a.ncb;
     const int row0 = rb * BM, col0 = cb * BN;
     const int ld = a.ld;
+    const int j = col0 + 32 * wave + l31;  // this lane's output column
+    const bool col_ok = j < a.N;
+
+    // ---- epilogue operands, fetched now so their latency hides under the whole GEMM -----
+    // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
+    //   erow(r) = (r & 3) + 8 * (r >> 2) + 4 * half
+    // e0/e1: old state at that element (DL: c, s; MF: mu, sigma; others: x);
+    // e2/e3: Adam moments.  Rows >= B and columns >= N are inside the padded arrays.
+    constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
+    constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
+    float e0[16], e1[16], e2[16], e3[16];
+    const size_t ebase = (size_t)(row0 + 4 * half) * ld + j;
+    {
+        const float* p0 = (MODE == MODE_MF) ? a.st0 : a.a0;
+        const float* p1 = (MODE == MODE_MF) ? a.st1 : a.a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
+            if constexpr (HAS_E0) e0[r] = p0[idx];
+            if constexpr (HAS_E1) e1[r] = p1[idx];
+            if constexpr (ADAM) {
+                e2[r] = a.am[idx];
+                e3[r] = a.ad.use_v ? a.av[idx] : 0.0f;
+            }
+        }
+    }
+    const float vj = col_ok ? a.V[j] : 0.0f;
 
     // ---- global -> register staging addresses ------------------------------------
     const int a_r = tid >> 3, a_k = (tid & 7) << 2;   // A tile: 32 rows x 8 float4
@@ -160,27 +204,50 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
     const float* gA1 = (NA == 2) ? a.a1 + (size_t)(row0 + a_r) * ld + a_k : nullptr;
     const float* gQ = a.Q + (size_t)b_r * ld + col0 + b_c;
     const size_t q_step = (size_t)8 * ld;
+    const int sa_off = a_r * LDA + a_k;
+    const int sb_off = NA * A_TILE + b_r * BN + b_c;
 
-    f32x4 ra[NA], rq[4];
-    auto load_tile = [&](int kt) {
+    struct Staged {
+        f32x4 ra[NA], rq[4];
+    };
+    auto load_tile = [&](Staged& g, int kt) {
         const int k0 = kt * KT;
-        ra[0] = *reinterpret_cast<const f32x4*>(gA0 + k0);
-        if constexpr (NA == 2) ra[1] = *reinterpret_cast<const f32x4*>(gA1 + k0);
+        g.ra[0] = *reinterpret_cast<const f32x4*>(gA0 + k0);
+        if constexpr (NA == 2) g.ra[1] = *reinterpret_cast<const f32x4*>(gA1 + k0);
         const float* q = gQ + (size_t)k0 * ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rq[i] = *reinterpret_cast<const f32x4*>(q + i * q_step);
+        for (int i = 0; i < 4; ++i) g.rq[i] = *reinterpret_cast<const f32x4*>(q + i * q_step);
     };
-    auto store_tile = [&](int buf) {
-        float* base = lds + buf * STAGE;
+    auto store_tile = [&](const Staged& g, int stage) {
+        float* base = lds + stage * STAGE;
 #pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            f32x4 x = ra[n] * a.in_scale + a.in_shift;
-            *reinterpret_cast<f32x4*>(base + n * A_TILE + a_r * LDA + a_k) = x;
-        }
-        float* bs = base + NA * A_TILE;
+        for (int n = 0; n < NA; ++n)
+            *reinterpret_cast<f32x4*>(base + n * A_TILE + sa_off) = g.ra[n] * a.in_scale + a.in_shift;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(bs + (b_r + 8 * i) * BN + b_c) = rq[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(base + sb_off + 8 * i * BN) = g.rq[i];
+    };
+
+    // fragment read offsets inside a stage
+    const int fa = l31 * LDA + 16 * half;
+    const int fb = NA * A_TILE + (16 * half) * BN + 32 * wave + l31;
+    auto read_frags = [&](Frags<NA>& f, int stage) {
+        const float* st = lds + stage * STAGE;
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                f.a[n][q] = *reinterpret_cast<const f32x4*>(st + n * A_TILE + fa + 4 * q);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) f.b[m] = st[fb + m * BN];
+    };
+
+    // one eighth of a tile's fragments (slot sl of 8): keeps the LDS queue shallow so MFMA
+    // issue never waits behind a burst of reads
+    auto read_frags_part = [&](Frags<NA>& f, int stage, int sl) {
+        const float* st = lds + stage * STAGE;
+        if (sl < 4 * NA) f.a[sl >> 2][sl & 3] = *reinterpret_cast<const f32x4*>(st + (sl >> 2) * A_TILE + fa + 4 * (sl & 3));
+        f.b[2 * sl] = st[fb + (2 * sl) * BN];
+        f.b[2 * sl + 1] = st[fb + (2 * sl + 1) * BN];
     };
 
     f32x16 acc[NA];
@@ -188,55 +255,193 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
     for (int n = 0; n < NA; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    auto mfma_range = [&](const Frags<NA>& f, int m0, int m1) {
+#pragma unroll
+        for (int m = m0; m < m1; ++m)
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                if constexpr (ABL & 8) {
+                    acc[n][m] += f.a[n][m >> 2][m & 3] * f.b[m];  // keeps the operands live
+                } else {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[n][m >> 2][m & 3], f.b[m], acc[n], 0, 0, 0);
+                }
+            }
+    };
+
+    // Philox noise for accumulator register r of this lane, generated under the MFMAs of
+    // K tile r (sliced into the MFMA issue gaps) and parked in LDS until the epilogue.
+    // MF carries a second stream: the NEXT step's normals (for the next measured amplitude).
+    constexpr int NPH = (MODE == MODE_MF) ? 2 : 1;
+    PhiloxState ph[NPH];
+    float ph_radius[NPH];
+    auto noise_begin = [&](int r) {
+        const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) ph[i] = philox_init(a.row_offset + b, a.step + i, j);
+    };
+    auto noise_rounds = [&](int r0, int r1) {
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) philox_rounds(ph[i], a.seed, r0, r1);
+    };
+    auto noise_radius = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) ph_radius[i] = philox_radius(ph[i]);
+    };
+    auto noise_end = [&](int r) {
+        const NormalPair p = philox_pair(ph[0], ph_radius[0]);
+        lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
+        if constexpr (MODE == MODE_DL) lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
+        if constexpr (MODE == MODE_MF) lds_noise[(1 * 16 + r) * NTHREADS + tid] = philox_pair(ph[1], ph_radius[1]).n0;
+    };
+    auto make_noise = [&](int r) {
+        noise_begin(r);
+        noise_rounds(0, 10);
+        noise_radius();
+        noise_end(r);
+    };
+    const bool gen_noise = NOISY && !a.replay;
 
     const int nkt = (a.N + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0);
+    const int last = nkt - 1;
+    // Two staging register sets: the loads of tile t+4 are issued in iteration t and written
+    // to the ring in iteration t+2, ~1.6 tiles (~1.5 us) of MFMA time later.
+    Staged gs0, gs1;
+    Frags<NA> f0, f1;
+    {   // prologue: tiles 0,1 into the ring, tiles 2,3 in flight (indices clamped: a
+        // duplicate of the last tile in a ring slot nobody consumes is harmless)
+        Staged t0, t1;
+        load_tile(t0, 0);
+        load_tile(t1, min(1, last));
+        load_tile(gs0, min(2, last));
+        load_tile(gs1, min(3, last));
+        store_tile(t0, 0);
+        store_tile(t1, 1);
+    }
     __syncthreads();
+    read_frags(f0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop body starts with settled LDS counters
 
-    // fragment read offsets inside a stage
-    const int fa = l31 * LDA + 16 * half;
-    const int fb = NA * A_TILE + (16 * half) * BN + 32 * wave + l31;
+    // Iteration t, branch-free.  Eight order-pinned slots (sched_barrier(0): nothing moves
+    // across); slot s = the MFMAs of k-steps 2s, 2s+1 of tile t, plus ONE staging action
+    // (fragment reads of tile t+1 | ring write of tile t+2 | global loads of tile t+4) and ONE
+    // slice of the Philox state machine for accumulator register t, alternated with the
+    // MFMAs by sched_group_barrier so the matrix pipe never waits on VALU/LDS/VMEM issue.
+    // One barrier per tile.  Reads/writes past the last tile touch ring slots nobody consumes.
+#define CCVM_SLOT_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#define CCVM_SLOT_END(VALU_PER_MFMA)                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2 * NA; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             /* 1 MFMA      */ \
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0); /* VALU        */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             /* 1 DS read   */ \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             /* 1 DS write  */ \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             /* 1 VMEM read */ \
+    }                                                                                   \
+    __builtin_amdgcn_sched_barrier(0)
+    auto iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, Staged& g, int t, auto with_noise) {
+        constexpr bool WN = decltype(with_noise)::value;
+        constexpr int V = (24 * NPH) / (2 * NA) + 2;  // VALU ops offered per MFMA gap
+        const int k4 = min(t + 4, last) * KT;
+        float* wbase = lds + ((t + 2) % NSTAGE) * STAGE;
+        const float* q4 = gQ + (size_t)k4 * ld;
+        const int rstage = (t + 1) % NSTAGE;
+#define CCVM_READS(SL) if constexpr (!(ABL & 4)) read_frags_part(nxt, rstage, SL)
+        CCVM_SLOT_BEGIN();
+        CCVM_READS(0);
+        if constexpr (WN) { noise_begin(t); noise_rounds(0, 2); }
+        mfma_range(cur, 0, 2);
+        CCVM_SLOT_END(V);
+        CCVM_READS(1);
+        if constexpr (!(ABL & 2)) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+                *reinterpret_cast<f32x4*>(wbase + n * A_TILE + sa_off) = g.ra[n] * a.in_scale + a.in_shift;
+        }
+        if constexpr (WN) noise_rounds(2, 4);
+        mfma_range(cur, 2, 4);
+        CCVM_SLOT_END(V);
+        CCVM_READS(2);
+        if constexpr (!(ABL & 2)) {
+            *reinterpret_cast<f32x4*>(wbase + sb_off) = g.rq[0];
+            *reinterpret_cast<f32x4*>(wbase + sb_off + 8 * BN) = g.rq[1];
+        }
+        if constexpr (WN) noise_rounds(4, 6);
+        mfma_range(cur, 4, 6);
+        CCVM_SLOT_END(V);
+        CCVM_READS(3);
+        if constexpr (!(ABL & 2)) {
+            *reinterpret_cast<f32x4*>(wbase + sb_off + 16 * BN) = g.rq[2];
+            *reinterpret_cast<f32x4*>(wbase + sb_off + 24 * BN) = g.rq[3];
+        }
+        if constexpr (WN) noise_rounds(6, 8);
+        mfma_range(cur, 6, 8);
+        CCVM_SLOT_END(V);
+        CCVM_READS(4);
+        if constexpr (!(ABL & 1)) {
+            g.ra[0] = *reinterpret_cast<const f32x4*>(gA0 + k4);
+            if constexpr (NA == 2) g.ra[1] = *reinterpret_cast<const f32x4*>(gA1 + k4);
+            g.rq[0] = *reinterpret_cast<const f32x4*>(q4);
+        }
+        if constexpr (WN) noise_rounds(8, 10);
+        mfma_range(cur, 8, 10);
+        CCVM_SLOT_END(V);
+        CCVM_READS(5);
+        if constexpr (!(ABL & 1)) {
+            g.rq[1] = *reinterpret_cast<const f32x4*>(q4 + q_step);
+            g.rq[2] = *reinterpret_cast<const f32x4*>(q4 + 2 * q_step);
+            g.rq[3] = *reinterpret_cast<const f32x4*>(q4 + 3 * q_step);
+        }
+        if constexpr (WN) noise_radius();
+        mfma_range(cur, 10, 12);
+        CCVM_SLOT_END(V);
+        CCVM_READS(6);
+        if constexpr (WN) noise_end(t);
+        mfma_range(cur, 12, 14);
+        CCVM_SLOT_END(V);
+        CCVM_READS(7);
+        mfma_range(cur, 14, 16);
+        CCVM_SLOT_END(V);
+        if constexpr (!(ABL & 32)) __syncthreads();
+    };
+#undef CCVM_SLOT_BEGIN
+#undef CCVM_SLOT_END
+#undef CCVM_READS
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    int t = 0;
+    if (gen_noise) {
+        const int tn = min(nkt, 16);
+        for (; t + 1 < tn; t += 2) {
+            iteration(f0, f1, gs0, t, Yes{});
+            iteration(f1, f0, gs1, t + 1, Yes{});
+        }
+    }
+    const int noise_done = t;
+    for (; t + 1 < nkt; t += 2) {
+        iteration(f0, f1, gs0, t, No{});
+        iteration(f1, f0, gs1, t + 1, No{});
+    }
+    if (t < nkt) iteration(f0, f1, gs0, t, No{});
+    if (gen_noise) {
+        for (int r = noise_done; r < 16; ++r) make_noise(r);
+    }
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nkt);
-        if (more) load_tile(kt + 1);
-
-        const float* st = lds + cur * STAGE;
-        f32x4 af[NA][4];
+    if constexpr (ABL & 16) {  // ablation: keep the accumulators live, skip the real epilogue
+        float sum = vj;
 #pragma unroll
         for (int n = 0; n < NA; ++n)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                af[n][q] = *reinterpret_cast<const f32x4*>(st + n * A_TILE + fa + 4 * q);
-        float bf[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) bf[m] = st[fb + m * BN];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-#pragma unroll
-            for (int n = 0; n < NA; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[n][m >> 2][m & 3], bf[m], acc[n], 0, 0, 0);
-        }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) sum += acc[n][r] + e0[r] + (HAS_E1 ? e1[r] : 0.0f);
+        if (sum == 123.456f) a.o0[0] = sum;
+        return;
     }
 
     // ---- epilogue in the accumulator layout ---------------------------------------
-    // reg r of lane (half, l31): row = (r&3) + 8*(r>>2) + 4*half, col = l31.
-    const int j = col0 + 32 * wave + l31;
-    const bool col_ok = j < a.N;
-    const float vj = col_ok ? a.V[j] : 0.0f;
-
     if constexpr (MODE == MODE_ENERGY) {
         // partial over this wave's 32 columns of (1/2 (x@Q)[b,j] + V[j]) * x[b,j]
         float part[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float x = col_ok ? a.a0[(size_t)b * ld + j] : 0.0f;
-            float p = (0.5f * acc[0][r] + vj) * x;
+            float p = col_ok ? (0.5f * acc[0][r] + vj) * e0[r] : 0.0f;
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
             part[r] = p;
@@ -253,14 +458,15 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
         }
         return;
     } else {
+        // results first (pure arithmetic on registers), stores afterwards: no load ever waits
+        // behind a store
+        float r0v[16], r1v[16], r2v[16], r3v[16], r4v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool ok = col_ok && (b < a.B);
-            const size_t idx = (size_t)b * ld + j;
-            // noise
             float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
-            if constexpr (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN) {
+            if constexpr (NOISY) {
                 if (a.replay) {
                     if (ok) {
                         const size_t widx = (size_t)j * a.B + b;
@@ -270,94 +476,105 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
                             if (a.s.mf.has_next) n0n = a.w0n[widx];
                     }
                 } else {
-                    const NormalPair p = normal_pair(a.seed, a.row_offset + b, a.step, j);
-                    n0 = p.n0;
-                    n1 = p.n1;
-                    if constexpr (MODE == MODE_MF)
-                        if (a.s.mf.has_next) n0n = normal_pair(a.seed, a.row_offset + b, a.step + 1, j).n0;
+                    // written by this same thread in noise_end: no barrier needed
+                    n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
+                    if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                    if constexpr (MODE == MODE_MF) n0n = lds_noise[(1 * 16 + r) * NTHREADS + tid];
                 }
             }
 
             if constexpr (MODE == MODE_DL) {
                 const DlScalars& k = a.s.dl;
-                const float c = a.a0[idx], s = a.a1[idx];
+                const float c = e0[r], s = e1[r];
                 const float c2 = c * c, s2 = s * s;
                 const float diff = k.g2 * __builtin_sqrtf(c2 + s2 + 0.5f);
                 const float fbk = k.a_v * vj;
-                const float cn = c + (k.a_q * acc[0][r] + fbk + k.dt * ((k.pm_c - c2 - s2) * c)) + diff * (n0 * k.w_c);
-                const float sn = s + (k.a_q * acc[1][r] + fbk + k.dt * ((k.pm_s - c2 - s2) * s)) + diff * (n1 * k.w_s);
-                if (ok) {
-                    a.o0[idx] = cn;
-                    a.o1[idx] = sn;
-                }
+                r0v[r] = c + (k.a_q * acc[0][r] + fbk + k.dt * ((k.pm_c - c2 - s2) * c)) + diff * (n0 * k.w_c);
+                r1v[r] = s + (k.a_q * acc[1][r] + fbk + k.dt * ((k.pm_s - c2 - s2) * s)) + diff * (n1 * k.w_s);
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
-                const float mu = a.st0[idx], sg = a.st1[idx];
+                const float mu = e0[r], sg = e1[r];
                 const float wdot = n0 * k.inv_sdt;
                 const float mu2 = mu * mu;
                 const float term1 = (k.a0 - k.g2 * mu2) * mu;
                 float fb = k.f_q * acc[0][r] + k.f_v * vj;
                 if constexpr (ADAM) {
                     const AdamScalars& ad = a.ad;
-                    const float m = ad.beta1 * a.am[idx] + ad.one_m_beta1 * fb;
+                    const float m = ad.beta1 * e2[r] + ad.one_m_beta1 * fb;
                     const float mhat = m * ad.inv_bc1;
                     float upd;
                     if (ad.use_v) {
-                        const float v = ad.beta2 * a.av[idx] + ad.one_m_beta2 * (fb * fb);
+                        const float v = ad.beta2 * e3[r] + ad.one_m_beta2 * (fb * fb);
                         const float vhat = v * ad.inv_bc2;
                         upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
-                        if (ok) a.av[idx] = v;
+                        r4v[r] = v;
                     } else {
                         upd = ad.alpha * mhat;
                     }
-                    if (ok) a.am[idx] = m;
+                    r3v[r] = m;
                     fb = ad.add_assign ? fb + upd : upd;
                 }
                 const float sh = sg - 0.5f;
                 const float dsig = 2.0f * (k.a0 - 3.0f * k.g2 * mu2) * sg - 2.0f * k.j_i * (sh * sh) + (k.one_j + 2.0f * k.g2 * mu2);
                 const float diffusion = k.sqrt_j * sh * wdot;
                 const float mun = mu + k.dt * (term1 + fb + diffusion);
-                const float sgn = sg + k.dt * dsig;
-                if (ok) {
-                    a.st0[idx] = mun;
-                    a.st1[idx] = sgn;
-                    if (k.has_next) a.o0[idx] = clampf(mun + k.k_next * n0n, -k.S, k.S);
-                }
+                r0v[r] = mun;
+                r1v[r] = sg + k.dt * dsig;
+                r2v[r] = clampf(mun + k.k_next * n0n, -k.S, k.S);
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
-                const float c = a.a0[idx];
+                const float c = e0[r];
                 float g = k.g_q * acc[0][r] + k.g_v * vj;
                 if constexpr (ADAM) {
                     const AdamScalars& ad = a.ad;
-                    const float m = ad.beta1 * a.am[idx] + ad.one_m_beta1 * g;
+                    const float m = ad.beta1 * e2[r] + ad.one_m_beta1 * g;
                     const float mhat = m * ad.inv_bc1;
                     float upd;
                     if (ad.use_v) {
-                        const float v = ad.beta2 * a.av[idx] + ad.one_m_beta2 * (g * g);
+                        const float v = ad.beta2 * e3[r] + ad.one_m_beta2 * (g * g);
                         const float vhat = v * ad.inv_bc2;
                         upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
-                        if (ok) a.av[idx] = v;
+                        r4v[r] = v;
                     } else {
                         upd = ad.alpha * mhat;
                     }
-                    if (ok) a.am[idx] = m;
+                    r3v[r] = m;
                     g = ad.add_assign ? g + upd : upd;
                 }
                 float x = c + k.dt_fs * g + k.w * n0;
                 if (k.use_pump) x += k.dt * ((k.pm - c * c) * c);
-                if (ok) a.o0[idx] = clampf(x, -k.S, k.S);
+                r0v[r] = clampf(x, -k.S, k.S);
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
-                const float x = a.a0[idx];
-                if (ok) a.o0[idx] = clampf(x - k.step * (acc[0][r] + vj), k.lo, k.hi);
+                r0v[r] = clampf(e0[r] - k.step * (acc[0][r] + vj), k.lo, k.hi);
             } else if constexpr (MODE == MODE_ADAMPP) {
                 const PpScalars& k = a.s.pp;
-                const float x = a.a0[idx];
                 const float g = acc[0][r] + vj;
-                if (ok) a.o0[idx] = clampf(x - k.step * (g / (fabsf(g) + k.eps)), k.lo, k.hi);
+                r0v[r] = clampf(e0[r] - k.step * (g / (fabsf(g) + k.eps)), k.lo, k.hi);
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                if (ok) a.o0[idx] = k.step * acc[0][r] + k.eps * vj;
+                r0v[r] = k.step * acc[0][r] + k.eps * vj;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
+            if (col_ok && b < a.B) {
+                if constexpr (MODE == MODE_DL) {
+                    a.o0[idx] = r0v[r];
+                    a.o1[idx] = r1v[r];
+                } else if constexpr (MODE == MODE_MF) {
+                    a.st0[idx] = r0v[r];
+                    a.st1[idx] = r1v[r];
+                    if (a.s.mf.has_next) a.o0[idx] = r2v[r];
+                } else {
+                    a.o0[idx] = r0v[r];
+                }
+                if constexpr (ADAM) {
+                    a.am[idx] = r3v[r];
+                    if (a.ad.use_v) a.av[idx] = r4v[r];
+                }
             }
         }
     }

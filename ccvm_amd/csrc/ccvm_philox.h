@@ -7,6 +7,9 @@
 // 0,1 give one Box-Muller pair (n0, n1).  The DL solver uses n0 for the in-phase and
 // n1 for the quadrature increment; single-state solvers use n0.
 //
+// The generator is written as a resumable state machine (init / rounds / finish) so the
+// step kernel can slice it into the issue gaps between MFMAs.
+//
 // oracle/philox_ref.py restates exactly this mapping on the host (integer part
 // bit-exact, float part to ~1e-6) so that PHILOX-mode runs are checkable too.
 #pragma once
@@ -19,24 +22,34 @@ struct NormalPair {
     float n0, n1;
 };
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1,
-                                              uint32_t& o0, uint32_t& o1) {
+struct PhiloxState {
+    uint32_t c0, c1, c2, c3;
+};
+
+__device__ __forceinline__ PhiloxState philox_init(int64_t grow, int step, int col) {
+    PhiloxState s;
+    s.c0 = static_cast<uint32_t>(col);
+    s.c1 = static_cast<uint32_t>(grow);
+    s.c2 = static_cast<uint32_t>(step);
+    s.c3 = static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32);
+    return s;
+}
+
+// rounds [r0, r1) of the ten; the key of round r is seed + r * (W0, W1)
+__device__ __forceinline__ void philox_rounds(PhiloxState& s, uint64_t seed, int r0, int r1) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
-        k0 += W0;
-        k1 += W1;
+    for (int r = r0; r < r1; ++r) {
+        const uint32_t k0 = static_cast<uint32_t>(seed) + static_cast<uint32_t>(r) * W0;
+        const uint32_t k1 = static_cast<uint32_t>(seed >> 32) + static_cast<uint32_t>(r) * W1;
+        const uint32_t hi0 = __umulhi(M0, s.c0), lo0 = M0 * s.c0;
+        const uint32_t hi1 = __umulhi(M1, s.c2), lo1 = M1 * s.c2;
+        s.c0 = hi1 ^ s.c1 ^ k0;
+        s.c1 = lo1;
+        s.c2 = hi0 ^ s.c3 ^ k1;
+        s.c3 = lo0;
     }
-    o0 = c0;
-    o1 = c1;
 }
 
 // 24-bit uniform strictly inside (0, 1): ((x >> 8) + 0.5) * 2^-24.
@@ -44,18 +57,24 @@ __device__ __forceinline__ float u01(uint32_t x) {
     return (static_cast<float>(x >> 8) + 0.5f) * 5.9604644775390625e-8f;
 }
 
-__device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, int step, int col) {
-    uint32_t x0, x1;
-    philox4x32_10(static_cast<uint32_t>(col), static_cast<uint32_t>(grow),
-                  static_cast<uint32_t>(step), static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
-                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), x0, x1);
-    const float u1 = u01(x0), u2 = u01(x1);
-    // r = sqrt(-2 ln u1); v_sin/v_cos take their argument in revolutions.
-    const float r = __builtin_sqrtf(-2.0f * __logf(u1));
+// Box-Muller radius from word 0:  r = sqrt(-2 ln u1)
+__device__ __forceinline__ float philox_radius(const PhiloxState& s) {
+    return __builtin_sqrtf(-2.0f * __logf(u01(s.c0)));
+}
+
+// the pair from the radius and word 1 (v_sin/v_cos take their argument in revolutions)
+__device__ __forceinline__ NormalPair philox_pair(const PhiloxState& s, float radius) {
+    const float u2 = u01(s.c1);
     NormalPair p;
-    p.n0 = r * __builtin_amdgcn_cosf(u2);
-    p.n1 = r * __builtin_amdgcn_sinf(u2);
+    p.n0 = radius * __builtin_amdgcn_cosf(u2);
+    p.n1 = radius * __builtin_amdgcn_sinf(u2);
     return p;
+}
+
+__device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, int step, int col) {
+    PhiloxState s = philox_init(grow, step, col);
+    philox_rounds(s, seed, 0, 10);
+    return philox_pair(s, philox_radius(s));
 }
 
 }  // namespace ccvm

@@ -1,0 +1,113 @@
+"""The C-ABI shared library loads without a GPU and exports exactly what
+include/ccvm_hip.h declares; host-only entry points behave (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ccvm_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccvm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_binding_and_library_agree(hip_lib):
+    from ccvm_amd import _lib
+
+    declared = declared_functions()
+    assert declared, "no declarations parsed from the header"
+    assert sorted(_lib.SIGNATURES) == declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = {line.split()[-1] for line in nm.stdout.splitlines() if " T " in line}
+    for name in declared:
+        assert name in exported, f"{name} declared in ccvm_hip.h but not exported"
+        assert getattr(hip_lib, name) is not None
+
+
+def test_library_is_gfx950_only(hip_lib):
+    from ccvm_amd import _lib
+
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", _lib.LIB_PATH],
+                         capture_output=True, text=True)
+    if out.returncode == 0 and "amdgcn" in out.stdout:
+        assert "gfx950" in out.stdout
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_layout_helpers_and_version(hip_lib):
+    assert hip_lib.ccvm_abi_version() == 1
+    assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
+    assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
+    assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
+    state = 1024 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state
+    assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 2 * state
+    assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == state
+    assert hip_lib.ccvm_workspace_bytes(3, 1000, 1000) == 32 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes(4, 1000, 1000) == 2 * state
+    assert hip_lib.ccvm_workspace_bytes(9, 1000, 1000) == 0
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors of the C structs: sizes follow from the header's field lists."""
+    from ccvm_amd import _lib
+
+    assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.Adam) == 4 + 4 + 3 * 8 + 2 * 8
+    assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8
+    assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8
+    assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8
+
+
+def test_host_side_argument_checks_need_no_gpu(hip_lib):
+    """Validation happens before any HIP call, so these run in the CPU container."""
+    assert hip_lib.ccvm_clamp(None, 4, 4, 128, 0.0, 1.0, None) == -1
+    assert b"NULL" in hip_lib.ccvm_last_error()
+    assert hip_lib.ccvm_pack(None, 1, 1, 1, None, 1, 1, None) == -1
+    buf = ctypes.create_string_buffer(64)
+    addr = ctypes.c_void_p(ctypes.addressof(buf))
+    assert hip_lib.ccvm_clamp(addr, 4, 20, 64, 0.0, 1.0, None) == -2  # ld != ccvm_ld(20)
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    import torch
+
+    from ccvm_amd import _lib, engine
+
+    if not torch.cuda.is_available():
+        import pytest
+
+        with pytest.raises(_lib.EngineUnavailable):
+            engine.gpu_device()
+        from ccvm_amd.problem_classes.boxqp import ProblemInstance
+
+        inst = ProblemInstance.from_arrays(torch.eye(3), torch.ones(3))
+        with pytest.raises(_lib.EngineUnavailable):
+            inst.compute_energy(torch.ones((2, 3)))
+    # a missing library is an error, never a fallback
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libccvm_hip.so"))
+    import pytest
+
+    with pytest.raises(_lib.EngineUnavailable):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under ccvm_amd/ or ccvm_simulators/ may
+    import it (and nothing there reads /root/reference)."""
+    bad = []
+    for pkg in ("ccvm_amd", "ccvm_simulators"):
+        for base, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for name in files:
+                if name.endswith((".py", ".hip", ".h")):
+                    text = open(os.path.join(base, name)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "/root/reference" in text:
+                        bad.append(os.path.join(base, name))
+    assert not bad, bad

@@ -1,0 +1,315 @@
+"""GPU parity tests (run on an MI355X with `-m gpu`): the HIP path, through the public
+solver API and the C ABI, against (1) the golden vectors the REFERENCE produced and (2) the
+oracle on identical noise.
+
+Stated fp32 tolerance (measured): with identical noise, a re-ordered fp32
+drift moves final amplitudes by <= 1.1e-4 and objectives by <= 4e-4 over 100-15000 steps.
+Gates at N = 20:  |dx| <= 5e-4,  |dobj| <= 2e-3 (values ~130-150),  best objective rel 1e-5,
+success fractions within +-1/B (+-2/B for post-processed runs); absolute gates scale with
+sqrt(N/20) for larger N.
+"""
+import math
+
+import pytest
+import torch
+
+from golden_util import all_cases, check_noise_checksum, golden
+
+pytestmark = pytest.mark.gpu
+
+ATOL_X, ATOL_OBJ = 5e-4, 2e-3
+
+
+def _solver_for(kind, batch, device="cpu"):
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
+
+    cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
+    solver = cls(device=device, batch_size=batch)
+    solver.noise_mode = "replay"
+    return solver
+
+
+def _instance(g, device="cpu"):
+    from ccvm_amd.problem_classes.boxqp import ProblemInstance
+
+    inst = ProblemInstance.from_arrays(g.q(), g.v(), device=device, name=g.instance["name"],
+                                       optimal_sol=g.instance["optimal_sol"], best_sol=g.instance["best_sol"])
+    return inst
+
+
+def _run_case(g, meta, device="cpu"):
+    from ccvm_amd.solvers.algorithms import AdamParameters
+
+    kind = meta["kind"]
+    solver = _solver_for(kind, meta["batch"], device)
+    inst = _instance(g, device)
+    solver.parameter_key = {inst.problem_size: dict(meta["params"])}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    kwargs = {}
+    if kind in ("dl", "mf", "pl"):
+        kwargs["pump_rate_flag"] = meta["pump_rate_flag"]
+    if meta["adam"]:
+        kwargs["algorithm_parameters"] = AdamParameters(**meta["adam"])
+    torch.manual_seed(meta["seed"])
+    return solver(instance=inst, post_processor=meta["post"], **kwargs)
+
+
+@pytest.mark.parametrize("tag,case", all_cases())
+def test_solver_matches_reference_golden(tag, case):
+    g = golden(tag)
+    meta = g.cases[case]
+    check_noise_checksum(meta, g.instance["problem_size"], meta["batch"])
+    sol = _run_case(g, meta)
+    # Adam runs with alpha = 0.001 and no add_assign barely move (objective far from optimum,
+    # values ~20-60); every case uses the same absolute gates.
+    for field in g.fields(case):
+        want = g.out(case, field)
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        tol = ATOL_OBJ if field == "objective_values" else ATOL_X * max(1.0, float(want.abs().max()))
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol, f"{tag}/{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * abs(
+        meta["best_objective_value"]) + 1e-4
+    slack = (2.0 if meta["post"] else 1.0) / meta["batch"] + 1e-9
+    for key, frac in meta["solution_performance"].items():
+        assert abs(sol.solution_performance[key] - frac) <= slack, (key, sol.solution_performance, frac)
+
+
+def test_dl_example_anchor():
+    """The reference's DL example exactly as shipped (B=1000, T=1500, seed 1234,
+    tuningH020-100-0): best 130.7142, `optimal` fraction 0.987."""
+    import json
+    import os
+
+    from golden_util import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "dl_example_anchor.json")) as fh:
+        meta = json.load(fh)
+    g = golden("tuningH020")
+    sol = _run_case(g, meta)
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * meta["best_objective_value"]
+    for key, frac in meta["solution_performance"].items():
+        assert abs(sol.solution_performance[key] - frac) <= 2.0 / meta["batch"]
+
+
+def test_cuda_resident_instance_matches_host_resident():
+    """device="cuda" (tensors stay on the GPU) and device="cpu" (staged) are the same engine."""
+    g = golden("test020")
+    meta = g.cases["pl_T100"]
+    a = _run_case(g, meta, "cpu")
+    b = _run_case(g, meta, "cuda")
+    assert b.objective_values.is_cuda and b.variables["problem_variables"].is_cuda
+    # get_scaling_factor reduces |Q| on the caller's device, so Q can differ in the last bit
+    assert torch.allclose(a.objective_values, b.objective_values.cpu(), rtol=2e-6, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------
+# PHILOX mode against the oracle fed with the host restatement of the same generator
+# ------------------------------------------------------------------------------------------
+def _gate(n):
+    return math.sqrt(max(n, 20) / 20.0)
+
+
+@pytest.mark.parametrize("kind,n,b,t", [
+    ("dl", 100, 256, 40), ("mf", 100, 256, 40), ("langevin", 100, 256, 40), ("pl", 100, 256, 40),
+    ("dl", 333, 130, 12), ("mf", 500, 200, 8), ("pl", 257, 65, 12),
+    ("dl", 1000, 1000, 6),  # BASELINE headline shape
+])
+def test_philox_mode_matches_oracle(kind, n, b, t):
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from oracle import ccvm_oracle as oracle
+    from oracle.philox_ref import PhiloxNoise
+
+    q, v, f = scaled_qv(n, kind)
+    p = dict(EXAMPLE_PARAMS[kind])
+    seed, row_offset = 0x1234_5678_9ABC, 4096
+    noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=row_offset)
+    prob = engine.DeviceProblem(q, v)
+    ref_noise = PhiloxNoise(seed, row_offset)
+    if kind == "dl":
+        traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)
+        traj.advance(t)
+        c, s = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05,
+                              (0.0, 1.0), True, ref_noise)
+        pairs = [("c", c), ("s", s)]
+    elif kind == "mf":
+        traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=0.01), (0.0, 1.0), noise)
+        traj.advance(t)
+        mu, mu_tilde, sigma = oracle.mf_loop(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"],
+                                             p["S"], 0.01, (0.0, 1.0), True, None, ref_noise)
+        pairs = [("mu", mu), ("sigma", sigma), ("mu_tilde", mu_tilde)]
+    else:
+        traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl"), (0.0, 1.0), noise)
+        traj.advance(t)
+        if kind == "pl":
+            c = oracle.pl_loop(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"],
+                               (0.0, 1.0), True, None, ref_noise)
+        else:
+            c = oracle.langevin_loop(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"],
+                                     (0.0, 1.0), None, ref_noise)
+        pairs = [("c", c)]
+    for name, want in pairs:
+        got = traj.compact(name).cpu()
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= ATOL_X * _gate(n) * scale, f"{kind} N={n} {name}: {err:.3e}"
+    # padding stays zero
+    for name, arr in traj.state.items():
+        assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
+        assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
+
+
+def test_philox_normals_match_host_restatement_and_are_gaussian():
+    from ccvm_amd import engine
+    from oracle.philox_ref import normal_pairs
+
+    seed, off, step, b, n = 987654321012345, 7, 123, 512, 300
+    w0, w1 = engine.philox_normals(seed, off, step, b, n, two=True)
+    r0, r1 = normal_pairs(seed, off, step, b, n)
+    assert float((w0.cpu().T - torch.from_numpy(r0)).abs().max()) <= 2e-5
+    assert float((w1.cpu().T - torch.from_numpy(r1)).abs().max()) <= 2e-5
+    big0, big1 = engine.philox_normals(seed, 0, 0, 2048, 1024, two=True)
+    for w in (big0, big1):
+        x = w.double().flatten()
+        assert abs(float(x.mean())) < 4e-3 and abs(float(x.var()) - 1) < 6e-3
+        assert abs(float((x**3).mean())) < 1.5e-2 and abs(float((x**4).mean()) - 3) < 4e-2
+    assert abs(float((big0.double() * big1.double()).mean())) < 4e-3
+    # different steps / rows decorrelate
+    nxt = engine.philox_normals(seed, 0, 1, 2048, 1024)
+    assert abs(float((big0.double() * nxt.double()).mean())) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------
+# C-ABI level invariances
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["dl", "mf", "langevin"])
+def test_chunking_does_not_change_the_result(kind):
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    n, b, t = 96, 70, 30
+    q, v, _ = scaled_qv(n, "pl" if kind == "langevin" else kind)
+    prob = engine.DeviceProblem(q, v)
+    p = dict(EXAMPLE_PARAMS["pl" if kind == "langevin" else kind], g=0.03, use_pump=True)
+    adam = None if kind == "dl" else {"alpha": 0.01, "beta1": 0.9, "beta2": 0.999, "add_assign": True}
+    outs = []
+    for chunks in ([t], [1, 7, 2, 20]):
+        traj = engine.Trajectories(prob, b, kind, t, p, (0.0, 1.0),
+                                   engine.NoiseSpec(mode="philox", seed=99), adam=adam)
+        for k in chunks:
+            traj.advance(k)
+        outs.append({name: traj.compact(name).cpu() for name in traj.state})
+    for name in outs[0]:
+        assert torch.equal(outs[0][name], outs[1][name]), name
+
+
+def test_batch_sharding_by_row_offset_is_exact():
+    """Rows [0, B) in one call == two calls on halves with row_offset (the multi-GPU path)."""
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    n, b, t = 130, 96, 15
+    q, v, _ = scaled_qv(n, "dl")
+    prob = engine.DeviceProblem(q, v)
+    p = dict(EXAMPLE_PARAMS["dl"], g=0.05)
+    full = engine.Trajectories(prob, b, "dl", t, p, (0.0, 1.0), engine.NoiseSpec(mode="philox", seed=5))
+    full.advance(t)
+    parts = []
+    for r in range(2):
+        tr = engine.Trajectories(prob, b // 2, "dl", t, p, (0.0, 1.0),
+                                 engine.NoiseSpec(mode="philox", seed=5, row_offset=r * (b // 2)))
+        tr.advance(t)
+        parts.append(tr.compact("c").cpu())
+    assert torch.equal(full.compact("c").cpu(), torch.cat(parts))
+
+
+def test_post_loop_kernels_match_oracle():
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import scaled_qv
+    from oracle import ccvm_oracle as oracle
+
+    for n, b in ((20, 100), (1000, 1000), (257, 33)):
+        q, v, f = scaled_qv(n, "mf")
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand((b, n), generator=g)
+        e = engine.energy(x, q, v, float(f))
+        want = oracle.compute_energy(x, q, v, f)
+        assert float((e - want).abs().max()) <= 2e-5 * float(want.abs().max()) * _gate(n)
+        y = engine.change_variables(x * 40 - 20, 20.0, 0.0, 1.0)
+        assert float((y - oracle.change_variables(x * 40 - 20, 0.0, 1.0, 20.0)).abs().max()) <= 1e-6
+        z = engine.clamp(x * 4 - 2, -0.5, 0.5)
+        assert torch.equal(z, torch.clamp(x * 4 - 2, -0.5, 0.5))
+        fb = engine.feedback(x, q, v, in_scale=0.05, in_shift=1.0, f_q=-50.0, f_v=-100.0)
+        want = oracle.mf_grads(x, q, v, 20.0, 4000.0, 0.0, 1.0)
+        assert float((fb - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * _gate(n)
+        for method, ref in (("grad-descent", oracle.pp_grad_descent), ("adam", oracle.pp_adam)):
+            got, _ = engine.postprocess(method, x, q, v)
+            assert float((got - ref(x, q, v)).abs().max()) <= 1e-5 * _gate(n), (method, n)
+
+
+def test_feedback_is_linear_at_full_size():
+    """Size-independent property at the headline shape: the fused matvec is linear,
+    F(a x + b y) - F(0) = a (F(x) - F(0)) + b (F(y) - F(0))."""
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import scaled_qv
+
+    n, b = 1000, 1000
+    q, v, _ = scaled_qv(n, "dl")
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.randn((b, n), generator=g), torch.randn((b, n), generator=g)
+    F = lambda z: engine.feedback(z, q, v, in_scale=0.37, in_shift=1.0, f_q=-2.0, f_v=-3.0)
+    f0 = F(torch.zeros((b, n)))
+    lhs = F(0.5 * x - 1.5 * y) - f0
+    rhs = 0.5 * (F(x) - f0) - 1.5 * (F(y) - f0)
+    assert float((lhs - rhs).abs().max()) <= 5e-5 * max(1.0, float(rhs.abs().max()))
+
+
+def test_abi_rejects_bad_arguments(hip_lib):
+    import ctypes
+
+    from ccvm_amd import _lib, engine
+
+    dev = engine.gpu_device()
+    x = torch.zeros((64, 128), device=dev)
+    assert hip_lib.ccvm_clamp(ctypes.c_void_p(x.data_ptr()), 10, 20, 64, 0.0, 1.0, None) == -2  # bad ld
+    assert b"ccvm_ld" in hip_lib.ccvm_last_error()
+    assert hip_lib.ccvm_clamp(None, 10, 20, 128, 0.0, 1.0, None) == -1
+    nz = _lib.Noise()
+    nz.mode = 7
+    p = _lib.LangevinParams()
+    p.dt, p.S, p.lower, p.upper = 0.1, 1.0, 0.0, 1.0
+    ws = torch.zeros(64 * 128 * 4, dtype=torch.uint8, device=dev)
+    q = torch.zeros((128, 128), device=dev)
+    args = lambda step0, k, T, wsb: hip_lib.ccvm_langevin_run(
+        ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(x.data_ptr()), 10, 20,
+        128, step0, k, T, ctypes.byref(p), None, ctypes.byref(nz), ctypes.c_void_p(ws.data_ptr()), wsb, None)
+    assert args(0, 1, 10, ws.numel()) == -1          # unknown noise mode
+    nz.mode = 0
+    assert args(8, 5, 10, ws.numel()) == -1          # step range outside the run
+    assert args(0, 1, 10, 16) == -3                  # workspace too small
+    assert args(0, 1, 10, ws.numel()) == 0
+    torch.cuda.synchronize()
+
+
+def test_unsupported_requests_fail_loudly():
+    from ccvm_amd.post_processor.factory import PostProcessorFactory
+    from ccvm_amd.solvers import DLSolver, MFSolver
+    from ccvm_amd.solvers.algorithms import AdamParameters
+
+    g = golden("test020")
+    inst = _instance(g)
+    with pytest.raises(NotImplementedError):
+        PostProcessorFactory.create_postprocessor("bfgs")
+    dl = DLSolver(device="cpu", batch_size=8)
+    dl.parameter_key = {20: dict(g.cases["dl_T1"]["params"])}
+    with pytest.raises(TypeError):  # same exception type as the reference's broken call
+        dl(instance=inst, algorithm_parameters=AdamParameters())
+    mf = MFSolver(device="cpu", batch_size=8)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(20))}
+    with pytest.raises(NotImplementedError):
+        mf(instance=inst)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"])}
+    mf.calculate_grads = lambda *a, **k: 0
+    with pytest.raises(NotImplementedError):
+        mf(instance=inst)

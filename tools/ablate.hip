@@ -1,0 +1,108 @@
+// Ablation / calibration harness for the step kernel (developer tool, not product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ablate.hip -o tools/ablate && tools/ablate
+// Times (a) a bare v_mfma_f32_32x32x2_f32 loop = the MFMA roofline as THIS chip delivers it,
+// (b) the DL step kernel at N=1000, B=1000 with parts removed (ABL bits, see ccvm_kernels.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../ccvm_amd/csrc/ccvm_kernels.h"
+
+using namespace ccvm;
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e = (x);                                                    \
+        if (e != hipSuccess) {                                                 \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            return 1;                                                          \
+        }                                                                      \
+    } while (0)
+
+// 1024 MFMAs per wave on two alternating accumulators, operands in registers.
+__global__ __launch_bounds__(256) void mfma_only(float* out, int n, float x) {
+    f32x16 a0, a1;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    float u = x + threadIdx.x, v = x - threadIdx.x;
+    for (int i = 0; i < n; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v, u, a1, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <typename F>
+float time_us(F&& launch, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.f / iters;
+}
+
+template <int ABL>
+float run_variant(const StepArgs& a, int iters) {
+    return time_us([&] { hipLaunchKernelGGL((step_kernel<MODE_DL, false, ABL>), dim3(a.nrb * a.ncb), dim3(NTHREADS), 0, 0, a); }, iters);
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 1000, B = argc > 2 ? atoi(argv[2]) : 1000;
+    const int ld = (N + 127) / 128 * 128, rows = (B + 63) / 64 * 64;
+    const size_t state = (size_t)rows * ld;
+    float *Q, *V, *c, *s, *c2, *s2, *out;
+    CK(hipMalloc(&Q, (size_t)ld * ld * 4));
+    CK(hipMalloc(&V, ld * 4));
+    CK(hipMalloc(&c, state * 4)); CK(hipMalloc(&s, state * 4));
+    CK(hipMalloc(&c2, state * 4)); CK(hipMalloc(&s2, state * 4));
+    CK(hipMalloc(&out, 1024));
+    std::vector<float> h((size_t)ld * ld);
+    unsigned rng = 12345;
+    auto rnd = [&] { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f); };
+    for (auto& x : h) x = rnd() * 0.01f;
+    CK(hipMemcpy(Q, h.data(), (size_t)ld * ld * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(V, h.data(), ld * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < state; ++i) h[i] = rnd();
+    CK(hipMemcpy(c, h.data(), state * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(s, h.data(), state * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(c2, 0, state * 4)); CK(hipMemset(s2, 0, state * 4));
+
+    const int nm = 512;  // 2 MFMAs per iteration -> 1024 per wave, as the N=1000 DL step
+    float t = time_us([&] { hipLaunchKernelGGL(mfma_only, dim3(256), dim3(256), 0, 0, out, nm, 1.0f); }, 50);
+    printf("mfma_only 256 WG x 4 waves x 1024 MFMA: %8.2f us  (%.1f TF, %.1f cycles/MFMA @2.4GHz)\n", t,
+           256.0 * 4 * 1024 * 4096 / t / 1e6, t * 2400.0 / 1024);
+    t = time_us([&] { hipLaunchKernelGGL(mfma_only, dim3(512), dim3(256), 0, 0, out, nm, 1.0f); }, 50);
+    printf("mfma_only 512 WG (2 waves/SIMD)        : %8.2f us  (%.1f TF)\n", t, 512.0 * 4 * 1024 * 4096 / t / 1e6);
+
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = Q; a.V = V; a.a0 = c; a.a1 = s; a.o0 = c2; a.o1 = s2;
+    a.B = B; a.N = N; a.ld = ld; a.nrb = (B + BM - 1) / BM; a.ncb = ld / BN;
+    a.in_scale = 0.37f; a.in_shift = 1.0f; a.seed = 42; a.step = 3;
+    a.s.dl = DlScalars{-1e-4f, -1e-4f, 1.f, -3.f, 1e-3f, 0.1f, 0.03f, 0.03f};
+    const int it = 50;
+    printf("grid %d x %d threads, N=%d B=%d\n", a.nrb * a.ncb, NTHREADS, N, B);
+    printf("full                         : %8.2f us\n", run_variant<0>(a, it));
+    printf("no epilogue            (16)  : %8.2f us\n", run_variant<16>(a, it));
+    printf("no global loads         (1)  : %8.2f us\n", run_variant<1>(a, it));
+    printf("no ring writes          (2)  : %8.2f us\n", run_variant<2>(a, it));
+    printf("no loads, no writes     (3)  : %8.2f us\n", run_variant<3>(a, it));
+    printf("no frag reads           (4)  : %8.2f us\n", run_variant<4>(a, it));
+    printf("no loads/writes/reads   (7)  : %8.2f us\n", run_variant<7>(a, it));
+    printf("... and no barrier     (39)  : %8.2f us\n", run_variant<39>(a, it));
+    printf("... and no epilogue    (55)  : %8.2f us\n", run_variant<55>(a, it));
+    printf("no MFMA                 (8)  : %8.2f us\n", run_variant<8>(a, it));
+    printf("no MFMA, no epilogue   (24)  : %8.2f us\n", run_variant<24>(a, it));
+    a.replay = 0;
+    return 0;
+}
