@@ -32,6 +32,7 @@ SOLVER_MF = 1
 SOLVER_LANGEVIN = 2
 WS_ENERGY = 3
 WS_POSTPROCESS = 4
+WS_FEEDBACK = 5
 
 
 class EngineUnavailable(RuntimeError):
@@ -135,7 +136,7 @@ SIGNATURES = {
     "ccvm_change_variables": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     "ccvm_energy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
     "ccvm_feedback": (
-        c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P]
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, c_size_t, _P]
     ),
     "ccvm_pp_grad_descent": (
         c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P, c_size_t, _P]

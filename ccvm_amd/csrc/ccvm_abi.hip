@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/ccvm_hip.h"
@@ -85,9 +86,23 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.N = N;
     a.ld = ld;
     a.nrb = (B + BM - 1) / BM;
-    a.ncb = ld / BN;
+    a.ncb = (N + BN - 1) / BN;
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
+    a.qsum = V;  // any valid array while in_shift == 0
+}
+
+// Column sums of Q into `area` ((QSUM_SLICES + 1) * ld floats); returns the qsum pointer.
+size_t qsum_area_bytes(int N) { return (size_t)(QSUM_SLICES + 1) * ccvm_ld(N) * sizeof(float); }
+
+int compute_qsum(const float* Q, int N, int ld, float* area, hipStream_t st, const float** out) {
+    float* part = area + ld;
+    hipLaunchKernelGGL(qsum_partial_kernel, dim3((ld + 127) / 128, QSUM_SLICES), dim3(128), 0, st, Q, N, ld, part);
+    hipLaunchKernelGGL(qsum_final_kernel, dim3((ld + 127) / 128), dim3(128), 0, st, part, ld, area);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVM_E_HIP, "column sums of Q: %s", hipGetErrorString(e));
+    *out = area;
+    return CCVM_OK;
 }
 
 void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N, bool two, bool next) {
@@ -106,7 +121,7 @@ void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N
 template <int MODE, bool ADAM>
 int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
     const int grid = a.nrb * a.ncb;
-    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(2 * NTHREADS), 0, st, a);
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
 }
@@ -128,12 +143,14 @@ int ccvm_rows(int B) { return B <= 0 ? 0 : round_up(B, 64); }
 size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t ld = (size_t)ccvm_ld(N), rows = (size_t)ccvm_rows(B);
     const size_t state = rows * ld * sizeof(float);
+    const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
-        case 0: return 2 * state;                        // DL: c', s'
-        case 1: return 2 * state;                        // MF: measured-amplitude ping-pong
-        case 2: return state;                            // Langevin: c'
+        case 0: return 2 * state + qs;                   // DL: c', s'
+        case 1: return 2 * state + qs;                   // MF: measured-amplitude ping-pong
+        case 2: return state + qs;                       // Langevin: c'
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
+        case 5: return qs;                               // ccvm_feedback
         default: return 0;
     }
 }
@@ -191,6 +208,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     base_args(a, Q, V, B, N, ld);
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
+    if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
     int cur = 0;
     for (int i = step0; i < step0 + nsteps; ++i) {
         const double frac = (double)(i + 1) / (double)T;
@@ -263,6 +281,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     base_args(a, Q, V, B, N, ld);
     a.in_scale = (float)(ul / p->S);
     a.in_shift = (float)up;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
     a.st0 = mu;
     a.st1 = sigma;
     if (use_adam) {
@@ -332,6 +351,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     base_args(a, Q, V, B, N, ld);
     a.in_scale = (float)(ul / (2.0 * p->S));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
     if (use_adam) {
         a.am = adam->m;
         a.av = adam->v;
@@ -407,17 +427,19 @@ int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, in
 }
 
 int ccvm_feedback(const float* Q, const float* V, const float* x, float* y, int B, int N, int ld, double in_scale,
-                  double in_shift, double f_q, double f_v, void* stream) {
+                  double in_shift, double f_q, double f_v, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_feedback";
     int rc;
     if (!Q || !V || !x || !y || x == y) return fail(CCVM_E_INVALID, "%s: NULL or aliased argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
-    if (!aligned16(Q) || !aligned16(x) || !aligned16(y))
-        return fail(CCVM_E_LAYOUT, "%s: Q, x and y must be 16-byte aligned", fn);
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(y) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x, y and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(5, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     StepArgs a;
     base_args(a, Q, V, B, N, ld);
     a.in_scale = (float)in_scale;
     a.in_shift = (float)in_shift;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws), (hipStream_t)stream, &a.qsum))) return rc;
     a.a0 = x;
     a.o0 = y;
     a.s.pp.step = (float)f_q;

@@ -1,28 +1,35 @@
 // Device kernels of the CCVM dynamics engine (gfx950 / MI355X only).
 //
-// One Euler-Maruyama step of every solver is  X' = f(X, A(X) @ Q, noise)  with B
-// independent rows and one dense N x N coupling matrix.  `step_kernel` is that whole
-// step in one launch: an fp32-MFMA GEMM (v_mfma_f32_32x32x2_f32, exact f32) over
-// LDS-staged tiles, and an epilogue that applies the solver's drift/diffusion/clamp
-// with in-kernel Philox noise, in the MFMA accumulator layout (no LDS round trip).
+// One Euler-Maruyama step of every solver is  X' = f(X, A(X) @ Q, noise)  with B independent
+// rows and one dense N x N coupling matrix.  `step_kernel` is that whole step in one launch:
+// an fp32-MFMA GEMM (v_mfma_f32_32x32x2_f32, exact f32) fed from an LDS ring, and an epilogue
+// that applies the solver's drift/diffusion/clamp with in-kernel counter-based noise, in the
+// MFMA accumulator layout (no LDS round trip for the result).
 //
-// Tiling (64-wide waves, one wave per SIMD):
-//   workgroup = 256 threads = 4 waves -> 32 batch rows x 128 columns;
-//   wave w owns columns [32w, 32w+32) and NA accumulators of 32x32 (DL: c and s share
-//   the Q fragments, so each Q element read from LDS feeds two MFMAs);
-//   K is walked in tiles of 32, double-buffered in LDS with register-staged
-//   prefetch (global loads for tile t+1 are issued before the MFMAs of tile t).
-//   Inside a K tile lane-half h owns k in [16h, 16h+16): A fragments are four
-//   ds_read_b128 per accumulator (row stride 36 floats: conflict-free), Q fragments
-//   are conflict-free ds_read_b32.  The k order differs from the reference's BLAS,
-//   which is inside the stated fp32 tolerance.
+// Workgroup = 512 threads = 8 waves, wave-specialised (one producer + one consumer per SIMD):
+//   consumers (waves 0-3): 32 batch rows x 128 columns; wave w owns columns [32w, 32w+32) and
+//     NA accumulators of 32x32 (DL: c and s share the Q fragments).  Per K tile of 32 they read
+//     next tile's fragments from the ring (conflict-free ds_read_b128 / ds_read_b32) in the
+//     issue gaps of this tile's 16*NA MFMAs, then run the epilogue.
+//   producers (waves 4-7): stream tiles L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA: no
+//     VGPRs, no ds_write), four tiles ahead in a 4-stage ring, and generate the Threefry
+//     normals for the consumers' accumulator elements into LDS.
+// Why this shape (all measured with tools/ablate.hip): a single wave issues in
+// order, so any LDS/VMEM/VALU issue stall delays its next MFMA; ds_write_b128 staging from
+// VGPRs blocked the SIMD's MFMA for its 13-cycle data transfer; L2-hit latency under load is
+// ~1.5 us, so >= 3 tiles must be in flight.
+// One s_barrier per K tile.  The A tile is XOR-swizzled in LDS through the per-lane SOURCE
+// address of the DMA (dest is lane-linear by hardware); the input map x*scale+shift is folded
+// into the epilogue as  scale*(x@Q) + shift*colsum(Q).  Inside a K tile lane-half h owns
+// k in [16h, 16h+16); the k order differs from the reference's BLAS, which is inside the
+// stated fp32 tolerance.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <type_traits>
 
-#include "ccvm_philox.h"
+#include "ccvm_noise.h"
 
 namespace ccvm {
 
@@ -32,8 +39,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 32;        // batch rows per workgroup
 constexpr int BN = 128;       // output columns per workgroup
 constexpr int KT = 32;        // K tile
-constexpr int LDA = KT + 4;   // LDS row stride of an A tile (floats)
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS = 256; // consumer threads (the tile mapping); the workgroup has 2x this
+constexpr int NSTAGE = 4;     // LDS ring depth = DMA prefetch distance in tiles
+constexpr int A_TILE = BM * KT;   // floats, 128-B rows, XOR-swizzled 16-B chunks
+constexpr int Q_TILE = KT * BN;   // floats, 512-B rows, linear
 
 enum Mode : int {
     MODE_DL = 0,        // two-state DL-CCVM step
@@ -98,6 +107,7 @@ struct AdamScalars {
 struct StepArgs {
     const float* Q;
     const float* V;
+    const float* qsum;  // column sums of Q (length ld): the affine input map's constant term
     const float* a0;    // GEMM input 0 (pitched B x N)
     const float* a1;    // GEMM input 1 (DL: s)
     float* o0;          // DL: c'; MF: next measured amplitude; LV/GD/ADAMPP: x'; ENERGY: partials
@@ -137,33 +147,88 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- per-element updates ---------------------------------------------------------------
+// The epilogue is unrolled over the 16 accumulator registers; with free FMA contraction the
+// compiler fuses differently for different registers and a row's rounding would depend on its
+// position in the tile (breaking "shards are bit-identical to the unsharded run").  These
+// helpers pin the operation sequence: contraction off, fmaf where fusion is intended.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float adam_precondition(const AdamScalars& ad, float g, float m_old, float v_old,
+                                                   float& m_new, float& v_new) {
+    m_new = __builtin_fmaf(ad.beta1, m_old, ad.one_m_beta1 * g);
+    const float mhat = m_new * ad.inv_bc1;
+    float upd;
+    if (ad.use_v) {
+        v_new = __builtin_fmaf(ad.beta2, v_old, ad.one_m_beta2 * (g * g));
+        const float vhat = v_new * ad.inv_bc2;
+        upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
+    } else {
+        v_new = 0.0f;
+        upd = ad.alpha * mhat;
+    }
+    return ad.add_assign ? g + upd : upd;
+}
+
+__device__ __forceinline__ void dl_update(const DlScalars& k, float c, float s, float qc, float qs, float vj,
+                                          float n0, float n1, float& cn, float& sn) {
+    const float c2 = c * c, s2 = s * s;
+    const float r2 = c2 + s2;
+    const float diff = k.g2 * __builtin_sqrtf(r2 + 0.5f);
+    const float fbk = k.a_v * vj;
+    const float dc = __builtin_fmaf(k.a_q, qc, fbk) + k.dt * ((k.pm_c - r2) * c);
+    const float ds = __builtin_fmaf(k.a_q, qs, fbk) + k.dt * ((k.pm_s - r2) * s);
+    cn = c + __builtin_fmaf(diff, n0 * k.w_c, dc);
+    sn = s + __builtin_fmaf(diff, n1 * k.w_s, ds);
+}
+
+__device__ __forceinline__ void mf_update(const MfScalars& k, float mu, float sg, float fb, float n0,
+                                          float& mun, float& sgn) {
+    const float wdot = n0 * k.inv_sdt;
+    const float mu2 = mu * mu;
+    const float term1 = (k.a0 - k.g2 * mu2) * mu;
+    const float sh = sg - 0.5f;
+    const float dsig = 2.0f * (k.a0 - 3.0f * k.g2 * mu2) * sg - 2.0f * k.j_i * (sh * sh) + (k.one_j + 2.0f * k.g2 * mu2);
+    const float diffusion = k.sqrt_j * sh * wdot;
+    mun = __builtin_fmaf(k.dt, term1 + fb + diffusion, mu);
+    sgn = __builtin_fmaf(k.dt, dsig, sg);
+}
+
+__device__ __forceinline__ float lv_update(const LvScalars& k, float c, float g, float n0) {
+    float x = __builtin_fmaf(k.dt_fs, g, c) + k.w * n0;
+    if (k.use_pump) x = __builtin_fmaf(k.dt, (k.pm - c * c) * c, x);
+    return clampf(x, -k.S, k.S);
+}
+#pragma clang fp contract(fast)
+
 template <int NA>
 struct Frags {
     f32x4 a[NA][4];  // lane (row l31, half h): k = 16h .. 16h+15 of the tile, 4 x b128
     float b[16];     // Q[k = 16h + m][col 32w + l31]
 };
 
-constexpr int NSTAGE = 3;          // LDS ring: tile t computing (in registers), t+1 readable, t+2 being written
-constexpr int NOISE_SLOTS = 2;     // normals kept per element (DL: c,s; MF: this step, next step)
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_cvoid;
 
-// ABL: ablation bits for tools/ablate.hip (0 in the product): 1 no global loads in the loop,
-// 2 no ring writes, 4 no fragment reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier.
+// ABL: ablation bits for tools/ablate.hip (0 in the product): 1 no DMA loads, 4 no fragment
+// reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier (timing only), 64 no noise.
 template <int MODE, bool ADAM, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
     constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
-    constexpr int A_TILE = BM * LDA;
-    constexpr int STAGE = NA * A_TILE + KT * BN;
-    constexpr int NOISE_LDS = NOISY ? NOISE_SLOTS * 16 * NTHREADS : 0;
-    // one array (guide: a second __shared__ object can de-pipeline the loop)
+    constexpr int STAGE = NA * A_TILE + Q_TILE;
+    constexpr int NOISE_LDS = NOISY ? 2 * 16 * NTHREADS : 0;
+    // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE + NOISE_LDS];
     float* const lds_noise = lds + NSTAGE * STAGE;
 
-    const int tid = threadIdx.x;
+    // tid / wave index the 256-thread tile mapping; a producer thread shares the mapping of the
+    // consumer thread 256 below it (it makes that thread's noise)
+    const int tid = threadIdx.x & (NTHREADS - 1);
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int l31 = lane & 31;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHREADS;
 
     const int tile = xcd_remap(blockIdx.x, a.nrb * a.ncb);
     const int rb = tile / a.ncb, cb = tile - rb * a.ncb;
@@ -171,7 +236,81 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
     const int ld = a.ld;
     const int j = col0 + 32 * wave + l31;  // this lane's output column
     const bool col_ok = j < a.N;
+    const int nkt = (a.N + KT - 1) / KT;
+    const int last = nkt - 1;
+    const bool gen_noise = NOISY && !a.replay;
 
+    if (producer) {
+        // =========================== producer waves ====================================
+        // DMA pieces of one tile: 4 per A tile (8 rows x 128 B) then 16 of Q (2 rows x 512 B);
+        // each wave issues PPW of them.  LDS destination = piece base + lane * 16 (hardware);
+        // the A tile's swizzle (chunk c of row r stored at position c ^ ((r >> 1) & 7)) is applied
+        // to the per-lane SOURCE address.
+        constexpr int PPW = NA + 4;
+        const float* src[PPW];
+        int dst[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i;  // wave-uniform
+            if (p < 4 * NA) {
+                const int n = p >> 2, g = p & 3;
+                const int r = 8 * g + (lane >> 3), pos = lane & 7;
+                const float* base = (n == 0) ? a.a0 : a.a1;
+                src[i] = base + (size_t)(row0 + r) * ld + 4 * (pos ^ ((r >> 1) & 7));
+                dst[i] = n * A_TILE + g * 256;
+            } else {
+                const int q = p - 4 * NA;
+                src[i] = a.Q + (size_t)(2 * q + (lane >> 5)) * ld + col0 + 4 * (lane & 31);
+                dst[i] = NA * A_TILE + q * 256;
+            }
+        }
+        auto dma_tile = [&](int kt) {
+            if constexpr (ABL & 1) return;
+            const int k0 = min(kt, last) * KT;  // clamped: a duplicate tile in an unread slot is harmless
+            float* sbase = lds + (kt % NSTAGE) * STAGE;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int p = wave * PPW + i;
+                const float* g = src[i] + ((p < 4 * NA) ? (size_t)k0 : (size_t)k0 * ld);
+                __builtin_amdgcn_global_load_lds((global_cvoid*)g, (lds_void*)(sbase + dst[i]), 16, 0, 0);
+            }
+        };
+        auto make_noise = [&](int r) {
+            if constexpr (NOISY && !(ABL & 64)) {
+                const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const NormalPair p = normal_pair(a.seed, a.row_offset + b, a.step, j);
+                lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
+                if constexpr (MODE == MODE_DL) lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
+                if constexpr (MODE == MODE_MF)  // the NEXT step's normal, for the next measured amplitude
+                    lds_noise[(1 * 16 + r) * NTHREADS + tid] =
+                        a.s.mf.has_next ? normal_pair(a.seed, a.row_offset + b, a.step + 1, j).n0 : 0.0f;
+            }
+        };
+        // tile kt must have landed before the barrier that precedes its first fragment read:
+        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PPW)
+        auto publish = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+            if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        };
+#pragma unroll
+        for (int kt = 0; kt < NSTAGE; ++kt) dma_tile(kt);
+        publish();  // tiles 0, 1 visible
+        // the consumers read tile 0's fragments right after that barrier: slot 0 may only be
+        // refilled (with tile NSTAGE) once they are done
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nkt; ++t) {
+            dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
+            if (gen_noise && t < 16) make_noise(t);
+            publish();             // tile t + 2 visible
+        }
+        if (gen_noise)
+            for (int r = min(nkt, 16); r < 16; ++r) make_noise(r);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue
+        return;
+    }
+
+    // ============================= consumer waves =======================================
     // ---- epilogue operands, fetched now so their latency hides under the whole GEMM -----
     // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
     //   erow(r) = (r & 3) + 8 * (r >> 2) + 4 * half
@@ -196,56 +335,19 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
         }
     }
     const float vj = col_ok ? a.V[j] : 0.0f;
+    const float shift_j = a.in_shift * a.qsum[j];  // shift * colsum(Q)[j]
 
-    // ---- global -> register staging addresses ------------------------------------
-    const int a_r = tid >> 3, a_k = (tid & 7) << 2;   // A tile: 32 rows x 8 float4
-    const int b_r = tid >> 5, b_c = (tid & 31) << 2;  // Q tile: rows b_r + 8q, 32 float4 per row
-    const float* gA0 = a.a0 + (size_t)(row0 + a_r) * ld + a_k;
-    const float* gA1 = (NA == 2) ? a.a1 + (size_t)(row0 + a_r) * ld + a_k : nullptr;
-    const float* gQ = a.Q + (size_t)b_r * ld + col0 + b_c;
-    const size_t q_step = (size_t)8 * ld;
-    const int sa_off = a_r * LDA + a_k;
-    const int sb_off = NA * A_TILE + b_r * BN + b_c;
-
-    struct Staged {
-        f32x4 ra[NA], rq[4];
-    };
-    auto load_tile = [&](Staged& g, int kt) {
-        const int k0 = kt * KT;
-        g.ra[0] = *reinterpret_cast<const f32x4*>(gA0 + k0);
-        if constexpr (NA == 2) g.ra[1] = *reinterpret_cast<const f32x4*>(gA1 + k0);
-        const float* q = gQ + (size_t)k0 * ld;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g.rq[i] = *reinterpret_cast<const f32x4*>(q + i * q_step);
-    };
-    auto store_tile = [&](const Staged& g, int stage) {
-        float* base = lds + stage * STAGE;
-#pragma unroll
-        for (int n = 0; n < NA; ++n)
-            *reinterpret_cast<f32x4*>(base + n * A_TILE + sa_off) = g.ra[n] * a.in_scale + a.in_shift;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(base + sb_off + 8 * i * BN) = g.rq[i];
-    };
-
-    // fragment read offsets inside a stage
-    const int fa = l31 * LDA + 16 * half;
+    // fragment read offsets inside a stage (A: swizzled chunk position)
+    const int sw = (l31 >> 1) & 7;
+    const int fa = l31 * KT;
     const int fb = NA * A_TILE + (16 * half) * BN + 32 * wave + l31;
-    auto read_frags = [&](Frags<NA>& f, int stage) {
-        const float* st = lds + stage * STAGE;
-#pragma unroll
-        for (int n = 0; n < NA; ++n)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                f.a[n][q] = *reinterpret_cast<const f32x4*>(st + n * A_TILE + fa + 4 * q);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) f.b[m] = st[fb + m * BN];
-    };
-
-    // one eighth of a tile's fragments (slot sl of 8): keeps the LDS queue shallow so MFMA
-    // issue never waits behind a burst of reads
+    // one eighth of a tile's fragments (slot sl of 8): keeps the LDS queue shallow
     auto read_frags_part = [&](Frags<NA>& f, int stage, int sl) {
         const float* st = lds + stage * STAGE;
-        if (sl < 4 * NA) f.a[sl >> 2][sl & 3] = *reinterpret_cast<const f32x4*>(st + (sl >> 2) * A_TILE + fa + 4 * (sl & 3));
+        if (sl < 4 * NA) {
+            const int n = sl >> 2, q = sl & 3;
+            f.a[n][q] = *reinterpret_cast<const f32x4*>(st + n * A_TILE + fa + 4 * ((4 * half + q) ^ sw));
+        }
         f.b[2 * sl] = st[fb + (2 * sl) * BN];
         f.b[2 * sl + 1] = st[fb + (2 * sl + 1) * BN];
     };
@@ -268,162 +370,51 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
             }
     };
 
-    // Philox noise for accumulator register r of this lane, generated under the MFMAs of
-    // K tile r (sliced into the MFMA issue gaps) and parked in LDS until the epilogue.
-    // MF carries a second stream: the NEXT step's normals (for the next measured amplitude).
-    constexpr int NPH = (MODE == MODE_MF) ? 2 : 1;
-    PhiloxState ph[NPH];
-    float ph_radius[NPH];
-    auto noise_begin = [&](int r) {
-        const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-        for (int i = 0; i < NPH; ++i) ph[i] = philox_init(a.row_offset + b, a.step + i, j);
-    };
-    auto noise_rounds = [&](int r0, int r1) {
-#pragma unroll
-        for (int i = 0; i < NPH; ++i) philox_rounds(ph[i], a.seed, r0, r1);
-    };
-    auto noise_radius = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPH; ++i) ph_radius[i] = philox_radius(ph[i]);
-    };
-    auto noise_end = [&](int r) {
-        const NormalPair p = philox_pair(ph[0], ph_radius[0]);
-        lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
-        if constexpr (MODE == MODE_DL) lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
-        if constexpr (MODE == MODE_MF) lds_noise[(1 * 16 + r) * NTHREADS + tid] = philox_pair(ph[1], ph_radius[1]).n0;
-    };
-    auto make_noise = [&](int r) {
-        noise_begin(r);
-        noise_rounds(0, 10);
-        noise_radius();
-        noise_end(r);
-    };
-    const bool gen_noise = NOISY && !a.replay;
-
-    const int nkt = (a.N + KT - 1) / KT;
-    const int last = nkt - 1;
-    // Two staging register sets: the loads of tile t+4 are issued in iteration t and written
-    // to the ring in iteration t+2, ~1.6 tiles (~1.5 us) of MFMA time later.
-    Staged gs0, gs1;
     Frags<NA> f0, f1;
-    {   // prologue: tiles 0,1 into the ring, tiles 2,3 in flight (indices clamped: a
-        // duplicate of the last tile in a ring slot nobody consumes is harmless)
-        Staged t0, t1;
-        load_tile(t0, 0);
-        load_tile(t1, min(1, last));
-        load_tile(gs0, min(2, last));
-        load_tile(gs1, min(3, last));
-        store_tile(t0, 0);
-        store_tile(t1, 1);
-    }
-    __syncthreads();
-    read_frags(f0, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop body starts with settled LDS counters
-
-    // Iteration t, branch-free.  Eight order-pinned slots (sched_barrier(0): nothing moves
-    // across); slot s = the MFMAs of k-steps 2s, 2s+1 of tile t, plus ONE staging action
-    // (fragment reads of tile t+1 | ring write of tile t+2 | global loads of tile t+4) and ONE
-    // slice of the Philox state machine for accumulator register t, alternated with the
-    // MFMAs by sched_group_barrier so the matrix pipe never waits on VALU/LDS/VMEM issue.
-    // One barrier per tile.  Reads/writes past the last tile touch ring slots nobody consumes.
-#define CCVM_SLOT_BEGIN() __builtin_amdgcn_sched_barrier(0)
-#define CCVM_SLOT_END(VALU_PER_MFMA)                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2 * NA; ++i_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             /* 1 MFMA      */ \
-        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0); /* VALU        */ \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             /* 1 DS read   */ \
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             /* 1 DS write  */ \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             /* 1 VMEM read */ \
-    }                                                                                   \
-    __builtin_amdgcn_sched_barrier(0)
-    auto iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, Staged& g, int t, auto with_noise) {
-        constexpr bool WN = decltype(with_noise)::value;
-        constexpr int V = (24 * NPH) / (2 * NA) + 2;  // VALU ops offered per MFMA gap
-        const int k4 = min(t + 4, last) * KT;
-        float* wbase = lds + ((t + 2) % NSTAGE) * STAGE;
-        const float* q4 = gQ + (size_t)k4 * ld;
-        const int rstage = (t + 1) % NSTAGE;
-#define CCVM_READS(SL) if constexpr (!(ABL & 4)) read_frags_part(nxt, rstage, SL)
-        CCVM_SLOT_BEGIN();
-        CCVM_READS(0);
-        if constexpr (WN) { noise_begin(t); noise_rounds(0, 2); }
-        mfma_range(cur, 0, 2);
-        CCVM_SLOT_END(V);
-        CCVM_READS(1);
-        if constexpr (!(ABL & 2)) {
+    __syncthreads();  // tiles 0, 1 are in the ring (fence + barrier: LDS reads stay below it)
 #pragma unroll
-            for (int n = 0; n < NA; ++n)
-                *reinterpret_cast<f32x4*>(wbase + n * A_TILE + sa_off) = g.ra[n] * a.in_scale + a.in_shift;
+    for (int sl = 0; sl < 8; ++sl) read_frags_part(f0, 0, sl);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop starts with settled LDS counters
+    if constexpr (!(ABL & 32)) __syncthreads();  // slot 0 may now be refilled
+
+    // iteration t: the 16*NA MFMAs of tile t (fragments in registers) with the fragment reads of
+    // tile t+1 in their issue gaps -- slot by slot, order pinned, and none in the last slot so no
+    // read latency is exposed at the barrier.
+    auto c_iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, int t) {
+        const int rstage = (t + 1) % NSTAGE;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) {
+                // 8 read groups over slots 0..5: slots 0,1 carry two
+                if (sl < 2) { read_frags_part(nxt, rstage, 2 * sl); read_frags_part(nxt, rstage, 2 * sl + 1); }
+                else if (sl < 6) read_frags_part(nxt, rstage, sl + 2);
+            }
+            mfma_range(cur, 2 * sl, 2 * sl + 2);
+#pragma unroll
+            for (int i_ = 0; i_ < 2 * NA; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
+            }
         }
-        if constexpr (WN) noise_rounds(2, 4);
-        mfma_range(cur, 2, 4);
-        CCVM_SLOT_END(V);
-        CCVM_READS(2);
-        if constexpr (!(ABL & 2)) {
-            *reinterpret_cast<f32x4*>(wbase + sb_off) = g.rq[0];
-            *reinterpret_cast<f32x4*>(wbase + sb_off + 8 * BN) = g.rq[1];
-        }
-        if constexpr (WN) noise_rounds(4, 6);
-        mfma_range(cur, 4, 6);
-        CCVM_SLOT_END(V);
-        CCVM_READS(3);
-        if constexpr (!(ABL & 2)) {
-            *reinterpret_cast<f32x4*>(wbase + sb_off + 16 * BN) = g.rq[2];
-            *reinterpret_cast<f32x4*>(wbase + sb_off + 24 * BN) = g.rq[3];
-        }
-        if constexpr (WN) noise_rounds(6, 8);
-        mfma_range(cur, 6, 8);
-        CCVM_SLOT_END(V);
-        CCVM_READS(4);
-        if constexpr (!(ABL & 1)) {
-            g.ra[0] = *reinterpret_cast<const f32x4*>(gA0 + k4);
-            if constexpr (NA == 2) g.ra[1] = *reinterpret_cast<const f32x4*>(gA1 + k4);
-            g.rq[0] = *reinterpret_cast<const f32x4*>(q4);
-        }
-        if constexpr (WN) noise_rounds(8, 10);
-        mfma_range(cur, 8, 10);
-        CCVM_SLOT_END(V);
-        CCVM_READS(5);
-        if constexpr (!(ABL & 1)) {
-            g.rq[1] = *reinterpret_cast<const f32x4*>(q4 + q_step);
-            g.rq[2] = *reinterpret_cast<const f32x4*>(q4 + 2 * q_step);
-            g.rq[3] = *reinterpret_cast<const f32x4*>(q4 + 3 * q_step);
-        }
-        if constexpr (WN) noise_radius();
-        mfma_range(cur, 10, 12);
-        CCVM_SLOT_END(V);
-        CCVM_READS(6);
-        if constexpr (WN) noise_end(t);
-        mfma_range(cur, 12, 14);
-        CCVM_SLOT_END(V);
-        CCVM_READS(7);
-        mfma_range(cur, 14, 16);
-        CCVM_SLOT_END(V);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(ABL & 32)) __syncthreads();
     };
-#undef CCVM_SLOT_BEGIN
-#undef CCVM_SLOT_END
-#undef CCVM_READS
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
-    int t = 0;
-    if (gen_noise) {
-        const int tn = min(nkt, 16);
-        for (; t + 1 < tn; t += 2) {
-            iteration(f0, f1, gs0, t, Yes{});
-            iteration(f1, f0, gs1, t + 1, Yes{});
+    {
+        int t = 0;
+        for (; t + 1 < nkt; t += 2) {
+            c_iteration(f0, f1, t);
+            c_iteration(f1, f0, t + 1);
         }
+        if (t < nkt) c_iteration(f0, f1, t);
     }
-    const int noise_done = t;
-    for (; t + 1 < nkt; t += 2) {
-        iteration(f0, f1, gs0, t, No{});
-        iteration(f1, f0, gs1, t + 1, No{});
-    }
-    if (t < nkt) iteration(f0, f1, gs0, t, No{});
-    if (gen_noise) {
-        for (int r = noise_done; r < 16; ++r) make_noise(r);
-    }
+    __syncthreads();  // producers' noise is complete
+
+    // the affine input map, folded:  (x*scale + shift) @ Q = scale * (x @ Q) + shift * colsum(Q)
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = __builtin_fmaf(a.in_scale, acc[n][r], shift_j);
 
     if constexpr (ABL & 16) {  // ablation: keep the accumulators live, skip the real epilogue
         float sum = vj;
@@ -458,13 +449,13 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
         }
         return;
     } else {
-        // results first (pure arithmetic on registers), stores afterwards: no load ever waits
-        // behind a store
-        float r0v[16], r1v[16], r2v[16], r3v[16], r4v[16];
+        // every operand is already in registers (prefetch above), so each result is stored
+        // as soon as it is computed: no load ever waits behind a store
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool ok = col_ok && (b < a.B);
+            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
             float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
             if constexpr (NOISY) {
                 if (a.replay) {
@@ -476,105 +467,60 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepArgs a) {
                             if (a.s.mf.has_next) n0n = a.w0n[widx];
                     }
                 } else {
-                    // written by this same thread in noise_end: no barrier needed
+                    // written by this thread's producer twin, behind the final barrier
                     n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
                     if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
                     if constexpr (MODE == MODE_MF) n0n = lds_noise[(1 * 16 + r) * NTHREADS + tid];
                 }
             }
 
+            // Adam preconditioning of the feedback term g (MF / Langevin variants)
+            auto adam = [&](float g) {
+                if constexpr (ADAM) {
+                    float m, v;
+                    const float out = adam_precondition(a.ad, g, e2[r], e3[r], m, v);
+                    if (ok) {
+                        a.am[idx] = m;
+                        if (a.ad.use_v) a.av[idx] = v;
+                    }
+                    return out;
+                } else {
+                    return g;
+                }
+            };
+
             if constexpr (MODE == MODE_DL) {
-                const DlScalars& k = a.s.dl;
-                const float c = e0[r], s = e1[r];
-                const float c2 = c * c, s2 = s * s;
-                const float diff = k.g2 * __builtin_sqrtf(c2 + s2 + 0.5f);
-                const float fbk = k.a_v * vj;
-                r0v[r] = c + (k.a_q * acc[0][r] + fbk + k.dt * ((k.pm_c - c2 - s2) * c)) + diff * (n0 * k.w_c);
-                r1v[r] = s + (k.a_q * acc[1][r] + fbk + k.dt * ((k.pm_s - c2 - s2) * s)) + diff * (n1 * k.w_s);
+                float cn, sn;
+                dl_update(a.s.dl, e0[r], e1[r], acc[0][r], acc[1][r], vj, n0, n1, cn, sn);
+                if (ok) {
+                    a.o0[idx] = cn;
+                    a.o1[idx] = sn;
+                }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
-                const float mu = e0[r], sg = e1[r];
-                const float wdot = n0 * k.inv_sdt;
-                const float mu2 = mu * mu;
-                const float term1 = (k.a0 - k.g2 * mu2) * mu;
-                float fb = k.f_q * acc[0][r] + k.f_v * vj;
-                if constexpr (ADAM) {
-                    const AdamScalars& ad = a.ad;
-                    const float m = ad.beta1 * e2[r] + ad.one_m_beta1 * fb;
-                    const float mhat = m * ad.inv_bc1;
-                    float upd;
-                    if (ad.use_v) {
-                        const float v = ad.beta2 * e3[r] + ad.one_m_beta2 * (fb * fb);
-                        const float vhat = v * ad.inv_bc2;
-                        upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
-                        r4v[r] = v;
-                    } else {
-                        upd = ad.alpha * mhat;
-                    }
-                    r3v[r] = m;
-                    fb = ad.add_assign ? fb + upd : upd;
+                const float fb = adam(__builtin_fmaf(k.f_q, acc[0][r], k.f_v * vj));
+                float mun, sgn;
+                mf_update(k, e0[r], e1[r], fb, n0, mun, sgn);
+                if (ok) {
+                    a.st0[idx] = mun;
+                    a.st1[idx] = sgn;
+                    if (k.has_next) a.o0[idx] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
                 }
-                const float sh = sg - 0.5f;
-                const float dsig = 2.0f * (k.a0 - 3.0f * k.g2 * mu2) * sg - 2.0f * k.j_i * (sh * sh) + (k.one_j + 2.0f * k.g2 * mu2);
-                const float diffusion = k.sqrt_j * sh * wdot;
-                const float mun = mu + k.dt * (term1 + fb + diffusion);
-                r0v[r] = mun;
-                r1v[r] = sg + k.dt * dsig;
-                r2v[r] = clampf(mun + k.k_next * n0n, -k.S, k.S);
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
-                const float c = e0[r];
-                float g = k.g_q * acc[0][r] + k.g_v * vj;
-                if constexpr (ADAM) {
-                    const AdamScalars& ad = a.ad;
-                    const float m = ad.beta1 * e2[r] + ad.one_m_beta1 * g;
-                    const float mhat = m * ad.inv_bc1;
-                    float upd;
-                    if (ad.use_v) {
-                        const float v = ad.beta2 * e3[r] + ad.one_m_beta2 * (g * g);
-                        const float vhat = v * ad.inv_bc2;
-                        upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
-                        r4v[r] = v;
-                    } else {
-                        upd = ad.alpha * mhat;
-                    }
-                    r3v[r] = m;
-                    g = ad.add_assign ? g + upd : upd;
-                }
-                float x = c + k.dt_fs * g + k.w * n0;
-                if (k.use_pump) x += k.dt * ((k.pm - c * c) * c);
-                r0v[r] = clampf(x, -k.S, k.S);
+                const float g = adam(__builtin_fmaf(k.g_q, acc[0][r], k.g_v * vj));
+                const float x = lv_update(k, e0[r], g, n0);
+                if (ok) a.o0[idx] = x;
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
-                r0v[r] = clampf(e0[r] - k.step * (acc[0][r] + vj), k.lo, k.hi);
+                if (ok) a.o0[idx] = clampf(__builtin_fmaf(-k.step, acc[0][r] + vj, e0[r]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_ADAMPP) {
                 const PpScalars& k = a.s.pp;
                 const float g = acc[0][r] + vj;
-                r0v[r] = clampf(e0[r] - k.step * (g / (fabsf(g) + k.eps)), k.lo, k.hi);
+                if (ok) a.o0[idx] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[r]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                r0v[r] = k.step * acc[0][r] + k.eps * vj;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
-            if (col_ok && b < a.B) {
-                if constexpr (MODE == MODE_DL) {
-                    a.o0[idx] = r0v[r];
-                    a.o1[idx] = r1v[r];
-                } else if constexpr (MODE == MODE_MF) {
-                    a.st0[idx] = r0v[r];
-                    a.st1[idx] = r1v[r];
-                    if (a.s.mf.has_next) a.o0[idx] = r2v[r];
-                } else {
-                    a.o0[idx] = r0v[r];
-                }
-                if constexpr (ADAM) {
-                    a.am[idx] = r3v[r];
-                    if (a.ad.use_v) a.av[idx] = r4v[r];
-                }
+                if (ok) a.o0[idx] = __builtin_fmaf(k.step, acc[0][r], k.eps * vj);
             }
         }
     }
@@ -659,6 +605,26 @@ __global__ void energy_reduce_kernel(const float* partial, int nstrips, int rows
     float e = 0.0f;
     for (int s = 0; s < nstrips; ++s) e += partial[(size_t)s * rows_pad + b];
     obj[b] = e * scaled_by;
+}
+
+// Column sums of Q in two deterministic passes: part[s][j] over row slice s, then a fixed-order
+// sum over slices (no atomics: results must not depend on arrival order).
+constexpr int QSUM_SLICES = 32;
+__global__ void qsum_partial_kernel(const float* __restrict__ Q, int N, int ld, float* __restrict__ part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (j >= ld) return;
+    const int per = (N + QSUM_SLICES - 1) / QSUM_SLICES;
+    const int k0 = s * per, k1 = min(N, k0 + per);
+    float acc = 0.0f;
+    for (int k = k0; k < k1; ++k) acc += Q[(size_t)k * ld + j];
+    part[(size_t)s * ld + j] = acc;
+}
+__global__ void qsum_final_kernel(const float* __restrict__ part, int ld, float* __restrict__ qsum) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    float acc = 0.0f;
+    for (int s = 0; s < QSUM_SLICES; ++s) acc += part[(size_t)s * ld + j];
+    qsum[j] = acc;
 }
 
 // Qs = 1/2 (Q + Q^T) on the padded [ld][ld] matrix

@@ -1,0 +1,69 @@
+// Counter-based Wiener noise for the fused step kernels (gfx950 device code).
+//
+// Threefry2x32-20 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11 -- the Random123 generator JAX also uses).  Chosen over Philox4x32 for this chip:
+// Threefry is add / rotate / xor only (full-rate VALU), while every Philox round needs two
+// 32x32->64 multiplies, which are quarter-rate on CDNA and measurably slowed the MFMA pipe
+// they share a SIMD with ("Noise").
+//
+//   counter = (column, global_row_lo),  key = (seed_lo ^ step, seed_hi ^ global_row_hi)
+//
+// so a trajectory's noise depends only on its GLOBAL row index, the column and the step --
+// never on the tiling, the grid or how the batch is sharded over GPUs.  The two output words
+// give one Box-Muller pair (n0, n1): the DL solver uses n0 for the in-phase and n1 for the
+// quadrature increment; single-state solvers use n0.
+//
+// oracle/noise_ref.py restates exactly this mapping on the host (integer part bit-exact,
+// checked against the Random123 known-answer vectors; float part to ~1e-6).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccvm {
+
+struct NormalPair {
+    float n0, n1;
+};
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
+    return __builtin_amdgcn_alignbit(x, x, 32 - r);  // v_alignbit_b32: one full-rate op
+}
+
+__device__ __forceinline__ void threefry2x32_20(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
+                                                uint32_t& o0, uint32_t& o1) {
+    const uint32_t ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
+    uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+#define CCVM_TF_ROUND(R) x0 += x1; x1 = rotl32(x1, R) ^ x0
+#define CCVM_TF_KEY(S) x0 += ks[(S) % 3]; x1 += ks[((S) + 1) % 3] + (S)
+    CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(1u);
+    CCVM_TF_ROUND(17); CCVM_TF_ROUND(29); CCVM_TF_ROUND(16); CCVM_TF_ROUND(24); CCVM_TF_KEY(2u);
+    CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(3u);
+    CCVM_TF_ROUND(17); CCVM_TF_ROUND(29); CCVM_TF_ROUND(16); CCVM_TF_ROUND(24); CCVM_TF_KEY(4u);
+    CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(5u);
+#undef CCVM_TF_ROUND
+#undef CCVM_TF_KEY
+    o0 = x0;
+    o1 = x1;
+}
+
+// 24-bit uniform strictly inside (0, 1): ((x >> 8) + 0.5) * 2^-24.
+__device__ __forceinline__ float u01(uint32_t x) {
+    return (static_cast<float>(x >> 8) + 0.5f) * 5.9604644775390625e-8f;
+}
+
+__device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, int step, int col) {
+    uint32_t x0, x1;
+    threefry2x32_20(static_cast<uint32_t>(col), static_cast<uint32_t>(grow),
+                    static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step),
+                    static_cast<uint32_t>(seed >> 32) ^ static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
+                    x0, x1);
+    // Box-Muller: r = sqrt(-2 ln u1); v_sin/v_cos take their argument in revolutions
+    const float r = __builtin_sqrtf(-2.0f * __logf(u01(x0)));
+    const float u2 = u01(x1);
+    NormalPair p;
+    p.n0 = r * __builtin_amdgcn_cosf(u2);
+    p.n1 = r * __builtin_amdgcn_sinf(u2);
+    return p;
+}
+
+}  // namespace ccvm

@@ -87,7 +87,7 @@ def unpack(src, rows, cols):
 class NoiseSpec:
     """How the Wiener increments of a run are produced.
 
-    mode "philox": counter-based generator fused into the step kernel; ``seed`` keys
+    mode "philox": counter-based generator (Threefry2x32-20) fused into the step kernel; ``seed`` keys
         it and ``row_offset`` is the global index of local row 0 (batch sharding).
     mode "replay": standard normals are drawn on the host from ``generator`` (None =
         torch's global CPU generator, i.e. exactly what the reference consumes after
@@ -106,14 +106,18 @@ class NoiseSpec:
             raise ValueError(f"unknown noise mode {self.mode!r}; expected 'philox' or 'replay'")
 
 
-def default_noise(mode=None, row_offset=0):
-    """Noise spec for a solver call.  PHILOX seeds are drawn from torch's global CPU
+def draw_seed():
+    """A PHILOX key from torch's global CPU generator (so torch.manual_seed reproduces runs)."""
+    return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+
+
+def default_noise(mode=None, row_offset=0, seed=None):
+    """Noise spec for a solver call.  PHILOX seeds default to a draw from torch's global CPU
     generator so ``torch.manual_seed`` makes runs reproducible in both modes."""
     mode = mode or os.environ.get("CCVM_AMD_NOISE", "philox")
     if mode == "replay":
         return NoiseSpec(mode="replay", row_offset=row_offset)
-    seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-    return NoiseSpec(mode="philox", seed=seed, row_offset=row_offset)
+    return NoiseSpec(mode="philox", seed=draw_seed() if seed is None else int(seed), row_offset=row_offset)
 
 
 class _NoiseFeeder:
@@ -325,9 +329,10 @@ def feedback(x, q_matrix, v_vector, in_scale, in_shift, f_q, f_v):
         prob = DeviceProblem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
         yp = torch.zeros_like(xp)
+        ws = torch.empty((max(lib.ccvm_workspace_bytes(_lib.WS_FEEDBACK, b, n), 16),), dtype=torch.uint8, device=dev)
         _lib.check(
             lib.ccvm_feedback(_ptr(prob.q), _ptr(prob.v), _ptr(xp), _ptr(yp), b, n, prob.ld, float(in_scale),
-                              float(in_shift), float(f_q), float(f_v), _stream_ptr()),
+                              float(in_shift), float(f_q), float(f_v), _ptr(ws), ws.numel(), _stream_ptr()),
             "ccvm_feedback",
         )
         return unpack(yp, b, n).to(x.device)

@@ -1,0 +1,106 @@
+"""Batch sharding over the GPUs of one node.
+
+Trajectories never interact, so a batch of B rows is split into contiguous row ranges,
+one per rank (one process per GPU, ``torch.distributed``; backend "nccl" is RCCL over
+xGMI).  Nothing is exchanged during the T steps.  Each rank runs its rows with the SAME
+Philox key and its own ``row_offset``, so the union of the shards is bit-identical to the
+unsharded run.  The only collective is one all-gather of the per-row objective values
+(B floats in total) after the loop; the reference has no counterpart (it is single-process).
+"""
+import copy
+import time
+
+import torch
+import torch.distributed as dist
+
+from .solution import Solution
+
+
+def shard_bounds(batch, world, rank):
+    """Contiguous [lo, hi) of ``rank``; the first ``batch % world`` ranks get one extra row."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(int(batch), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _all_gather_rows(local, counts, group):
+    """All-gather of 1-D/2-D tensors whose leading sizes differ (pad to the maximum)."""
+    world = len(counts)
+    width = max(counts)
+    pad_shape = (width,) + tuple(local.shape[1:])
+    padded = torch.zeros(pad_shape, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([part[:n] for part, n in zip(parts, counts)])
+
+
+def broadcast_seed(seed, group=None, device="cpu"):
+    """Rank 0's Philox key for every rank."""
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
+
+
+def solve_sharded(solver, instance, group=None, gather_variables=False, local_solve=None, **call_kwargs):
+    """Solve ``instance`` with ``solver.batch_size`` rows split over the ranks of ``group``.
+
+    Every rank returns the SAME global ``Solution`` (objective values of all rows, global
+    success statistics, solve time = slowest rank's wall time / global batch).  ``variables``
+    hold this rank's rows unless ``gather_variables``.
+
+    ``local_solve(solver, instance, **call_kwargs) -> Solution`` defaults to calling the solver
+    (the HIP engine); tests inject an oracle-backed stand-in to exercise the sharding logic on
+    CPU with gloo.
+    """
+    if not dist.is_initialized():
+        raise RuntimeError("solve_sharded needs an initialised torch.distributed process group")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    batch = int(solver.batch_size)
+    if batch < world:
+        raise ValueError(f"batch_size {batch} is smaller than the number of ranks {world}")
+    counts = [hi - lo for lo, hi in (shard_bounds(batch, world, r) for r in range(world))]
+    lo, hi = shard_bounds(batch, world, rank)
+    backend = dist.get_backend(group)
+    comm_device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    local = copy.copy(solver)  # shallow: shares parameter_key, rebinds the per-rank fields
+    local.batch_size = hi - lo
+    local.row_offset = solver.row_offset + lo
+    if solver.noise_seed is None and (solver.noise_mode or "philox") == "philox":
+        from . import engine
+
+        local.noise_seed = broadcast_seed(engine.draw_seed() if rank == 0 else 0, group, comm_device)
+
+    t0 = time.time()
+    sol = (local_solve or (lambda s, inst, **kw: s(instance=inst, **kw)))(local, instance, **call_kwargs)
+    wall = torch.tensor([time.time() - t0, sol.pp_time * (hi - lo)], dtype=torch.float64, device=comm_device)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX, group=group)
+
+    obj = _all_gather_rows(sol.objective_values.to(comm_device), counts, group)
+    variables = dict(sol.variables)
+    if gather_variables:
+        variables = {
+            k: _all_gather_rows(v.to(comm_device), counts, group).to(v.device) if torch.is_tensor(v) else v
+            for k, v in sol.variables.items()
+        }
+    out = Solution(
+        problem_size=sol.problem_size,
+        batch_size=batch,
+        instance_name=sol.instance_name,
+        iterations=sol.iterations,
+        objective_values=obj.to(sol.objective_values.device),
+        solve_time=float(wall[0].item()) / batch,
+        pp_time=float(wall[1].item()) / batch,
+        optimal_value=sol.optimal_value,
+        best_value=sol.best_value,
+        num_frac_values=sol.num_frac_values,
+        solution_vector=sol.solution_vector,
+        variables=variables,
+        device=sol.device,
+    )
+    out.evolution_file = sol.evolution_file
+    out.shard = {"rank": rank, "world": world, "rows": (lo, hi)}
+    return out

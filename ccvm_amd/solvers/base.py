@@ -81,6 +81,8 @@ class CCVMSolver(ABC):
         self.noise_mode = None
         #: global index of this process's first batch row (multi-GPU sharding)
         self.row_offset = 0
+        #: PHILOX key; None draws one from torch's global CPU generator per call
+        self.noise_seed = None
 
     # ------------------------------------------------------------------ #
     @property
@@ -208,7 +210,7 @@ class CCVMSolver(ABC):
     def _new_trajectories(self, kind, batch_size, iterations, params, adam=None):
         self._require_fused_hooks()
         problem = engine.DeviceProblem(self.q_matrix, self.v_vector)
-        noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset)
+        noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset, seed=self.noise_seed)
         return engine.Trajectories(
             problem, batch_size, kind, iterations, params, self.solution_bounds, noise, adam=adam
         )

@@ -50,7 +50,8 @@ typedef enum ccvm_status {
 
 /* Wiener-noise source for one call. */
 typedef enum ccvm_noise_mode {
-    CCVM_NOISE_PHILOX = 0, /* Philox4x32-10 + Box-Muller fused into the step kernel   */
+    CCVM_NOISE_PHILOX = 0, /* counter-based generator (Threefry2x32-20 + Box-Muller) fused
+                              into the step kernel; the name is historical               */
     CCVM_NOISE_REPLAY = 1  /* read standard normals the caller generated (parity mode) */
 } ccvm_noise_mode;
 
@@ -123,8 +124,9 @@ int ccvm_unpack(const float* src, int src_ld,
                 float* dst, int rows, int cols, int dst_ld, void* stream);
 
 /* ---- the hot path: nsteps fused Euler-Maruyama steps ------------------------- */
-/* Bytes of caller-provided scratch each *_run call needs (ping-pong state, the MF
- * measured-amplitude buffers, schedule tables).  `solver`: 0 DL, 1 MF, 2 Langevin. */
+/* Bytes of caller-provided scratch a call needs (ping-pong state, the MF measured-amplitude
+ * buffers, column sums of Q).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run, 2 ccvm_langevin_run,
+ * 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);
 
 /* Steps step0 .. step0+nsteps-1 of a T-step DL-CCVM run, in place on c and s.
@@ -172,10 +174,12 @@ int ccvm_energy(const float* Q, const float* V, const float* x,
  *   y = f_q * ((x * in_scale + in_shift) @ Q) + f_v * V
  * e.g. MFSolver._calculate_grads_boxqp (mf_solver.py:200-233) is in_scale = (u-l)/S,
  * in_shift = u+l, f_q = -fs (u-l)/(4S), f_v = -fs (u-l)/(2S).  y must not alias x and
- * must have zero padding on entry (it is only written on the logical B x N region). */
+ * must have zero padding on entry (it is only written on the logical B x N region).
+ * workspace: ccvm_workspace_bytes(5, B, N). */
 int ccvm_feedback(const float* Q, const float* V, const float* x, float* y,
                   int B, int N, int ld, double in_scale, double in_shift,
-                  double f_q, double f_v, void* stream);
+                  double f_q, double f_v,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Post-processors.  x is updated in place.
  * grad-descent: `iters` times  x <- clamp(x - step * (x Q + V), lo, hi)

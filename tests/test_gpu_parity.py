@@ -119,14 +119,14 @@ def test_philox_mode_matches_oracle(kind, n, b, t):
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
     from oracle import ccvm_oracle as oracle
-    from oracle.philox_ref import PhiloxNoise
+    from oracle.noise_ref import FusedNoise
 
     q, v, f = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
     seed, row_offset = 0x1234_5678_9ABC, 4096
     noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=row_offset)
     prob = engine.DeviceProblem(q, v)
-    ref_noise = PhiloxNoise(seed, row_offset)
+    ref_noise = FusedNoise(seed, row_offset)
     if kind == "dl":
         traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)
         traj.advance(t)
@@ -162,7 +162,7 @@ def test_philox_mode_matches_oracle(kind, n, b, t):
 
 def test_philox_normals_match_host_restatement_and_are_gaussian():
     from ccvm_amd import engine
-    from oracle.philox_ref import normal_pairs
+    from oracle.noise_ref import normal_pairs
 
     seed, off, step, b, n = 987654321012345, 7, 123, 512, 300
     w0, w1 = engine.philox_normals(seed, off, step, b, n, two=True)
@@ -279,7 +279,7 @@ def test_abi_rejects_bad_arguments(hip_lib):
     nz.mode = 7
     p = _lib.LangevinParams()
     p.dt, p.S, p.lower, p.upper = 0.1, 1.0, 0.0, 1.0
-    ws = torch.zeros(64 * 128 * 4, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(hip_lib.ccvm_workspace_bytes(2, 10, 20), dtype=torch.uint8, device=dev)
     q = torch.zeros((128, 128), device=dev)
     args = lambda step0, k, T, wsb: hip_lib.ccvm_langevin_run(
         ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(x.data_ptr()), 10, 20,

@@ -1,0 +1,109 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups, with the oracle standing
+in for the HIP engine as the per-rank solve.  Checks that sharding by global row index is
+exact (union of shards == unsharded run), that the gather handles uneven shards, and that
+every rank ends with the same global Solution."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_local_solve(solver, instance, **kw):
+    """Oracle-backed stand-in for the engine: PL solver with the engine's Philox stream."""
+    from ccvm_amd.solution import Solution
+    from oracle import ccvm_oracle as oracle
+    from oracle.noise_ref import FusedNoise
+
+    n = instance.problem_size
+    p = solver.parameter_key[n]
+    out = oracle.solve_pl(
+        instance.q_matrix, instance.v_vector, solver.batch_size, p["iterations"], p["pump"], p["dt"],
+        p["sigma"], p["feedback_scale"], p["S"], scaled_by=instance.scaled_by,
+        noise=FusedNoise(solver.noise_seed, solver.row_offset),
+    )
+    return Solution(
+        problem_size=n, batch_size=solver.batch_size, instance_name=instance.name,
+        iterations=p["iterations"], objective_values=out["objective_values"], solve_time=1e-3,
+        pp_time=0.0, optimal_value=instance.optimal_sol, best_value=instance.best_sol,
+        num_frac_values=0, solution_vector=[], variables={"problem_variables": out["problem_variables"]},
+    )
+
+
+def _make(batch):
+    from ccvm_amd.solvers import PumpedLangevinSolver
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
+
+    inst = synthetic_instance(24, seed=3)
+    inst.optimal_sol = 50.0
+    solver = PumpedLangevinSolver(device="cpu", batch_size=batch)
+    solver.parameter_key = {24: dict(EXAMPLE_PARAMS["pl"], iterations=12)}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    return solver, inst
+
+
+def _worker(rank, world, port, batch, queue):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ccvm_amd.sharded import solve_sharded
+
+        solver, inst = _make(batch)
+        torch.manual_seed(100 + rank)  # ranks disagree on purpose: rank 0's key must win
+        sol = solve_sharded(solver, inst, gather_variables=True, local_solve=_oracle_local_solve)
+        queue.put((rank, sol.objective_values.clone(), sol.variables["problem_variables"].clone(),
+                   sol.best_objective_value, sol.solution_performance, sol.batch_size, sol.shard,
+                   solver.noise_seed))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch", [(2, 10), (3, 10)])
+def test_sharded_solve_equals_unsharded(world, batch):
+    from oracle.noise_ref import FusedNoise  # noqa: F401
+
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((queue.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    # the key every rank used is rank 0's draw after torch.manual_seed(100)
+    torch.manual_seed(100)
+    from ccvm_amd import engine
+
+    seed = engine.draw_seed()
+    solver, inst = _make(batch)
+    solver.noise_seed = seed
+    whole = _oracle_local_solve(solver, inst)
+    sizes = []
+    for rank, obj, xs, best, perf, b, shard, _ in results:
+        assert b == batch and shard["world"] == world and shard["rank"] == rank
+        sizes.append(shard["rows"][1] - shard["rows"][0])
+        assert torch.equal(obj, whole.objective_values)          # exact: same global rows, same noise
+        assert torch.equal(xs, whole.variables["problem_variables"])
+        assert best == whole.best_objective_value and perf == whole.solution_performance
+    assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1
+
+
+def test_shard_bounds():
+    from ccvm_amd.sharded import shard_bounds
+
+    assert [shard_bounds(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert [shard_bounds(8000, 8, r) for r in range(8)] == [(1000 * r, 1000 * (r + 1)) for r in range(8)]
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)

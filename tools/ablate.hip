@@ -53,12 +53,12 @@ float time_us(F&& launch, int iters) {
 
 template <int ABL>
 float run_variant(const StepArgs& a, int iters) {
-    return time_us([&] { hipLaunchKernelGGL((step_kernel<MODE_DL, false, ABL>), dim3(a.nrb * a.ncb), dim3(NTHREADS), 0, 0, a); }, iters);
+    return time_us([&] { hipLaunchKernelGGL((step_kernel<MODE_DL, false, ABL>), dim3(a.nrb * a.ncb), dim3(2 * NTHREADS), 0, 0, a); }, iters);
 }
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 1000, B = argc > 2 ? atoi(argv[2]) : 1000;
-    const int ld = (N + 127) / 128 * 128, rows = (B + 63) / 64 * 64;
+    const int ld = argc > 3 ? atoi(argv[3]) : (N + 127) / 128 * 128, rows = (B + 63) / 64 * 64;
     const size_t state = (size_t)rows * ld;
     float *Q, *V, *c, *s, *c2, *s2, *out;
     CK(hipMalloc(&Q, (size_t)ld * ld * 4));
@@ -87,22 +87,21 @@ int main(int argc, char** argv) {
     StepArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = Q; a.V = V; a.a0 = c; a.a1 = s; a.o0 = c2; a.o1 = s2;
-    a.B = B; a.N = N; a.ld = ld; a.nrb = (B + BM - 1) / BM; a.ncb = ld / BN;
+    a.B = B; a.N = N; a.ld = ld; a.nrb = (B + BM - 1) / BM; a.ncb = (N + BN - 1) / BN;
     a.in_scale = 0.37f; a.in_shift = 1.0f; a.seed = 42; a.step = 3;
     a.s.dl = DlScalars{-1e-4f, -1e-4f, 1.f, -3.f, 1e-3f, 0.1f, 0.03f, 0.03f};
+    a.qsum = V;
     const int it = 50;
-    printf("grid %d x %d threads, N=%d B=%d\n", a.nrb * a.ncb, NTHREADS, N, B);
+    printf("grid %d x %d threads, N=%d B=%d ld=%d\n", a.nrb * a.ncb, 2 * NTHREADS, N, B, ld);
     printf("full                         : %8.2f us\n", run_variant<0>(a, it));
     printf("no epilogue            (16)  : %8.2f us\n", run_variant<16>(a, it));
-    printf("no global loads         (1)  : %8.2f us\n", run_variant<1>(a, it));
-    printf("no ring writes          (2)  : %8.2f us\n", run_variant<2>(a, it));
-    printf("no loads, no writes     (3)  : %8.2f us\n", run_variant<3>(a, it));
+    printf("no DMA loads            (1)  : %8.2f us\n", run_variant<1>(a, it));
     printf("no frag reads           (4)  : %8.2f us\n", run_variant<4>(a, it));
-    printf("no loads/writes/reads   (7)  : %8.2f us\n", run_variant<7>(a, it));
-    printf("... and no barrier     (39)  : %8.2f us\n", run_variant<39>(a, it));
-    printf("... and no epilogue    (55)  : %8.2f us\n", run_variant<55>(a, it));
+    printf("no noise               (64)  : %8.2f us\n", run_variant<64>(a, it));
+    printf("no loads, no noise     (65)  : %8.2f us\n", run_variant<65>(a, it));
+    printf("no loads/reads/noise   (69)  : %8.2f us\n", run_variant<69>(a, it));
+    printf("... and no epilogue    (85)  : %8.2f us\n", run_variant<85>(a, it));
     printf("no MFMA                 (8)  : %8.2f us\n", run_variant<8>(a, it));
     printf("no MFMA, no epilogue   (24)  : %8.2f us\n", run_variant<24>(a, it));
-    a.replay = 0;
     return 0;
 }
