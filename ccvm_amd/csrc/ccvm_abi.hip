@@ -121,7 +121,7 @@ void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N
 template <int MODE, bool ADAM>
 int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
     const int grid = a.nrb * a.ncb;
-    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(2 * NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(WG_THREADS), 0, st, a);
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
 }

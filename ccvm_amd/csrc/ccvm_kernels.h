@@ -39,7 +39,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 32;        // batch rows per workgroup
 constexpr int BN = 128;       // output columns per workgroup
 constexpr int KT = 32;        // K tile
-constexpr int NTHREADS = 256; // consumer threads (the tile mapping); the workgroup has 2x this
+constexpr int NTHREADS = 256; // consumer threads (the tile mapping)
+constexpr int NPW = 4;        // producer waves (one per SIMD)
+constexpr int WG_THREADS = NTHREADS + 64 * NPW;
 constexpr int NSTAGE = 4;     // LDS ring depth = DMA prefetch distance in tiles
 constexpr int A_TILE = BM * KT;   // floats, 128-B rows, XOR-swizzled 16-B chunks
 constexpr int Q_TILE = KT * BN;   // floats, 512-B rows, linear
@@ -119,6 +121,7 @@ struct StepArgs {
     const float* w0;    // REPLAY: this step's [N][B] block
     const float* w1;    // REPLAY: DL second stream
     const float* w0n;   // REPLAY (MF): next step's block
+    unsigned long long* dbg;  // ablation stamps only
     uint64_t seed;
     int64_t row_offset;
     int step;
@@ -173,7 +176,7 @@ __device__ __forceinline__ void dl_update(const DlScalars& k, float c, float s, 
                                           float n0, float n1, float& cn, float& sn) {
     const float c2 = c * c, s2 = s * s;
     const float r2 = c2 + s2;
-    const float diff = k.g2 * __builtin_sqrtf(r2 + 0.5f);
+    const float diff = k.g2 * __builtin_amdgcn_sqrtf(r2 + 0.5f);  // raw v_sqrt_f32 (1 ulp)
     const float fbk = k.a_v * vj;
     const float dc = __builtin_fmaf(k.a_q, qc, fbk) + k.dt * ((k.pm_c - r2) * c);
     const float ds = __builtin_fmaf(k.a_q, qs, fbk) + k.dt * ((k.pm_s - r2) * s);
@@ -206,13 +209,25 @@ struct Frags {
     float b[16];     // Q[k = 16h + m][col 32w + l31]
 };
 
+// Diagnostic stamp.  NOTE: the lgkmcnt(0) it needs also drains LDS-DMA in flight (LDS-DMA counts
+// on lgkmcnt as well as vmcnt), so on the producer side it serialises the DMA it brackets.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ unsigned long long stamp_delta(unsigned long long a, unsigned long long b) { return b - a; }
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void global_cvoid;
 
 // ABL: ablation bits for tools/ablate.hip (0 in the product): 1 no DMA loads, 4 no fragment
-// reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier (timing only), 64 no noise.
+// reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier (timing only), 64 no noise,
+// 128 s_memtime stamps of the loop phases into a.dbg (diagnostic build: shares, not run time).
 template <int MODE, bool ADAM, int ABL = 0>
-__global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
     constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
     constexpr int STAGE = NA * A_TILE + Q_TILE;
@@ -242,25 +257,37 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
 
     if (producer) {
         // =========================== producer waves ====================================
-        // DMA pieces of one tile: 4 per A tile (8 rows x 128 B) then 16 of Q (2 rows x 512 B);
-        // each wave issues PPW of them.  LDS destination = piece base + lane * 16 (hardware);
-        // the A tile's swizzle (chunk c of row r stored at position c ^ ((r >> 1) & 7)) is applied
-        // to the per-lane SOURCE address.
-        constexpr int PPW = NA + 4;
-        const float* src[PPW];
-        int dst[PPW];
+        // DMA pieces of one tile: 4 per A tile (8 rows x 128 B) then 16 of Q (2 rows x 512 B),
+        // dealt round-robin to the NPW producer waves.  LDS destination = piece base + lane * 16
+        // (hardware); the A tile's swizzle (chunk c of row r stored at position c ^ ((r >> 1) & 7))
+        // is applied to the per-lane SOURCE address.
+        constexpr int NPIECE = 4 * NA + 16;
+        constexpr int PMAX = (NPIECE + NPW - 1) / NPW;
+        // Producers issue few instructions but each must get out promptly; at equal priority the
+        // SIMD arbiter favours the older (consumer) wave, which always has an MFMA pending.
+        __builtin_amdgcn_s_setprio(3);
+        const int pw = __builtin_amdgcn_readfirstlane((threadIdx.x - NTHREADS) >> 6);  // 0 .. NPW-1
+        const int plane = threadIdx.x & 63;
+        // Addressing: wave-uniform 64-bit base (SGPRs, advanced per tile by SALU) + a per-lane
+        // 32-bit byte offset that never changes -> no per-tile VALU (every VALU op costs matrix time).
+        unsigned voff[PMAX];
+        int dst[PMAX];
+        bool is_a[PMAX];
+        const char* sbase_g[PMAX];
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i;  // wave-uniform
-            if (p < 4 * NA) {
+        for (int i = 0; i < PMAX; ++i) {
+            const int p = min(pw + NPW * i, NPIECE - 1);  // wave-uniform; a wave without piece i repeats the last
+            is_a[i] = p < 4 * NA;
+            if (is_a[i]) {
                 const int n = p >> 2, g = p & 3;
-                const int r = 8 * g + (lane >> 3), pos = lane & 7;
-                const float* base = (n == 0) ? a.a0 : a.a1;
-                src[i] = base + (size_t)(row0 + r) * ld + 4 * (pos ^ ((r >> 1) & 7));
+                const int r = 8 * g + (plane >> 3), pos = plane & 7;
+                sbase_g[i] = reinterpret_cast<const char*>(((n == 0) ? a.a0 : a.a1) + (size_t)row0 * ld);
+                voff[i] = (unsigned)((r * ld + 4 * (pos ^ ((r >> 1) & 7))) * 4);
                 dst[i] = n * A_TILE + g * 256;
             } else {
                 const int q = p - 4 * NA;
-                src[i] = a.Q + (size_t)(2 * q + (lane >> 5)) * ld + col0 + 4 * (lane & 31);
+                sbase_g[i] = reinterpret_cast<const char*>(a.Q + col0);
+                voff[i] = (unsigned)(((2 * q + (plane >> 5)) * ld + 4 * (plane & 31)) * 4);
                 dst[i] = NA * A_TILE + q * 256;
             }
         }
@@ -269,12 +296,25 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
             const int k0 = min(kt, last) * KT;  // clamped: a duplicate tile in an unread slot is harmless
             float* sbase = lds + (kt % NSTAGE) * STAGE;
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int p = wave * PPW + i;
-                const float* g = src[i] + ((p < 4 * NA) ? (size_t)k0 : (size_t)k0 * ld);
-                __builtin_amdgcn_global_load_lds((global_cvoid*)g, (lds_void*)(sbase + dst[i]), 16, 0, 0);
+            for (int i = 0; i < PMAX; ++i) {
+                const char* tb = sbase_g[i] + (is_a[i] ? (size_t)k0 * 4 : (size_t)k0 * ld * 4);  // scalar
+                // saddr form: SGPR base + 32-bit lane offset, LDS destination base in M0 (written in
+                // the same statement: the compiler does not preserve M0 around asm).  vmcnt is
+                // counted by hand in publish().
+                const unsigned ldst = (unsigned)(size_t)(lds_void*)(sbase + dst[i]);
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(voff[i]), "s"(tb), "s"(ldst)
+                    : "memory");
             }
         };
+        // noise: producer thread (pw, lane) serves consumer thread tid = 64 * (pw & 3) + lane and
+        // the accumulator registers r = 2 * i + (pw >> 2): two independent chains per SIMD
+        constexpr int NCH = NPW / 4;  // noise chains per SIMD
+        const int par = pw >> 2;
         auto make_noise = [&](int r) {
             if constexpr (NOISY && !(ABL & 64)) {
                 const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -287,9 +327,11 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
             }
         };
         // tile kt must have landed before the barrier that precedes its first fragment read:
-        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PPW)
+        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PMAX).  NO lgkmcnt wait here:
+        // LDS-DMA also counts on lgkmcnt (measured: an lgkmcnt(0) drains every DMA in flight, ~1 us
+        // per tile), and the noise ds_writes are only consumed behind the final barrier.
         auto publish = [&]() {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
             if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
         };
 #pragma unroll
@@ -300,17 +342,19 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nkt; ++t) {
             dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
-            if (gen_noise && t < 16) make_noise(t);
+            if (gen_noise && t < 16 / NCH) make_noise(NCH * t + par);
             publish();             // tile t + 2 visible
         }
         if (gen_noise)
-            for (int r = min(nkt, 16); r < 16; ++r) make_noise(r);
+            for (int i = min(nkt, 16 / NCH); i < 16 / NCH; ++i) make_noise(NCH * i + par);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue
         return;
     }
 
     // ============================= consumer waves =======================================
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
     // ---- epilogue operands, fetched now so their latency hides under the whole GEMM -----
     // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
     //   erow(r) = (r & 3) + 8 * (r >> 2) + 4 * half
@@ -319,18 +363,22 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
     constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
     constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
     float e0[16], e1[16], e2[16], e3[16];
-    const size_t ebase = (size_t)(row0 + 4 * half) * ld + j;
+    // element address = [uniform: array + (row0 + 8 * (r >> 2)) * ld]  +  [lane: eoff[r & 3]]
+    // (scalar base + constant 32-bit lane offset: no per-access address VALU)
+    unsigned eoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) eoff[i] = (unsigned)((i + 4 * half) * ld + j);
+    auto gofs = [&](int r) { return (size_t)(row0 + 8 * (r >> 2)) * ld; };  // uniform part
     {
         const float* p0 = (MODE == MODE_MF) ? a.st0 : a.a0;
         const float* p1 = (MODE == MODE_MF) ? a.st1 : a.a1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
-            if constexpr (HAS_E0) e0[r] = p0[idx];
-            if constexpr (HAS_E1) e1[r] = p1[idx];
+            if constexpr (HAS_E0) e0[r] = (p0 + gofs(r))[eoff[r & 3]];
+            if constexpr (HAS_E1) e1[r] = (p1 + gofs(r))[eoff[r & 3]];
             if constexpr (ADAM) {
-                e2[r] = a.am[idx];
-                e3[r] = a.ad.use_v ? a.av[idx] : 0.0f;
+                e2[r] = (a.am + gofs(r))[eoff[r & 3]];
+                e3[r] = a.ad.use_v ? (a.av + gofs(r))[eoff[r & 3]] : 0.0f;
             }
         }
     }
@@ -380,15 +428,32 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
     // iteration t: the 16*NA MFMAs of tile t (fragments in registers) with the fragment reads of
     // tile t+1 in their issue gaps -- slot by slot, order pinned, and none in the last slot so no
     // read latency is exposed at the barrier.
-    auto c_iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, int t) {
-        const int rstage = (t + 1) % NSTAGE;
+    unsigned long long c_work = 0, c_bar = 0, c_last = 0;
+    // per-stage fragment base pointers: inside the loop every LDS address is base + immediate
+    const float* stA[NSTAGE];
+    const float* stB[NSTAGE];
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+        stA[st] = lds + st * STAGE + fa;
+        stB[st] = lds + st * STAGE + fb;
+    }
+    auto read_part = [&](Frags<NA>& f, int st, int sl) {  // st is a compile-time constant at every call
+        if (sl < 4 * NA) {
+            const int n = sl >> 2, q = sl & 3;
+            f.a[n][q] = *reinterpret_cast<const f32x4*>(stA[st] + n * A_TILE + 4 * ((4 * half + q) ^ sw));
+        }
+        f.b[2 * sl] = stB[st][(2 * sl) * BN];
+        f.b[2 * sl + 1] = stB[st][(2 * sl + 1) * BN];
+    };
+    auto c_iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, auto stage_tag) {
+        constexpr int rstage = decltype(stage_tag)::value;
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 4)) {
-                // 8 read groups over slots 0..5: slots 0,1 carry two
-                if (sl < 2) { read_frags_part(nxt, rstage, 2 * sl); read_frags_part(nxt, rstage, 2 * sl + 1); }
-                else if (sl < 6) read_frags_part(nxt, rstage, sl + 2);
+                // 8 read groups over slots 0..5 (slots 0,1 carry two), none right before the barrier
+                if (sl < 2) { read_part(nxt, rstage, 2 * sl); read_part(nxt, rstage, 2 * sl + 1); }
+                else if (sl < 6) read_part(nxt, rstage, sl + 2);
             }
             mfma_range(cur, 2 * sl, 2 * sl + 2);
 #pragma unroll
@@ -398,17 +463,41 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 32)) __syncthreads();
+        if constexpr (ABL & 128) {
+            const unsigned long long s1 = stamp();
+            __syncthreads();
+            const unsigned long long s2 = stamp();
+            c_bar += stamp_delta(s1, s2);
+            c_work += stamp_delta(c_last, s1);
+            c_last = s2;
+        } else if constexpr (!(ABL & 32)) __syncthreads();
     };
     {
+        if constexpr (ABL & 128) c_last = stamp();
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        using S3 = std::integral_constant<int, 3>;
+        static_assert(NSTAGE == 4, "the consumer loop is unrolled by the ring depth");
+        // iteration t reads the fragments of tile t+1 from ring stage (t+1) % 4
         int t = 0;
-        for (; t + 1 < nkt; t += 2) {
-            c_iteration(f0, f1, t);
-            c_iteration(f1, f0, t + 1);
+        for (; t + 3 < nkt; t += 4) {
+            c_iteration(f0, f1, S1{});
+            c_iteration(f1, f0, S2{});
+            c_iteration(f0, f1, S3{});
+            c_iteration(f1, f0, S0{});
         }
-        if (t < nkt) c_iteration(f0, f1, t);
+        if (t < nkt) { c_iteration(f0, f1, S1{}); ++t; }
+        if (t < nkt) { c_iteration(f1, f0, S2{}); ++t; }
+        if (t < nkt) { c_iteration(f0, f1, S3{}); ++t; }
     }
     __syncthreads();  // producers' noise is complete
+    if constexpr (ABL & 128) {
+        if (threadIdx.x == 0) {
+            unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
+            d[4] = c_work; d[5] = c_bar;
+        }
+    }
 
     // the affine input map, folded:  (x*scale + shift) @ Q = scale * (x @ Q) + shift * colsum(Q)
 #pragma unroll
@@ -450,27 +539,28 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
         return;
     } else {
         // every operand is already in registers (prefetch above), so each result is stored
-        // as soon as it is computed: no load ever waits behind a store
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool ok = col_ok && (b < a.B);
-            const size_t idx = ebase + (size_t)((r & 3) + 8 * (r >> 2)) * ld;
+        // as soon as it is computed: no load ever waits behind a store.
+        // `element(r, ok, from_lds)` handles accumulator register r; the common case (whole row
+        // block inside the batch, fused noise) runs it under ONE column mask with no per-element
+        // branches, edge blocks and replay mode take the general path.
+        auto element = [&](int r, bool ok, auto fused_tag) {
+            constexpr bool FUSED = decltype(fused_tag)::value;
+            const size_t gb = gofs(r);       // uniform
+            const unsigned lo = eoff[r & 3];  // per lane
             float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
             if constexpr (NOISY) {
-                if (a.replay) {
-                    if (ok) {
-                        const size_t widx = (size_t)j * a.B + b;
-                        n0 = a.w0[widx];
-                        if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
-                        if constexpr (MODE == MODE_MF)
-                            if (a.s.mf.has_next) n0n = a.w0n[widx];
-                    }
-                } else {
+                if constexpr (FUSED) {
                     // written by this thread's producer twin, behind the final barrier
                     n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
                     if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
                     if constexpr (MODE == MODE_MF) n0n = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                } else if (ok) {
+                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const size_t widx = (size_t)j * a.B + b;
+                    n0 = a.w0[widx];
+                    if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
+                    if constexpr (MODE == MODE_MF)
+                        if (a.s.mf.has_next) n0n = a.w0n[widx];
                 }
             }
 
@@ -480,8 +570,8 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
                     float m, v;
                     const float out = adam_precondition(a.ad, g, e2[r], e3[r], m, v);
                     if (ok) {
-                        a.am[idx] = m;
-                        if (a.ad.use_v) a.av[idx] = v;
+                        (a.am + gb)[lo] = m;
+                        if (a.ad.use_v) (a.av + gb)[lo] = v;
                     }
                     return out;
                 } else {
@@ -493,8 +583,8 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
                 float cn, sn;
                 dl_update(a.s.dl, e0[r], e1[r], acc[0][r], acc[1][r], vj, n0, n1, cn, sn);
                 if (ok) {
-                    a.o0[idx] = cn;
-                    a.o1[idx] = sn;
+                    (a.o0 + gb)[lo] = cn;
+                    (a.o1 + gb)[lo] = sn;
                 }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
@@ -502,26 +592,41 @@ __global__ __launch_bounds__(2 * NTHREADS) void step_kernel(const StepArgs a) {
                 float mun, sgn;
                 mf_update(k, e0[r], e1[r], fb, n0, mun, sgn);
                 if (ok) {
-                    a.st0[idx] = mun;
-                    a.st1[idx] = sgn;
-                    if (k.has_next) a.o0[idx] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
+                    (a.st0 + gb)[lo] = mun;
+                    (a.st1 + gb)[lo] = sgn;
+                    if (k.has_next) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
                 const float g = adam(__builtin_fmaf(k.g_q, acc[0][r], k.g_v * vj));
                 const float x = lv_update(k, e0[r], g, n0);
-                if (ok) a.o0[idx] = x;
+                if (ok) (a.o0 + gb)[lo] = x;
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
-                if (ok) a.o0[idx] = clampf(__builtin_fmaf(-k.step, acc[0][r] + vj, e0[r]), k.lo, k.hi);
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, acc[0][r] + vj, e0[r]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_ADAMPP) {
                 const PpScalars& k = a.s.pp;
                 const float g = acc[0][r] + vj;
-                if (ok) a.o0[idx] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[r]), k.lo, k.hi);
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[r]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                if (ok) a.o0[idx] = __builtin_fmaf(k.step, acc[0][r], k.eps * vj);
+                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, acc[0][r], k.eps * vj);
             }
+        };
+        const bool whole_block = row0 + BM <= a.B;  // wave-uniform
+        if (whole_block && (gen_noise || !NOISY)) {
+            if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) element(r, true, Yes{});
+            }
+        } else if (gen_noise || !NOISY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                element(r, col_ok && (row0 + (r & 3) + 8 * (r >> 2) + 4 * half < a.B), Yes{});
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                element(r, col_ok && (row0 + (r & 3) + 8 * (r >> 2) + 4 * half < a.B), No{});
         }
     }
 }

@@ -57,8 +57,10 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, i
                     static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step),
                     static_cast<uint32_t>(seed >> 32) ^ static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
                     x0, x1);
-    // Box-Muller: r = sqrt(-2 ln u1); v_sin/v_cos take their argument in revolutions
-    const float r = __builtin_sqrtf(-2.0f * __logf(u01(x0)));
+    // Box-Muller: r = sqrt(-2 ln u1) with the raw v_log_f32 (log2) / v_sqrt_f32 (u1 >= 2^-25: no
+    // denormal fix-ups needed; every VALU op here costs matrix-pipe time); v_sin/v_cos take
+    // their argument in revolutions
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(x0)));
     const float u2 = u01(x1);
     NormalPair p;
     p.n0 = r * __builtin_amdgcn_cosf(u2);

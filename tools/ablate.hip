@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #include "../ccvm_amd/csrc/ccvm_kernels.h"
 
@@ -53,7 +54,7 @@ float time_us(F&& launch, int iters) {
 
 template <int ABL>
 float run_variant(const StepArgs& a, int iters) {
-    return time_us([&] { hipLaunchKernelGGL((step_kernel<MODE_DL, false, ABL>), dim3(a.nrb * a.ncb), dim3(2 * NTHREADS), 0, 0, a); }, iters);
+    return time_us([&] { hipLaunchKernelGGL((step_kernel<MODE_DL, false, ABL>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, 0, a); }, iters);
 }
 
 int main(int argc, char** argv) {
@@ -91,8 +92,12 @@ int main(int argc, char** argv) {
     a.in_scale = 0.37f; a.in_shift = 1.0f; a.seed = 42; a.step = 3;
     a.s.dl = DlScalars{-1e-4f, -1e-4f, 1.f, -3.f, 1e-3f, 0.1f, 0.03f, 0.03f};
     a.qsum = V;
+    unsigned long long* dbg;
+    CK(hipMalloc(&dbg, 256 * 8 * 8));
+    CK(hipMemset(dbg, 0, 256 * 8 * 8));
+    a.dbg = dbg;
     const int it = 50;
-    printf("grid %d x %d threads, N=%d B=%d ld=%d\n", a.nrb * a.ncb, 2 * NTHREADS, N, B, ld);
+    printf("grid %d x %d threads, N=%d B=%d ld=%d\n", a.nrb * a.ncb, WG_THREADS, N, B, ld);
     printf("full                         : %8.2f us\n", run_variant<0>(a, it));
     printf("no epilogue            (16)  : %8.2f us\n", run_variant<16>(a, it));
     printf("no DMA loads            (1)  : %8.2f us\n", run_variant<1>(a, it));
@@ -103,5 +108,19 @@ int main(int argc, char** argv) {
     printf("... and no epilogue    (85)  : %8.2f us\n", run_variant<85>(a, it));
     printf("no MFMA                 (8)  : %8.2f us\n", run_variant<8>(a, it));
     printf("no MFMA, no epilogue   (24)  : %8.2f us\n", run_variant<24>(a, it));
+    {   // phase shares from the stamped build (cycles per tile, median over workgroups)
+        hipLaunchKernelGGL((step_kernel<MODE_DL, false, 128>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hd(256 * 8);
+        CK(hipMemcpy(hd.data(), dbg, 256 * 8 * 8, hipMemcpyDeviceToHost));
+        const char* names[6] = {"P dma issue", "P noise", "P vmcnt wait", "P barrier wait", "C work (reads+MFMA)", "C barrier wait"};
+        const int nkt = (N + 31) / 32, nwg = a.nrb * a.ncb;
+        for (int k = 4; k < 6; ++k) {
+            std::vector<double> v;
+            for (int w = 0; w < nwg && w < 256; ++w) v.push_back((double)hd[w * 8 + k] / nkt);
+            std::sort(v.begin(), v.end());
+            printf("%-22s: min %7.0f  median %7.0f  max %7.0f cycles/tile\n", names[k], v.front(), v[v.size() / 2], v.back());
+        }
+    }
     return 0;
 }
