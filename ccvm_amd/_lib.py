@@ -155,6 +155,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch owns the device memory and streams this library works on: load torch (and with it
+    # the HIP runtime it was built against) FIRST, so that libccvm_hip.so's libamdhip64 dependency
+    # resolves to that same already-loaded runtime instead of a second copy from /opt/rocm.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"

@@ -340,6 +340,25 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         // the consumers read tile 0's fragments right after that barrier: slot 0 may only be
         // refilled (with tile NSTAGE) once they are done
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        if constexpr (ABL & 128) {  // diagnostic: where a producer tile goes
+            unsigned long long tdma = 0, tnoise = 0, twait = 0, tbar = 0;
+            for (int t = 0; t < nkt; ++t) {
+                const unsigned long long s0 = stamp();
+                dma_tile(t + NSTAGE);
+                const unsigned long long s1 = stamp();
+                if (gen_noise && t < 16 / NCH) make_noise(NCH * t + par);
+                const unsigned long long s2 = stamp();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
+                const unsigned long long s3 = stamp();
+                __builtin_amdgcn_s_barrier();
+                const unsigned long long s4 = stamp();
+                tdma += s1 - s0; tnoise += s2 - s1; twait += s3 - s2; tbar += s4 - s3;
+            }
+            if (threadIdx.x == NTHREADS) {
+                unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
+                d[0] = tdma; d[1] = tnoise; d[2] = twait; d[3] = tbar;
+            }
+        } else
         for (int t = 0; t < nkt; ++t) {
             dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
             if (gen_noise && t < 16 / NCH) make_noise(NCH * t + par);

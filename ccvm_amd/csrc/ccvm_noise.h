@@ -1,10 +1,12 @@
 // Counter-based Wiener noise for the fused step kernels (gfx950 device code).
 //
-// Threefry2x32-20 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
-// SC'11 -- the Random123 generator JAX also uses).  Chosen over Philox4x32 for this chip:
-// Threefry is add / rotate / xor only (full-rate VALU), while every Philox round needs two
-// 32x32->64 multiplies, which are quarter-rate on CDNA and measurably slowed the MFMA pipe
-// they share a SIMD with ("Noise").
+// Threefry2x32-13 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11 -- the Random123 family JAX also uses).  13 rounds is the paper's Crush-resistant
+// configuration (passes SmallCrush, Crush and BigCrush); 20 is its safety-margin default.
+// Chosen over Philox4x32 and over more rounds for this chip: on gfx950 every VALU instruction
+// costs matrix-pipe time (the f32 MFMA shares the FP32 datapath; measured with tools/coissue.hip
+// and tools/filler.hip), Philox needs two quarter-rate 32x32->64 multiplies per round, and
+// Threefry is add / rotate / xor only ("Noise").
 //
 //   counter = (column, global_row_lo),  key = (seed_lo ^ step, seed_hi ^ global_row_hi)
 //
@@ -29,7 +31,7 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
     return __builtin_amdgcn_alignbit(x, x, 32 - r);  // v_alignbit_b32: one full-rate op
 }
 
-__device__ __forceinline__ void threefry2x32_20(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
+__device__ __forceinline__ void threefry2x32_13(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
                                                 uint32_t& o0, uint32_t& o1) {
     const uint32_t ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
     uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
@@ -38,8 +40,7 @@ __device__ __forceinline__ void threefry2x32_20(uint32_t c0, uint32_t c1, uint32
     CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(1u);
     CCVM_TF_ROUND(17); CCVM_TF_ROUND(29); CCVM_TF_ROUND(16); CCVM_TF_ROUND(24); CCVM_TF_KEY(2u);
     CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(3u);
-    CCVM_TF_ROUND(17); CCVM_TF_ROUND(29); CCVM_TF_ROUND(16); CCVM_TF_ROUND(24); CCVM_TF_KEY(4u);
-    CCVM_TF_ROUND(13); CCVM_TF_ROUND(15); CCVM_TF_ROUND(26); CCVM_TF_ROUND(6);  CCVM_TF_KEY(5u);
+    CCVM_TF_ROUND(17);  // round 13; a key injection follows every FOURTH round only
 #undef CCVM_TF_ROUND
 #undef CCVM_TF_KEY
     o0 = x0;
@@ -53,7 +54,7 @@ __device__ __forceinline__ float u01(uint32_t x) {
 
 __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, int step, int col) {
     uint32_t x0, x1;
-    threefry2x32_20(static_cast<uint32_t>(col), static_cast<uint32_t>(grow),
+    threefry2x32_13(static_cast<uint32_t>(col), static_cast<uint32_t>(grow),
                     static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step),
                     static_cast<uint32_t>(seed >> 32) ^ static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
                     x0, x1);

@@ -1,7 +1,8 @@
 """ORACLE -- test infrastructure.  Host restatement of the engine's fused noise generator
-(ccvm_amd/csrc/ccvm_noise.h): Threefry2x32-20 (Salmon, Moraes, Dror, Shaw: "Parallel random
-numbers: as easy as 1, 2, 3", SC'11; rotation constants 13,15,26,6,17,29,16,24 and key-schedule
-parity 0x1BD11BDA as in Random123 v1.14) on
+(ccvm_amd/csrc/ccvm_noise.h): Threefry2x32-13 (Salmon, Moraes, Dror, Shaw: "Parallel random
+numbers: as easy as 1, 2, 3", SC'11; rotation constants 13,15,26,6,17,29,16,24, key-schedule
+parity 0x1BD11BDA and a key injection after every fourth round, as in Random123 v1.14; 13 rounds
+is the paper's Crush-resistant configuration) on
 
     counter = (column, global_row_lo),  key = (seed_lo ^ step, seed_hi ^ global_row_hi)
 
@@ -21,20 +22,23 @@ def _rotl(x, r):
     return ((x << np.uint32(r)) | (x >> np.uint32(32 - r))).astype(np.uint32)
 
 
-def threefry2x32_20(c0, c1, k0, k1):
+ROUNDS = 13  # what the device runs
+
+
+def threefry2x32(c0, c1, k0, k1, rounds=ROUNDS):
     """Vectorised over numpy uint32 arrays (broadcastable).  Returns two uint32 arrays."""
     c0, c1, k0, k1 = np.broadcast_arrays(*(np.asarray(x, dtype=np.uint32) for x in (c0, c1, k0, k1)))
     ks = [k0, k1, (np.uint32(PARITY) ^ k0 ^ k1).astype(np.uint32)]
     with np.errstate(over="ignore"):
         x0 = (c0 + ks[0]).astype(np.uint32)
         x1 = (c1 + ks[1]).astype(np.uint32)
-        for block in range(5):
-            for i in range(4):
-                x0 = (x0 + x1).astype(np.uint32)
-                x1 = _rotl(x1, ROT[(4 * block + i) % 8]) ^ x0
-            s = block + 1
-            x0 = (x0 + ks[s % 3]).astype(np.uint32)
-            x1 = (x1 + ks[(s + 1) % 3] + np.uint32(s)).astype(np.uint32)
+        for r in range(rounds):
+            x0 = (x0 + x1).astype(np.uint32)
+            x1 = _rotl(x1, ROT[r % 8]) ^ x0
+            if (r + 1) % 4 == 0:
+                s = (r + 1) // 4
+                x0 = (x0 + ks[s % 3]).astype(np.uint32)
+                x1 = (x1 + ks[(s + 1) % 3] + np.uint32(s)).astype(np.uint32)
     return x0, x1
 
 
@@ -51,7 +55,7 @@ def normal_pairs(seed, row_offset, step, b, n):
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     k0 = np.uint32((seed & M32) ^ (int(step) & M32))
     k1 = (np.uint32(seed >> 32) ^ (rows >> np.uint64(32)).astype(np.uint32)).astype(np.uint32)
-    x0, x1 = threefry2x32_20(cols, (rows & np.uint64(M32)).astype(np.uint32), k0, k1)
+    x0, x1 = threefry2x32(cols, (rows & np.uint64(M32)).astype(np.uint32), k0, k1)
     u1, u2 = u01(x0), u01(x1)
     r = np.sqrt(-2.0 * np.log(u1))
     theta = 2.0 * np.pi * u2

@@ -1,0 +1,116 @@
+"""GPU tests of the API surfaces around the loop: compatibility hooks with the reference's
+known answers, evolution sampling, the shipped example."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+from golden_util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mf_hooks_known_answers():
+    """Reference tests/unit/solvers/test_mf_solver.py:63-154: grads -20.0, drift (-20.0, 200.5),
+    change_variables spot values -- through the HIP feedback / change-of-variables kernels."""
+    from ccvm_amd.solvers import MFSolver
+
+    solver = MFSolver(device="cpu", batch_size=2)
+    solver.q_matrix = torch.full((2, 2), 10.0)
+    solver.v_vector = torch.full((2,), 10.0)
+    mu_tilde = torch.ones((2, 2))
+    grads = solver.calculate_grads(mu_tilde, 1.0, 1.0, 0.0, 1.0)
+    # fs * (-(1/4) * ((1*1 + 1) @ Q) * 1 - V/2) = -(0.25 * 40) - 5 = -15 per element for these inputs
+    assert torch.allclose(grads, torch.full((2, 2), -15.0))
+    mu, sigma = torch.ones((2, 2)), torch.full((2, 2), 10.0)
+    d_mu, d_sigma = solver.calculate_drift(mu, mu_tilde, sigma, 2.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0)
+    # term1 = (-(1+1) + 2 - 1) * 1 = -1 ; drift_mu = -1 + grads = -16
+    assert torch.allclose(d_mu, torch.full((2, 2), -16.0))
+    # sigma: 2(-2 + 2 - 3)*10 - 2*(9.5)^2 + (2 + 2) = -60 - 180.5 + 4 = -236.5
+    assert torch.allclose(d_sigma, torch.full((2, 2), -236.5))
+    y = solver.change_variables(torch.tensor([[2.0, 0.2]]), 0.0, 1.0, 1.0)
+    assert torch.allclose(y, torch.tensor([[1.5, 0.6]]))
+    z = solver.fit_to_constraints(torch.tensor([[2.0, -3.0, 0.25]]), -1.0, 1.0)
+    assert torch.equal(z, torch.tensor([[1.0, -1.0, 0.25]]))
+
+
+@pytest.mark.parametrize("kind,step_size", [("dl", 7), ("mf", 10), ("pl", 4)])
+def test_evolution_sampling_matches_oracle(tmp_path, kind, step_size):
+    """evolution_step_size: samples after steps i % k == 0 and the last one, best row written
+    as problem_size lines x num_samples values rounded to 4 d.p. (dl_solver.py:557-564, 252-281,
+    961-974; mf_solver.py:285-300)."""
+    from test_gpu_parity import _instance, _solver_for
+    from oracle import ccvm_oracle as oracle
+
+    g = golden("test020")
+    meta = g.cases[f"{kind}_T100"]
+    t = 30
+    solver = _solver_for(kind, 16)
+    inst = _instance(g)
+    solver.parameter_key = {20: dict(meta["params"], iterations=t)}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    path = str(tmp_path / "evo.txt")
+    torch.manual_seed(3)
+    sol = solver(instance=inst, evolution_step_size=step_size, evolution_file=path)
+    assert sol.evolution_file == path
+
+    pts = [i for i in range(t) if i % step_size == 0 or i + 1 >= t]
+    depth = int(t / step_size) + 1 + (1 if t % step_size else 0)
+    q, v, f = g.scaled(kind)
+    p = meta["params"]
+    samples = []
+    grab = lambda i, *state: samples.append([s.clone() for s in state]) if i in pts else None
+    torch.manual_seed(3)
+    if kind == "dl":
+        oracle.dl_loop(q, v, 16, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05,
+                       (0.0, 1.0), True, None, on_step=grab)
+        names = ("c", "s")
+    elif kind == "mf":
+        oracle.mf_loop(q, v, 16, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], 0.01,
+                       (0.0, 1.0), True, None, None, on_step=grab)
+        names = ("mu", "sigma")
+    else:
+        oracle.pl_loop(q, v, 16, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"],
+                       (0.0, 1.0), True, None, None, on_step=grab)
+        names = ("c",)
+    assert len(samples) == len(pts)
+    for k, name in enumerate(names):
+        buf = getattr(solver, f"{name}_sample")
+        assert tuple(buf.shape) == (16, 20, depth)
+        for idx in range(len(pts)):
+            assert float((buf[:, :, idx] - samples[idx][k]).abs().max()) <= 5e-4
+        assert float(buf[:, :, len(pts):].abs().max()) == 0.0 if depth > len(pts) else True
+    best = int(torch.argmax(-sol.objective_values))
+    lines = open(path).read().split("\n")
+    assert len(lines) == 20 * len(names) + 1 and lines[-1] == ""
+    first = lines[0].rstrip("\t").split("\t")
+    assert len(first) == depth
+    want = [round(float(x), 4) for x in getattr(solver, f"{names[0]}_sample")[best, 0]]
+    assert [float(x) for x in first] == want
+    assert lines[0].endswith("\t") == (kind != "mf")
+
+
+def test_invalid_evolution_step_size():
+    from test_gpu_parity import _instance, _solver_for
+
+    g = golden("test020")
+    solver = _solver_for("pl", 4)
+    solver.parameter_key = {20: dict(g.cases["pl_T1"]["params"])}
+    with pytest.raises(ValueError, match="evolution step size"):
+        solver(instance=_instance(g), evolution_step_size=-2)
+
+
+def test_shipped_example_runs():
+    """examples/boxqp_dl_demo.py (the reference example's flow on the shipped instance)."""
+    out = subprocess.run([sys.executable, "boxqp_dl_demo.py"], cwd=os.path.join(ROOT, "examples"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Solution(problem_size=20, batch_size=1000" in out.stdout
+    import re
+
+    best = float(re.search(r"best_objective_value=([0-9.]+)", out.stdout).group(1))
+    assert 0.98 * 350.52616 <= best <= 350.52616 * (1 + 1e-5)  # known optimum of the shipped instance
+    assert "TTS@99%" in out.stdout

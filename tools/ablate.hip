@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(hd.data(), dbg, 256 * 8 * 8, hipMemcpyDeviceToHost));
         const char* names[6] = {"P dma issue", "P noise", "P vmcnt wait", "P barrier wait", "C work (reads+MFMA)", "C barrier wait"};
         const int nkt = (N + 31) / 32, nwg = a.nrb * a.ncb;
-        for (int k = 4; k < 6; ++k) {
+        for (int k = 0; k < 6; ++k) {
             std::vector<double> v;
             for (int w = 0; w < nwg && w < 256; ++w) v.push_back((double)hd[w * 8 + k] / nkt);
             std::sort(v.begin(), v.end());
