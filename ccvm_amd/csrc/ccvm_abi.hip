@@ -7,10 +7,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/ccvm_hip.h"
 #include "ccvm_kernels.h"
+#include "ccvm_persist.h"
 
 using namespace ccvm;
 
@@ -126,6 +128,32 @@ int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
     return CCVM_OK;
 }
 
+// ---- persistent small-N path -----------------------------------------------------------------
+constexpr int PERSIST_MAX_N = 128;
+constexpr int TABLE_STEPS = 4096;  // steps per persistent launch (schedule table rows in the workspace)
+size_t table_bytes() { return (size_t)TABLE_STEPS * 8 * sizeof(float); }
+
+// CCVM_AMD_KERNEL=tile|persist forces a path (tests / profiling); default: persistent when it applies.
+bool want_persist(int N) {
+    if (N > PERSIST_MAX_N) return false;
+    const char* e = std::getenv("CCVM_AMD_KERNEL");  // read per call so a test can flip it
+    return !(e && !std::strcmp(e, "tile"));
+}
+
+template <int MODE>
+int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
+    const int rows = (MODE == MODE_DL) ? 8 : 16;
+    const dim3 grid((a.B + rows - 1) / rows), block(256);
+    const int N = a.N;
+    if (N <= 32) hipLaunchKernelGGL((persist_kernel<MODE, 2, 1>), grid, block, 0, st, a);
+    else if (N <= 64) hipLaunchKernelGGL((persist_kernel<MODE, 4, 1>), grid, block, 0, st, a);
+    else if (N <= 96) hipLaunchKernelGGL((persist_kernel<MODE, 6, 2>), grid, block, 0, st, a);
+    else if (N <= 112) hipLaunchKernelGGL((persist_kernel<MODE, 7, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((persist_kernel<MODE, 8, 2>), grid, block, 0, st, a);
+    CCVM_CHECK_LAUNCH(name);
+    return CCVM_OK;
+}
+
 inline int ew_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -145,9 +173,9 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t state = rows * ld * sizeof(float);
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
-        case 0: return 2 * state + qs;                   // DL: c', s'
+        case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
         case 1: return 2 * state + qs;                   // MF: measured-amplitude ping-pong
-        case 2: return state + qs;                       // Langevin: c'
+        case 2: return state + qs + table_bytes();       // Langevin: c'
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
         case 5: return qs;                               // ccvm_feedback
@@ -209,6 +237,29 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
     if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
+    if (nsteps > 0 && want_persist(N)) {
+        // whole chunks of the trajectory in one launch each (ccvm_persist.h)
+        float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N));
+        PersistArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.x1 = s; pa.table = table;
+        pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
+                       step0 + done, k};
+            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            pa.step0 = step0 + done;
+            pa.nsteps = k;
+            if (pa.replay) {
+                pa.w0 = nz->w0 + (size_t)done * N * B;
+                pa.w1 = nz->w1 + (size_t)done * N * B;
+            }
+            if ((rc = launch_persist<MODE_DL>(pa, st, fn))) return rc;
+        }
+        return CCVM_OK;
+    }
     int cur = 0;
     for (int i = step0; i < step0 + nsteps; ++i) {
         const double frac = (double)(i + 1) / (double)T;
@@ -352,6 +403,25 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     a.in_scale = (float)(ul / (2.0 * p->S));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
+    if (!use_adam && want_persist(N)) {
+        float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + state * sizeof(float) + qsum_area_bytes(N));
+        PersistArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table;
+        pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            LvSched sc{p->dt, p->sigma, p->feedback_scale, p->S, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
+                       step0 + done, k};
+            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            pa.step0 = step0 + done;
+            pa.nsteps = k;
+            if (pa.replay) pa.w0 = nz->w0 + (size_t)done * N * B;
+            if ((rc = launch_persist<MODE_LANGEVIN>(pa, st, fn))) return rc;
+        }
+        return CCVM_OK;
+    }
     if (use_adam) {
         a.am = adam->m;
         a.av = adam->v;
