@@ -174,7 +174,7 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
         case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
-        case 1: return 2 * state + qs;                   // MF: measured-amplitude ping-pong
+        case 1: return 3 * state + qs;                   // MF: measured-amplitude ping-pong + noise carry
         case 2: return state + qs + table_bytes();       // Langevin: c'
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
@@ -312,7 +312,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
 
     const size_t state = (size_t)ccvm_rows(B) * ld;
     float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
-    if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
+    float* carry = static_cast<float*>(ws) + 2 * state;  // this step's normals (fused mode)
+    if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
@@ -323,8 +324,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     // measured amplitude of the first step of this chunk (mf_solver.py:551-554)
     {
         const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(step0))) / sdt);
-        hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], B, N, ld,
-                           k0, (float)p->S, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
+        hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], carry, B, N,
+                           ld, k0, (float)p->S, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
         CCVM_CHECK_LAUNCH(fn);
     }
 
@@ -332,7 +333,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     base_args(a, Q, V, B, N, ld);
     a.in_scale = (float)(ul / p->S);
     a.in_shift = (float)up;
-    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum))) return rc;
+    a.carry = carry;
     a.st0 = mu;
     a.st1 = sigma;
     if (use_adam) {

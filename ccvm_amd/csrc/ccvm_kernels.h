@@ -116,6 +116,7 @@ struct StepArgs {
     float* o1;          // DL: s'
     float* st0;         // MF: mu (in place)
     float* st1;         // MF: sigma (in place)
+    float* carry;       // MF: this step's normals, written by the previous step (or mf_prepare), in place
     float* am;          // Adam first moment (in place)
     float* av;          // Adam second moment (in place)
     const float* w0;    // REPLAY: this step's [N][B] block
@@ -253,7 +254,9 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     const bool col_ok = j < a.N;
     const int nkt = (a.N + KT - 1) / KT;
     const int last = nkt - 1;
-    const bool gen_noise = NOISY && !a.replay;
+    const bool fused = NOISY && !a.replay;  // noise source: fused generator vs replayed normals
+    // what the producers generate: MF makes the NEXT step's normals only (none after the last step)
+    const bool gen_noise = fused && (MODE != MODE_MF || a.s.mf.has_next);
 
     if (producer) {
         // =========================== producer waves ====================================
@@ -315,15 +318,26 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         // the accumulator registers r = 2 * i + (pw >> 2): two independent chains per SIMD
         constexpr int NCH = NPW / 4;  // noise chains per SIMD
         const int par = pw >> 2;
-        auto make_noise = [&](int r) {
+        // DL: one call per accumulator register (its (W_c, W_s) pair).  One-stream solvers: registers
+        // 2i and 2i+1 are adjacent rows and share a call (normal_two_rows); MF generates the NEXT
+        // step's normals (this step's arrive through the carry buffer).
+        constexpr int NUNIT = (MODE == MODE_DL) ? 16 : 8;  // noise work units per lane and step
+        auto make_noise = [&](int u) {
             if constexpr (NOISY && !(ABL & 64)) {
-                const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const NormalPair p = normal_pair(a.seed, a.row_offset + b, a.step, j);
-                lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
-                if constexpr (MODE == MODE_DL) lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
-                if constexpr (MODE == MODE_MF)  // the NEXT step's normal, for the next measured amplitude
-                    lds_noise[(1 * 16 + r) * NTHREADS + tid] =
-                        a.s.mf.has_next ? normal_pair(a.seed, a.row_offset + b, a.step + 1, j).n0 : 0.0f;
+                if constexpr (MODE == MODE_DL) {
+                    const int r = u;
+                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const NormalPair p = normal_pair(a.seed, a.row_offset + b, a.step, j);
+                    lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
+                    lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
+                } else {
+                    const int r = 2 * u;  // rows b (even) and b + 1
+                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int st = (MODE == MODE_MF) ? a.step + 1 : a.step;
+                    const NormalPair p = normal_two_rows(a.seed, a.row_offset + b, st, j);
+                    lds_noise[r * NTHREADS + tid] = p.n0;
+                    lds_noise[(r + 1) * NTHREADS + tid] = p.n1;
+                }
             }
         };
         // tile kt must have landed before the barrier that precedes its first fragment read:
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 const unsigned long long s0 = stamp();
                 dma_tile(t + NSTAGE);
                 const unsigned long long s1 = stamp();
-                if (gen_noise && t < 16 / NCH) make_noise(NCH * t + par);
+                if (gen_noise && t < NUNIT / NCH) make_noise(NCH * t + par);
                 const unsigned long long s2 = stamp();
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
                 const unsigned long long s3 = stamp();
@@ -361,11 +375,11 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         } else
         for (int t = 0; t < nkt; ++t) {
             dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
-            if (gen_noise && t < 16 / NCH) make_noise(NCH * t + par);
+            if (gen_noise && t < NUNIT / NCH) make_noise(NCH * t + par);
             publish();             // tile t + 2 visible
         }
         if (gen_noise)
-            for (int i = min(nkt, 16 / NCH); i < 16 / NCH; ++i) make_noise(NCH * i + par);
+            for (int i = min(nkt, NUNIT / NCH); i < NUNIT / NCH; ++i) make_noise(NCH * i + par);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue
         return;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // e2/e3: Adam moments.  Rows >= B and columns >= N are inside the padded arrays.
     constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
     constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
-    float e0[16], e1[16], e2[16], e3[16];
+    float e0[16], e1[16], e2[16], e3[16], ecar[16];
     // element address = [uniform: array + (row0 + 8 * (r >> 2)) * ld]  +  [lane: eoff[r & 3]]
     // (scalar base + constant 32-bit lane offset: no per-access address VALU)
     unsigned eoff[4];
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 e2[r] = (a.am + gofs(r))[eoff[r & 3]];
                 e3[r] = a.ad.use_v ? (a.av + gofs(r))[eoff[r & 3]] : 0.0f;
             }
+            if constexpr (MODE == MODE_MF) ecar[r] = a.replay ? 0.0f : (a.carry + gofs(r))[eoff[r & 3]];
         }
     }
     const float vj = col_ok ? a.V[j] : 0.0f;
@@ -570,9 +585,13 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             if constexpr (NOISY) {
                 if constexpr (FUSED) {
                     // written by this thread's producer twin, behind the final barrier
-                    n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
-                    if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
-                    if constexpr (MODE == MODE_MF) n0n = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                    if constexpr (MODE == MODE_MF) {
+                        n0 = ecar[r];  // this step's normal, generated one step ago
+                        n0n = a.s.mf.has_next ? lds_noise[r * NTHREADS + tid] : 0.0f;
+                    } else {
+                        n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
+                        if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                    }
                 } else if (ok) {
                     const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const size_t widx = (size_t)j * a.B + b;
@@ -613,7 +632,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 if (ok) {
                     (a.st0 + gb)[lo] = mun;
                     (a.st1 + gb)[lo] = sgn;
-                    if (k.has_next) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
+                    if (k.has_next) {
+                        (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
+                        if constexpr (FUSED) (a.carry + gb)[lo] = n0n;  // next step's normal
+                    }
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
@@ -633,12 +655,12 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             }
         };
         const bool whole_block = row0 + BM <= a.B;  // wave-uniform
-        if (whole_block && (gen_noise || !NOISY)) {
+        if (whole_block && (fused || !NOISY)) {
             if (col_ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) element(r, true, Yes{});
             }
-        } else if (gen_noise || !NOISY) {
+        } else if (fused || !NOISY) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 element(r, col_ok && (row0 + (r & 3) + 8 * (r >> 2) + 4 * half < a.B), Yes{});
@@ -696,28 +718,35 @@ __global__ void change_variables_kernel(const float* x, float* y, int B, int N, 
 
 // Measured amplitude of step `step` from the current mu (start of an MF chunk):
 //   mu_tilde_c = clamp(mu + k * W, -S, S)    (reference mf_solver.py:551-554)
-__global__ void mf_prepare_kernel(const float* mu, float* out, int B, int N, int ld,
+// Also seeds the carry buffer with this step's normals (fused mode).
+__global__ void mf_prepare_kernel(const float* mu, float* out, float* carry, int B, int N, int ld,
                                   float k, float S, uint64_t seed, int64_t row_offset, int step,
                                   const float* w0) {
     const size_t total = (size_t)B * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
-        const float n0 = w0 ? w0[(size_t)j * B + b] : normal_pair(seed, row_offset + b, step, j).n0;
+        const float n0 = w0 ? w0[(size_t)j * B + b] : normal_single(seed, row_offset + b, step, j);
         const size_t idx = (size_t)b * ld + j;
         out[idx] = clampf(mu[idx] + k * n0, -S, S);
+        if (!w0) carry[idx] = n0;
     }
 }
 
+// w1 != NULL: the DL pair (W_c, W_s) per element; w1 == NULL: the one-stream normal (rows paired).
 __global__ void philox_fill_kernel(uint64_t seed, int64_t row_offset, int step, int B, int N,
                                    float* w0, float* w1) {
     const size_t total = (size_t)B * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(i / B), b = (int)(i - (size_t)j * B);
-        const NormalPair p = normal_pair(seed, row_offset + b, step, j);
-        w0[i] = p.n0;
-        if (w1) w1[i] = p.n1;
+        if (w1) {
+            const NormalPair p = normal_pair(seed, row_offset + b, step, j);
+            w0[i] = p.n0;
+            w1[i] = p.n1;
+        } else {
+            w0[i] = normal_single(seed, row_offset + b, step, j);
+        }
     }
 }
 

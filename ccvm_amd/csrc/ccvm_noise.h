@@ -12,8 +12,10 @@
 //
 // so a trajectory's noise depends only on its GLOBAL row index, the column and the step --
 // never on the tiling, the grid or how the batch is sharded over GPUs.  The two output words
-// give one Box-Muller pair (n0, n1): the DL solver uses n0 for the in-phase and n1 for the
-// quadrature increment; single-state solvers use n0.
+// give one Box-Muller pair (n0, n1):
+//   DL (two Wiener streams per element):  normal_pair(row)  -> (W_c, W_s) of element (row, col);
+//   MF / Langevin / pumped Langevin (one stream): global rows 2p and 2p+1 SHARE the call of "row" p,
+//     normal_single(row) = (row even ? n0 : n1) of normal_pair(row >> 1)   -- half the calls.
 //
 // oracle/noise_ref.py restates exactly this mapping on the host (integer part bit-exact,
 // checked against the Random123 known-answer vectors; float part to ~1e-6).
@@ -67,6 +69,23 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, i
     p.n0 = r * __builtin_amdgcn_cosf(u2);
     p.n1 = r * __builtin_amdgcn_sinf(u2);
     return p;
+}
+
+// One-stream solvers: the normal of element (global row, col) at `step`.
+__device__ __forceinline__ float normal_single(uint64_t seed, int64_t grow, int step, int col) {
+    const NormalPair p = normal_pair(seed, grow >> 1, step, col);
+    return (grow & 1) ? p.n1 : p.n0;
+}
+
+// The normals of two ADJACENT local rows b (even) and b+1 whose global rows are off+b, off+b+1:
+// one call when `off` is even (the common case), two when a shard starts at an odd row.
+__device__ __forceinline__ NormalPair normal_two_rows(uint64_t seed, int64_t grow_even_local, int step, int col) {
+    const NormalPair p = normal_pair(seed, grow_even_local >> 1, step, col);
+    if (!(grow_even_local & 1)) return p;
+    NormalPair r;
+    r.n0 = p.n1;
+    r.n1 = normal_pair(seed, (grow_even_local >> 1) + 1, step, col).n0;
+    return r;
 }
 
 }  // namespace ccvm

@@ -167,6 +167,13 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 if (16 * (wave + 4 * ct) >= N) continue;
+                // registers (0,1) and (2,3) are adjacent rows: one call per pair (ccvm_noise.h)
+                float ns[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (!a.replay) {
+                    const NormalPair pa = normal_two_rows(a.seed, a.row_offset + brow[0], step, col[ct]);
+                    const NormalPair pb = normal_two_rows(a.seed, a.row_offset + brow[2], step, col[ct]);
+                    ns[0] = pa.n0; ns[1] = pa.n1; ns[2] = pb.n0; ns[3] = pb.n1;
+                }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const bool ok = col_ok[ct] && row_ok[reg];
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
                     if (a.replay) {
                         if (ok) n0 = a.w0[((size_t)it * N + col[ct]) * a.B + brow[reg]];
                     } else {
-                        n0 = normal_pair(a.seed, a.row_offset + brow[reg], step, col[ct]).n0;
+                        n0 = ns[reg];
                     }
                     const float mine = own[ct][reg];
                     const float qx = __builtin_fmaf(a.in_scale, acc[ct][reg], shift_j[ct]);

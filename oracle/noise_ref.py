@@ -62,16 +62,31 @@ def normal_pairs(seed, row_offset, step, b, n):
     return (r * np.cos(theta)).astype(np.float32), (r * np.sin(theta)).astype(np.float32)
 
 
-class FusedNoise:
-    """Noise source for oracle.ccvm_oracle loops reproducing the engine's fused generator."""
+def normal_singles(seed, row_offset, step, b, n):
+    """One-stream solvers (MF, Langevin, pumped Langevin): global rows 2p and 2p+1 share the call
+    of "row" p -- row even takes n0, row odd n1.  float32 array of shape (B, N)."""
+    first = int(row_offset) >> 1
+    last = (int(row_offset) + b - 1) >> 1
+    n0, n1 = normal_pairs(seed, first, step, last - first + 1, n)
+    rows = np.arange(b, dtype=np.int64) + int(row_offset)
+    pair = (rows >> 1) - first
+    return np.where((rows & 1)[:, None] == 0, n0[pair], n1[pair]).astype(np.float32)
 
-    def __init__(self, seed, row_offset=0):
-        self.seed, self.row_offset = int(seed), int(row_offset)
+
+class FusedNoise:
+    """Noise source for oracle.ccvm_oracle loops reproducing the engine's fused generator.
+    ``single=True`` for the one-stream solvers (rows share calls pairwise, see normal_singles)."""
+
+    def __init__(self, seed, row_offset=0, single=False):
+        self.seed, self.row_offset, self.single = int(seed), int(row_offset), bool(single)
         self._cache = (None, None)
 
     def draw(self, step, stream, n, b):
         import torch
 
+        if self.single:
+            assert stream == 0
+            return torch.from_numpy(normal_singles(self.seed, self.row_offset, step, b, n))
         if self._cache[0] != (step, n, b):
             self._cache = ((step, n, b), normal_pairs(self.seed, self.row_offset, step, b, n))
         return torch.from_numpy(self._cache[1][stream].copy())

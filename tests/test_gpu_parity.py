@@ -139,10 +139,10 @@ def test_philox_mode_matches_oracle(kind, n, b, t, kernel_path):
 
     q, v, f = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
-    seed, row_offset = 0x1234_5678_9ABC, 4096
+    seed, row_offset = 0x1234_5678_9ABC, 4096 + (n % 2)  # odd N -> a shard that starts on an odd row
     noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=row_offset)
     prob = engine.DeviceProblem(q, v)
-    ref_noise = FusedNoise(seed, row_offset)
+    ref_noise = FusedNoise(seed, row_offset, single=kind != "dl")
     if kind == "dl":
         traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)
         traj.advance(t)
@@ -185,6 +185,11 @@ def test_philox_normals_match_host_restatement_and_are_gaussian():
     r0, r1 = normal_pairs(seed, off, step, b, n)
     assert float((w0.cpu().T - torch.from_numpy(r0)).abs().max()) <= 2e-5
     assert float((w1.cpu().T - torch.from_numpy(r1)).abs().max()) <= 2e-5
+    from oracle.noise_ref import normal_singles
+
+    for o in (off, off + 1):  # one-stream solvers: rows share calls pairwise; odd and even shard starts
+        ws = engine.philox_normals(seed, o, step, b, n)
+        assert float((ws.cpu().T - torch.from_numpy(normal_singles(seed, o, step, b, n))).abs().max()) <= 2e-5
     big0, big1 = engine.philox_normals(seed, 0, 0, 2048, 1024, two=True)
     for w in (big0, big1):
         x = w.double().flatten()

@@ -28,7 +28,7 @@ def _oracle_local_solve(solver, instance, **kw):
     out = oracle.solve_pl(
         instance.q_matrix, instance.v_vector, solver.batch_size, p["iterations"], p["pump"], p["dt"],
         p["sigma"], p["feedback_scale"], p["S"], scaled_by=instance.scaled_by,
-        noise=FusedNoise(solver.noise_seed, solver.row_offset),
+        noise=FusedNoise(solver.noise_seed, solver.row_offset, single=True),
     )
     return Solution(
         problem_size=n, batch_size=solver.batch_size, instance_name=instance.name,
