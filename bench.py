@@ -121,11 +121,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
 
+    # CCVM_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the collectives
+    # run over gloo on host copies; the real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = torch.device("cpu") if share else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, n, b = WORKLOADS[args.workload]
     total = args.warmup + args.steps
@@ -149,7 +159,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg per step launch on the launch stream
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -169,6 +179,7 @@ def main():
     obj = engine.energy(x, q, v, float(f))
     finite = bool(torch.isfinite(obj).all().item())
     if world > 1:
+        obj = obj.to(comm_dev)
         gathered = [torch.empty_like(obj) for _ in range(world)]
         dist.all_gather(gathered, obj)
         obj = torch.cat(gathered)
@@ -194,7 +205,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
-                            f"batch {b} per GPU x {world} GPU, fp32 state, fused Philox noise, "
+                            f"batch {b} per GPU x {world} GPU, fp32 state, fused Threefry noise, "
                             f"schedule of a {total}-step run",
                 "global_batch": b * world,
                 "parallelism": f"batch-sharded x{world}, no data-path collective",

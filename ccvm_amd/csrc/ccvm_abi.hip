@@ -92,6 +92,23 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
     a.qsum = V;  // any valid array while in_shift == 0
+    // XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb, (nrb/xr) * (ncb/xc) = 8; minimise the
+    // L2 footprint  xr * (bytes of an A row block) + xc * (bytes of a Q column panel)  ~  xr + 4 xc
+    // for one-state solvers (32 vs 128 floats wide), 2 xr + 4 xc for DL.  CCVM_AMD_XCD=0 disables.
+    a.xr = a.xc = 0;
+    const int total = a.nrb * a.ncb;
+    const char* e = std::getenv("CCVM_AMD_XCD");
+    if (total % 8 == 0 && !(e && e[0] == '0')) {
+        const int per = total / 8;
+        long best = -1;
+        for (int xc = 1; xc <= a.ncb; ++xc) {
+            if (per % xc || a.ncb % xc) continue;
+            const int xr = per / xc;
+            if (xr > a.nrb || a.nrb % xr || (a.nrb / xr) * (a.ncb / xc) != 8) continue;
+            const long cost = 2L * xr + 4L * xc;
+            if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
+        }
+    }
 }
 
 // Column sums of Q into `area` ((QSUM_SLICES + 1) * ld floats); returns the qsum pointer.

@@ -129,6 +129,7 @@ struct StepArgs {
     int replay;
     int B, N, ld;
     int nrb, ncb;       // row blocks, column blocks
+    int xr, xc;         // tiles of one XCD form an xr x xc rectangle (0: linear fallback)
     float in_scale, in_shift;  // GEMM input = x * in_scale + in_shift
     union {
         DlScalars dl;
@@ -246,8 +247,20 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     const int l31 = lane & 31;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHREADS;
 
-    const int tile = xcd_remap(blockIdx.x, a.nrb * a.ncb);
-    const int rb = tile / a.ncb, cb = tile - rb * a.ncb;
+    // Blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).  When the
+    // grid divides evenly, each XCD gets an xr x xc rectangle of tiles chosen on the host to
+    // minimise the bytes its private L2 must hold (xr A row-blocks + xc Q column panels).
+    int rb, cb;
+    if (a.xr > 0) {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int regions_c = a.ncb / a.xc;
+        rb = (x / regions_c) * a.xr + i / a.xc;
+        cb = (x % regions_c) * a.xc + i % a.xc;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, a.nrb * a.ncb);
+        rb = tile / a.ncb;
+        cb = tile - rb * a.ncb;
+    }
     const int row0 = rb * BM, col0 = cb * BN;
     const int ld = a.ld;
     const int j = col0 + 32 * wave + l31;  // this lane's output column

@@ -126,6 +126,8 @@ def _gate(n):
 @pytest.mark.parametrize("kind,n,b,t", [
     ("dl", 100, 256, 40), ("mf", 100, 256, 40), ("langevin", 100, 256, 40), ("pl", 100, 256, 40),
     ("dl", 20, 37, 25), ("dl", 64, 9, 25), ("dl", 90, 100, 20), ("dl", 128, 70, 20), ("pl", 33, 50, 25),
+    ("dl", 1, 5, 12), ("langevin", 1, 1, 12), ("mf", 7, 3, 12), ("pl", 16, 1, 12), ("dl", 129, 33, 10),
+    ("pl", 2000, 96, 3),  # largest BASELINE problem size
     ("dl", 333, 130, 12), ("mf", 500, 200, 8), ("pl", 257, 65, 12),
     ("dl", 1000, 1000, 6),  # BASELINE headline shape
 ])
