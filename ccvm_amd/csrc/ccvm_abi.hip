@@ -80,6 +80,8 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
     s.add_assign = ad->add_assign;
 }
 
+void set_grid(StepArgs& a, int ks);
+
 void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld) {
     std::memset(&a, 0, sizeof(a));
     a.Q = Q;
@@ -87,14 +89,18 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.B = B;
     a.N = N;
     a.ld = ld;
-    a.nrb = (B + BM - 1) / BM;
-    a.ncb = (N + BN - 1) / BN;
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
     a.qsum = V;  // any valid array while in_shift == 0
-    // XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb, (nrb/xr) * (ncb/xc) = 8; minimise the
-    // L2 footprint  xr * (bytes of an A row block) + xc * (bytes of a Q column panel)  ~  xr + 4 xc
-    // for one-state solvers (32 vs 128 floats wide), 2 xr + 4 xc for DL.  CCVM_AMD_XCD=0 disables.
+    set_grid(a, 1);
+}
+
+// Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
+// (nrb/xr) * (ncb/xc) = 8, minimising the L2 footprint  xr * (bytes of an A row block) + xc * (bytes
+// of a Q column panel).  CCVM_AMD_XCD=0 disables the rectangles (linear fallback).
+void set_grid(StepArgs& a, int ks) {
+    a.nrb = (a.B + BM - 1) / BM;
+    a.ncb = (a.N + BN / ks - 1) / (BN / ks);
     a.xr = a.xc = 0;
     const int total = a.nrb * a.ncb;
     const char* e = std::getenv("CCVM_AMD_XCD");
@@ -105,7 +111,7 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
             if (per % xc || a.ncb % xc) continue;
             const int xr = per / xc;
             if (xr > a.nrb || a.nrb % xr || (a.nrb / xr) * (a.ncb / xc) != 8) continue;
-            const long cost = 2L * xr + 4L * xc;
+            const long cost = 2L * xr + (4L / ks) * xc;
             if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
         }
     }
@@ -137,10 +143,24 @@ void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N
     }
 }
 
+// Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
+// a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).  CCVM_AMD_KS=1|2 forces one.
+int choose_ks(int B, int N) {
+    const char* e = std::getenv("CCVM_AMD_KS");
+    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+    const int tiles = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return tiles <= 128 ? 2 : 1;
+}
+
 template <int MODE, bool ADAM>
-int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
+int launch_step(StepArgs a, hipStream_t st, const char* name) {
+    const int ks = choose_ks(a.B, a.N);
+    set_grid(a, ks);
     const int grid = a.nrb * a.ncb;
-    hipLaunchKernelGGL((step_kernel<MODE, ADAM>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+    if (ks == 2)
+        hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 2>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 1>), dim3(grid), dim3(WG_THREADS), 0, st, a);
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
 }
@@ -510,7 +530,7 @@ int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, in
     a.o0 = static_cast<float*>(ws);
     if ((rc = launch_step<MODE_ENERGY, false>(a, st, fn))) return rc;
     hipLaunchKernelGGL(energy_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, st,
-                       static_cast<const float*>(ws), a.ncb * 4, a.nrb * BM, B, (float)scaled_by, obj);
+                       static_cast<const float*>(ws), (N + 31) / 32, a.nrb * BM, B, (float)scaled_by, obj);
     CCVM_CHECK_LAUNCH(fn);
     return CCVM_OK;
 }

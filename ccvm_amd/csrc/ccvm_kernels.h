@@ -227,12 +227,26 @@ typedef const __attribute__((address_space(1))) void global_cvoid;
 
 // ABL: ablation bits for tools/ablate.hip (0 in the product): 1 no DMA loads, 4 no fragment
 // reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier (timing only), 64 no noise,
-// 128 s_memtime stamps of the loop phases into a.dbg (diagnostic build: shares, not run time).
-template <int MODE, bool ADAM, int ABL = 0>
+// 128 s_memtime stamps of the consumer loop into a.dbg (diagnostic build: shares, not run time).
+//
+// KS (1 or 2): in-workgroup split of K.  KS = 1: tile 32 x 128, consumer wave w = column strip w.
+// KS = 2: tile 32 x 64 for grids that would leave CUs idle (e.g. N = 500, B = 1000: 128 tiles of
+// 32 x 128); consumer wave w = column strip (w & 1), K half (w >> 1): within every K tile it runs
+// the k-steps [8 kh, 8 kh + 8) of each lane-half.  After the loop the two halves swap 8 accumulator
+// registers through LDS, so each wave ends up with the full sum of 8 of the 16 rows and the
+// epilogue work stays balanced.
+template <int MODE, bool ADAM, int ABL = 0, int KS = 1>
 __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
+    static_assert(KS == 1 || KS == 2, "KS");
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
     constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
-    constexpr int STAGE = NA * A_TILE + Q_TILE;
+    constexpr int BNT = BN / KS;             // columns per workgroup
+    constexpr int QT = KT * BNT;             // floats of a Q tile
+    constexpr int STAGE = NA * A_TILE + QT;
+    constexpr int NM = 16 / KS;              // k-steps per consumer wave, lane-half and K tile
+    constexpr int NQA = 4 / KS;              // b128 A-fragment reads per accumulator and tile
+    constexpr int NG = 8 / KS;               // fragment read groups per tile
+    constexpr int NR = 16 / KS;              // accumulator registers a wave finishes (epilogue rows)
     constexpr int NOISE_LDS = NOISY ? 2 * 16 * NTHREADS : 0;
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE + NOISE_LDS];
@@ -246,6 +260,9 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHREADS;
+    const int cs = (KS == 1) ? wave : (wave & 1);   // column strip of 32
+    const int kh = (KS == 1) ? 0 : (wave >> 1);     // K half
+    const int R0 = kh * NR;                         // first accumulator register this wave finishes
 
     // Blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).  When the
     // grid divides evenly, each XCD gets an xr x xc rectangle of tiles chosen on the host to
@@ -261,27 +278,31 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         rb = tile / a.ncb;
         cb = tile - rb * a.ncb;
     }
-    const int row0 = rb * BM, col0 = cb * BN;
+    const int row0 = rb * BM, col0 = cb * BNT;
     const int ld = a.ld;
-    const int j = col0 + 32 * wave + l31;  // this lane's output column
+    const int j = col0 + 32 * cs + l31;  // this lane's output column
     const bool col_ok = j < a.N;
     const int nkt = (a.N + KT - 1) / KT;
     const int last = nkt - 1;
     const bool fused = NOISY && !a.replay;  // noise source: fused generator vs replayed normals
     // what the producers generate: MF makes the NEXT step's normals only (none after the last step)
     const bool gen_noise = fused && (MODE != MODE_MF || a.s.mf.has_next);
+    // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
+    auto erow = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
 
     if (producer) {
         // =========================== producer waves ====================================
-        // DMA pieces of one tile: 4 per A tile (8 rows x 128 B) then 16 of Q (2 rows x 512 B),
-        // dealt round-robin to the NPW producer waves.  LDS destination = piece base + lane * 16
-        // (hardware); the A tile's swizzle (chunk c of row r stored at position c ^ ((r >> 1) & 7))
-        // is applied to the per-lane SOURCE address.
-        constexpr int NPIECE = 4 * NA + 16;
-        constexpr int PMAX = (NPIECE + NPW - 1) / NPW;
         // Producers issue few instructions but each must get out promptly; at equal priority the
         // SIMD arbiter favours the older (consumer) wave, which always has an MFMA pending.
         __builtin_amdgcn_s_setprio(3);
+        // DMA pieces (1 KiB = one wave instruction) of a tile: 4 per A tile (8 rows x 128 B) then
+        // 16 / KS of Q (1024 / (4 BNT) rows x 4 BNT B), dealt round-robin to the NPW producer waves.
+        // LDS destination = piece base + lane * 16 (hardware); the A tile's swizzle (chunk c of row
+        // r stored at position c ^ ((r >> 1) & 7)) is applied to the per-lane SOURCE address.
+        constexpr int NPIECE = 4 * NA + 16 / KS;
+        constexpr int PMAX = (NPIECE + NPW - 1) / NPW;
+        constexpr int LPR = BNT / 4;           // lanes per Q row
+        constexpr int RPP = 64 / LPR;          // Q rows per piece
         const int pw = __builtin_amdgcn_readfirstlane((threadIdx.x - NTHREADS) >> 6);  // 0 .. NPW-1
         const int plane = threadIdx.x & 63;
         // Addressing: wave-uniform 64-bit base (SGPRs, advanced per tile by SALU) + a per-lane
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             } else {
                 const int q = p - 4 * NA;
                 sbase_g[i] = reinterpret_cast<const char*>(a.Q + col0);
-                voff[i] = (unsigned)(((2 * q + (plane >> 5)) * ld + 4 * (plane & 31)) * 4);
+                voff[i] = (unsigned)(((RPP * q + plane / LPR) * ld + 4 * (plane % LPR)) * 4);
                 dst[i] = NA * A_TILE + q * 256;
             }
         }
@@ -327,36 +348,30 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                     : "memory");
             }
         };
-        // noise: producer thread (pw, lane) serves consumer thread tid = 64 * (pw & 3) + lane and
-        // the accumulator registers r = 2 * i + (pw >> 2): two independent chains per SIMD
-        constexpr int NCH = NPW / 4;  // noise chains per SIMD
-        const int par = pw >> 2;
-        // DL: one call per accumulator register (its (W_c, W_s) pair).  One-stream solvers: registers
-        // 2i and 2i+1 are adjacent rows and share a call (normal_two_rows); MF generates the NEXT
-        // step's normals (this step's arrive through the carry buffer).
-        constexpr int NUNIT = (MODE == MODE_DL) ? 16 : 8;  // noise work units per lane and step
+        // Noise for the registers this thread's consumer twin finishes (R0 .. R0 + NR - 1).
+        // DL: one call per register (its (W_c, W_s) pair).  One-stream solvers: registers 2i and 2i+1
+        // are adjacent rows and share a call (normal_two_rows); MF generates the NEXT step's normals
+        // (this step's arrive through the carry buffer).
+        constexpr int NUNIT = ((MODE == MODE_DL) ? 16 : 8) / KS;  // noise work units per lane and step
         auto make_noise = [&](int u) {
             if constexpr (NOISY && !(ABL & 64)) {
                 if constexpr (MODE == MODE_DL) {
-                    const int r = u;
-                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const NormalPair p = normal_pair(a.seed, a.row_offset + b, a.step, j);
+                    const int r = R0 + u;
+                    const NormalPair p = normal_pair(a.seed, a.row_offset + row0 + erow(r), a.step, j);
                     lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
                     lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
                 } else {
-                    const int r = 2 * u;  // rows b (even) and b + 1
-                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int r = R0 + 2 * u;  // rows b (even) and b + 1
                     const int st = (MODE == MODE_MF) ? a.step + 1 : a.step;
-                    const NormalPair p = normal_two_rows(a.seed, a.row_offset + b, st, j);
+                    const NormalPair p = normal_two_rows(a.seed, a.row_offset + row0 + erow(r), st, j);
                     lds_noise[r * NTHREADS + tid] = p.n0;
                     lds_noise[(r + 1) * NTHREADS + tid] = p.n1;
                 }
             }
         };
         // tile kt must have landed before the barrier that precedes its first fragment read:
-        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PMAX).  NO lgkmcnt wait here:
-        // LDS-DMA also counts on lgkmcnt (measured: an lgkmcnt(0) drains every DMA in flight, ~1 us
-        // per tile), and the noise ds_writes are only consumed behind the final barrier.
+        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PMAX).  No lgkmcnt wait: the
+        // noise ds_writes are only consumed behind the final barrier.
         auto publish = [&]() {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
             if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
@@ -367,34 +382,15 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         // the consumers read tile 0's fragments right after that barrier: slot 0 may only be
         // refilled (with tile NSTAGE) once they are done
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-        if constexpr (ABL & 128) {  // diagnostic: where a producer tile goes
-            unsigned long long tdma = 0, tnoise = 0, twait = 0, tbar = 0;
-            for (int t = 0; t < nkt; ++t) {
-                const unsigned long long s0 = stamp();
-                dma_tile(t + NSTAGE);
-                const unsigned long long s1 = stamp();
-                if (gen_noise && t < NUNIT / NCH) make_noise(NCH * t + par);
-                const unsigned long long s2 = stamp();
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
-                const unsigned long long s3 = stamp();
-                __builtin_amdgcn_s_barrier();
-                const unsigned long long s4 = stamp();
-                tdma += s1 - s0; tnoise += s2 - s1; twait += s3 - s2; tbar += s4 - s3;
-            }
-            if (threadIdx.x == NTHREADS) {
-                unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
-                d[0] = tdma; d[1] = tnoise; d[2] = twait; d[3] = tbar;
-            }
-        } else
         for (int t = 0; t < nkt; ++t) {
             dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
-            if (gen_noise && t < NUNIT / NCH) make_noise(NCH * t + par);
+            if (gen_noise && t < NUNIT) make_noise(t);
             publish();             // tile t + 2 visible
         }
         if (gen_noise)
-            for (int i = min(nkt, NUNIT / NCH); i < NUNIT / NCH; ++i) make_noise(NCH * i + par);
+            for (int u = min(nkt, NUNIT); u < NUNIT; ++u) make_noise(u);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue
+        __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue; ring idle
         return;
     }
 
@@ -402,13 +398,12 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     // ---- epilogue operands, fetched now so their latency hides under the whole GEMM -----
-    // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
-    //   erow(r) = (r & 3) + 8 * (r >> 2) + 4 * half
-    // e0/e1: old state at that element (DL: c, s; MF: mu, sigma; others: x);
-    // e2/e3: Adam moments.  Rows >= B and columns >= N are inside the padded arrays.
+    // e0/e1: old state at the element (DL: c, s; MF: mu, sigma; others: x); e2/e3: Adam moments;
+    // ecar: MF's normals of this step.  Index i is accumulator register R0 + i.  Rows >= B and
+    // columns >= N are inside the padded arrays.
     constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
     constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
-    float e0[16], e1[16], e2[16], e3[16], ecar[16];
+    float e0[NR], e1[NR], e2[NR], e3[NR], ecar[NR];
     // element address = [uniform: array + (row0 + 8 * (r >> 2)) * ld]  +  [lane: eoff[r & 3]]
     // (scalar base + constant 32-bit lane offset: no per-access address VALU)
     unsigned eoff[4];
@@ -419,14 +414,11 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         const float* p0 = (MODE == MODE_MF) ? a.st0 : a.a0;
         const float* p1 = (MODE == MODE_MF) ? a.st1 : a.a1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if constexpr (HAS_E0) e0[r] = (p0 + gofs(r))[eoff[r & 3]];
-            if constexpr (HAS_E1) e1[r] = (p1 + gofs(r))[eoff[r & 3]];
-            if constexpr (ADAM) {
-                e2[r] = (a.am + gofs(r))[eoff[r & 3]];
-                e3[r] = a.ad.use_v ? (a.av + gofs(r))[eoff[r & 3]] : 0.0f;
-            }
-            if constexpr (MODE == MODE_MF) ecar[r] = a.replay ? 0.0f : (a.carry + gofs(r))[eoff[r & 3]];
+        for (int i = 0; i < NR; ++i) {
+            const int r = R0 + i;  // R0 is wave-uniform: addresses stay scalar + lane offset
+            if constexpr (HAS_E0) e0[i] = (p0 + gofs(r))[eoff[i & 3]];
+            if constexpr (HAS_E1) e1[i] = (p1 + gofs(r))[eoff[i & 3]];
+            if constexpr (MODE == MODE_MF) ecar[i] = a.replay ? 0.0f : (a.carry + gofs(r))[eoff[i & 3]];
         }
     }
     const float vj = col_ok ? a.V[j] : 0.0f;
@@ -435,16 +427,27 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // fragment read offsets inside a stage (A: swizzled chunk position)
     const int sw = (l31 >> 1) & 7;
     const int fa = l31 * KT;
-    const int fb = NA * A_TILE + (16 * half) * BN + 32 * wave + l31;
-    // one eighth of a tile's fragments (slot sl of 8): keeps the LDS queue shallow
-    auto read_frags_part = [&](Frags<NA>& f, int stage, int sl) {
-        const float* st = lds + stage * STAGE;
-        if (sl < 4 * NA) {
-            const int n = sl >> 2, q = sl & 3;
-            f.a[n][q] = *reinterpret_cast<const f32x4*>(st + n * A_TILE + fa + 4 * ((4 * half + q) ^ sw));
+    const int fb = NA * A_TILE + (16 * half + kh * NM) * BNT + 32 * cs + l31;
+    struct FragsT {
+        f32x4 a[NA][NQA];  // k-steps kh*NM .. kh*NM + NM - 1 of this lane-half, 4 per b128
+        float b[NM];
+    };
+    // per-stage fragment base pointers: inside the loop every LDS address is base + immediate
+    const float* stA[NSTAGE];
+    const float* stB[NSTAGE];
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+        stA[st] = lds + st * STAGE + fa;
+        stB[st] = lds + st * STAGE + fb;
+    }
+    // group g of a tile's fragments (NG groups): keeps the LDS queue shallow
+    auto read_part = [&](FragsT& f, int st, int g) {  // st is a compile-time constant at every call
+        if (g < NQA * NA) {
+            const int n = g / NQA, ql = g % NQA;
+            f.a[n][ql] = *reinterpret_cast<const f32x4*>(stA[st] + n * A_TILE + 4 * ((4 * half + kh * NQA + ql) ^ sw));
         }
-        f.b[2 * sl] = st[fb + (2 * sl) * BN];
-        f.b[2 * sl + 1] = st[fb + (2 * sl + 1) * BN];
+        f.b[2 * g] = stB[st][(2 * g) * BNT];
+        f.b[2 * g + 1] = stB[st][(2 * g + 1) * BNT];
     };
 
     f32x16 acc[NA];
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     for (int n = 0; n < NA; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    auto mfma_range = [&](const Frags<NA>& f, int m0, int m1) {
+    auto mfma_range = [&](const FragsT& f, int m0, int m1) {
 #pragma unroll
         for (int m = m0; m < m1; ++m)
 #pragma unroll
@@ -465,42 +468,27 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             }
     };
 
-    Frags<NA> f0, f1;
+    FragsT f0, f1;
     __syncthreads();  // tiles 0, 1 are in the ring (fence + barrier: LDS reads stay below it)
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) read_frags_part(f0, 0, sl);
+    for (int g = 0; g < NG; ++g) read_part(f0, 0, g);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop starts with settled LDS counters
     if constexpr (!(ABL & 32)) __syncthreads();  // slot 0 may now be refilled
 
-    // iteration t: the 16*NA MFMAs of tile t (fragments in registers) with the fragment reads of
-    // tile t+1 in their issue gaps -- slot by slot, order pinned, and none in the last slot so no
-    // read latency is exposed at the barrier.
+    // iteration t: the NM * NA MFMAs of tile t (fragments in registers) with the fragment reads of
+    // tile t+1 in their issue gaps -- slot by slot (2 k-steps each), order pinned, and none in the
+    // last two slots so no read latency is exposed at the barrier.
     unsigned long long c_work = 0, c_bar = 0, c_last = 0;
-    // per-stage fragment base pointers: inside the loop every LDS address is base + immediate
-    const float* stA[NSTAGE];
-    const float* stB[NSTAGE];
-#pragma unroll
-    for (int st = 0; st < NSTAGE; ++st) {
-        stA[st] = lds + st * STAGE + fa;
-        stB[st] = lds + st * STAGE + fb;
-    }
-    auto read_part = [&](Frags<NA>& f, int st, int sl) {  // st is a compile-time constant at every call
-        if (sl < 4 * NA) {
-            const int n = sl >> 2, q = sl & 3;
-            f.a[n][q] = *reinterpret_cast<const f32x4*>(stA[st] + n * A_TILE + 4 * ((4 * half + q) ^ sw));
-        }
-        f.b[2 * sl] = stB[st][(2 * sl) * BN];
-        f.b[2 * sl + 1] = stB[st][(2 * sl + 1) * BN];
-    };
-    auto c_iteration = [&](const Frags<NA>& cur, Frags<NA>& nxt, auto stage_tag) {
+    auto c_iteration = [&](const FragsT& cur, FragsT& nxt, auto stage_tag) {
         constexpr int rstage = decltype(stage_tag)::value;
+        constexpr int NSLOT = NM / 2;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
+        for (int sl = 0; sl < NSLOT; ++sl) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 4)) {
-                // 8 read groups over slots 0..5 (slots 0,1 carry two), none right before the barrier
+                // NG read groups over slots 0 .. NSLOT-3: slots 0,1 carry two
                 if (sl < 2) { read_part(nxt, rstage, 2 * sl); read_part(nxt, rstage, 2 * sl + 1); }
-                else if (sl < 6) read_part(nxt, rstage, sl + 2);
+                else if (sl + 2 < NG) read_part(nxt, rstage, sl + 2);
             }
             mfma_range(cur, 2 * sl, 2 * sl + 2);
 #pragma unroll
@@ -538,7 +526,17 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         if (t < nkt) { c_iteration(f1, f0, S2{}); ++t; }
         if (t < nkt) { c_iteration(f0, f1, S3{}); ++t; }
     }
-    __syncthreads();  // producers' noise is complete
+    if constexpr (ADAM) {
+        // Adam moments: fetched here, not at kernel start (holding 2 x NR more registers through the
+        // main loop spills at two waves per SIMD); the latency hides under the final barrier
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = R0 + i;
+            e2[i] = (a.am + gofs(r))[eoff[i & 3]];
+            e3[i] = a.ad.use_v ? (a.av + gofs(r))[eoff[i & 3]] : 0.0f;
+        }
+    }
+    __syncthreads();  // producers' noise is complete, no DMA in flight: the ring is free
     if constexpr (ABL & 128) {
         if (threadIdx.x == 0) {
             unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
@@ -546,18 +544,54 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         }
     }
 
+    // ---- KS = 2: swap halves so this wave holds the full K sum of registers R0 .. R0 + 7 ----
+    // fin[n][i] = total of accumulator register R0 + i
+    float fin[NA][NR];
+    if constexpr (KS == 1) {
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) fin[n][i] = acc[n][i];
+    } else {
+        float* xb = lds;  // [kh][cs][n][8][64]
+        auto slot = [&](int k_, int n, int i) { return (((k_ * 2 + cs) * NA + n) * 8 + i) * 64 + lane; };
+        if (kh == 0) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xb[slot(0, n, i)] = acc[n][8 + i];  // give rows 8..15
+        } else {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xb[slot(1, n, i)] = acc[n][i];      // give rows 0..7
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fin[n][i] = acc[n][i] + xb[slot(1, n, i)];       // k half 0 + k half 1
+        } else {
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fin[n][i] = xb[slot(0, n, i)] + acc[n][8 + i];   // k half 0 + k half 1
+        }
+    }
+
     // the affine input map, folded:  (x*scale + shift) @ Q = scale * (x @ Q) + shift * colsum(Q)
 #pragma unroll
     for (int n = 0; n < NA; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = __builtin_fmaf(a.in_scale, acc[n][r], shift_j);
+        for (int i = 0; i < NR; ++i) fin[n][i] = __builtin_fmaf(a.in_scale, fin[n][i], shift_j);
 
     if constexpr (ABL & 16) {  // ablation: keep the accumulators live, skip the real epilogue
         float sum = vj;
 #pragma unroll
         for (int n = 0; n < NA; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[n][r] + e0[r] + (HAS_E1 ? e1[r] : 0.0f);
+            for (int i = 0; i < NR; ++i) sum += fin[n][i] + e0[i] + (HAS_E1 ? e1[i] : 0.0f);
         if (sum == 123.456f) a.o0[0] = sum;
         return;
     }
@@ -565,49 +599,46 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // ---- epilogue in the accumulator layout ---------------------------------------
     if constexpr (MODE == MODE_ENERGY) {
         // partial over this wave's 32 columns of (1/2 (x@Q)[b,j] + V[j]) * x[b,j]
-        float part[16];
+        float part[NR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = col_ok ? (0.5f * acc[0][r] + vj) * e0[r] : 0.0f;
+        for (int i = 0; i < NR; ++i) {
+            float p = col_ok ? (0.5f * fin[0][i] + vj) * e0[i] : 0.0f;
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-            part[r] = p;
+            part[i] = p;
         }
         if (l31 == 0) {
-            // o0: [ncb*4 column strips][rows_pad] partial sums
-            const int strip = cb * 4 + wave;
+            // o0: [column strips of 32][rows_pad] partial sums
+            const int strip = cb * (BNT / 32) + cs;
             const int rows_pad = a.nrb * BM;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                a.o0[(size_t)strip * rows_pad + b] = part[r];
-            }
+            for (int i = 0; i < NR; ++i) a.o0[(size_t)strip * rows_pad + row0 + erow(R0 + i)] = part[i];
         }
         return;
     } else {
         // every operand is already in registers (prefetch above), so each result is stored
         // as soon as it is computed: no load ever waits behind a store.
-        // `element(r, ok, from_lds)` handles accumulator register r; the common case (whole row
+        // `element(i, ok, fused)` handles accumulator register R0 + i; the common case (whole row
         // block inside the batch, fused noise) runs it under ONE column mask with no per-element
         // branches, edge blocks and replay mode take the general path.
-        auto element = [&](int r, bool ok, auto fused_tag) {
+        auto element = [&](int i, bool ok, auto fused_tag) {
             constexpr bool FUSED = decltype(fused_tag)::value;
+            const int r = R0 + i;
             const size_t gb = gofs(r);       // uniform
-            const unsigned lo = eoff[r & 3];  // per lane
+            const unsigned lo = eoff[i & 3];  // per lane
             float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
             if constexpr (NOISY) {
                 if constexpr (FUSED) {
                     // written by this thread's producer twin, behind the final barrier
                     if constexpr (MODE == MODE_MF) {
-                        n0 = ecar[r];  // this step's normal, generated one step ago
+                        n0 = ecar[i];  // this step's normal, generated one step ago
                         n0n = a.s.mf.has_next ? lds_noise[r * NTHREADS + tid] : 0.0f;
                     } else {
                         n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
                         if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
                     }
                 } else if (ok) {
-                    const int b = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const size_t widx = (size_t)j * a.B + b;
+                    const size_t widx = (size_t)j * a.B + row0 + erow(r);
                     n0 = a.w0[widx];
                     if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
                     if constexpr (MODE == MODE_MF)
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             auto adam = [&](float g) {
                 if constexpr (ADAM) {
                     float m, v;
-                    const float out = adam_precondition(a.ad, g, e2[r], e3[r], m, v);
+                    const float out = adam_precondition(a.ad, g, e2[i], e3[i], m, v);
                     if (ok) {
                         (a.am + gb)[lo] = m;
                         if (a.ad.use_v) (a.av + gb)[lo] = v;
@@ -632,16 +663,16 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
 
             if constexpr (MODE == MODE_DL) {
                 float cn, sn;
-                dl_update(a.s.dl, e0[r], e1[r], acc[0][r], acc[1][r], vj, n0, n1, cn, sn);
+                dl_update(a.s.dl, e0[i], e1[i], fin[0][i], fin[NA - 1][i], vj, n0, n1, cn, sn);
                 if (ok) {
                     (a.o0 + gb)[lo] = cn;
                     (a.o1 + gb)[lo] = sn;
                 }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
-                const float fb = adam(__builtin_fmaf(k.f_q, acc[0][r], k.f_v * vj));
+                const float fb = adam(__builtin_fmaf(k.f_q, fin[0][i], k.f_v * vj));
                 float mun, sgn;
-                mf_update(k, e0[r], e1[r], fb, n0, mun, sgn);
+                mf_update(k, e0[i], e1[i], fb, n0, mun, sgn);
                 if (ok) {
                     (a.st0 + gb)[lo] = mun;
                     (a.st1 + gb)[lo] = sgn;
@@ -652,35 +683,33 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
-                const float g = adam(__builtin_fmaf(k.g_q, acc[0][r], k.g_v * vj));
-                const float x = lv_update(k, e0[r], g, n0);
+                const float g = adam(__builtin_fmaf(k.g_q, fin[0][i], k.g_v * vj));
+                const float x = lv_update(k, e0[i], g, n0);
                 if (ok) (a.o0 + gb)[lo] = x;
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, acc[0][r] + vj, e0[r]), k.lo, k.hi);
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, fin[0][i] + vj, e0[i]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_ADAMPP) {
                 const PpScalars& k = a.s.pp;
-                const float g = acc[0][r] + vj;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[r]), k.lo, k.hi);
+                const float g = fin[0][i] + vj;
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[i]), k.lo, k.hi);
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, acc[0][r], k.eps * vj);
+                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, fin[0][i], k.eps * vj);
             }
         };
         const bool whole_block = row0 + BM <= a.B;  // wave-uniform
         if (whole_block && (fused || !NOISY)) {
             if (col_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) element(r, true, Yes{});
+                for (int i = 0; i < NR; ++i) element(i, true, Yes{});
             }
         } else if (fused || !NOISY) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                element(r, col_ok && (row0 + (r & 3) + 8 * (r >> 2) + 4 * half < a.B), Yes{});
+            for (int i = 0; i < NR; ++i) element(i, col_ok && (row0 + erow(R0 + i) < a.B), Yes{});
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                element(r, col_ok && (row0 + (r & 3) + 8 * (r >> 2) + 4 * half < a.B), No{});
+            for (int i = 0; i < NR; ++i) element(i, col_ok && (row0 + erow(R0 + i) < a.B), No{});
         }
     }
 }
