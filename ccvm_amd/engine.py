@@ -41,6 +41,23 @@ def gpu_device():
     return torch.device("cuda", index)
 
 
+_warm = set()
+
+
+def warmup():
+    """One trivial launch per process and device: loads the library's code object and creates the
+    HIP context, so that one-time cost (~0.2 s) never lands inside a solver's timed region."""
+    dev = gpu_device()
+    if dev.index in _warm:
+        return
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        x = torch.zeros((64, 128), dtype=torch.float32, device=dev)
+        _lib.check(lib.ccvm_clamp(_ptr(x), 1, 1, 128, 0.0, 1.0, _stream_ptr()), "ccvm_clamp (warm-up)")
+        torch.cuda.synchronize(dev)
+    _warm.add(dev.index)
+
+
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -102,8 +119,10 @@ class NoiseSpec:
     generator: Optional[torch.Generator] = None
 
     def __post_init__(self):
+        if self.mode == "fused":  # clearer name for the in-kernel generator ("philox" is historical)
+            self.mode = "philox"
         if self.mode not in ("philox", "replay"):
-            raise ValueError(f"unknown noise mode {self.mode!r}; expected 'philox' or 'replay'")
+            raise ValueError(f"unknown noise mode {self.mode!r}; expected 'fused' (alias 'philox') or 'replay'")
 
 
 def draw_seed():
@@ -117,7 +136,7 @@ def default_noise(mode=None, row_offset=0, seed=None):
     mode = mode or os.environ.get("CCVM_AMD_NOISE", "philox")
     if mode == "replay":
         return NoiseSpec(mode="replay", row_offset=row_offset)
-    return NoiseSpec(mode="philox", seed=draw_seed() if seed is None else int(seed), row_offset=row_offset)
+    return NoiseSpec(mode=mode, seed=draw_seed() if seed is None else int(seed), row_offset=row_offset)
 
 
 class _NoiseFeeder:

@@ -69,7 +69,7 @@ def solve_sharded(solver, instance, group=None, gather_variables=False, local_so
     local = copy.copy(solver)  # shallow: shares parameter_key, rebinds the per-rank fields
     local.batch_size = hi - lo
     local.row_offset = solver.row_offset + lo
-    if solver.noise_seed is None and (solver.noise_mode or "philox") == "philox":
+    if solver.noise_seed is None and (solver.noise_mode or "philox") in ("philox", "fused"):
         from . import engine
 
         local.noise_seed = broadcast_seed(engine.draw_seed() if rank == 0 else 0, group, comm_device)

