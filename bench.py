@@ -107,8 +107,13 @@ def cpu_baseline(kind, n, b, total_steps, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="untimed: run the step kernel on scratch trajectories this long before the warm-up "
+                         "steps, so the GPU has left its idle clocks (the DVFS ramp takes ~15 ms: a 300-step "
+                         "burst from idle measures the ramp, 42 us/step, not the 36 us/step a real 1500-15000 "
+                         "step solve runs at)")
     ap.add_argument("--workload", default="dl_n1000_b1000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,6 +150,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.spinup_ms > 0:
+        scratch, _, _ = make_trajectories(kind, n, b, 1 << 20, rank, seed=2)
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            scratch.advance(256)
+            torch.cuda.synchronize(dev)
+        del scratch
     traj.advance(args.warmup)
     torch.cuda.synchronize(dev)
     barrier()
@@ -203,6 +215,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "spinup_ms": args.spinup_ms,
             "config": {
                 "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
                             f"batch {b} per GPU x {world} GPU, fp32 state, fused Threefry noise, "

@@ -222,6 +222,15 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 __device__ __forceinline__ unsigned long long stamp_delta(unsigned long long a, unsigned long long b) { return b - a; }
 
+// Sixteenths of a step's noise units made in the prologue by the consumer / by the producer wave
+// (the remainder is spread over the main loop).  Tuned with tools/ablate.hip.
+#ifndef CCVM_NOISE_PROLOGUE_C
+#define CCVM_NOISE_PROLOGUE_C 8
+#endif
+#ifndef CCVM_NOISE_PROLOGUE_P
+#define CCVM_NOISE_PROLOGUE_P 8
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void global_cvoid;
 
@@ -290,6 +299,37 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // accumulator register r of lane (half, l31) is element (row0 + erow(r), j):
     auto erow = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
 
+    // Noise for accumulator registers R0 .. R0 + NR - 1 of consumer thread `tid` (made by that thread
+    // and by its producer twin 256 threads above, into lds_noise; consumed in the epilogue).
+    // DL: one unit per register (its (W_c, W_s) pair).  One-stream solvers: registers 2i and 2i+1
+    // are adjacent rows and share a unit (normal_two_rows); MF generates the NEXT step's normals
+    // (this step's arrive through the carry buffer).
+    // Every VALU instruction issued while the matrix pipe is busy costs matrix time (measured:
+    // +4.1 us per DL step at N = 1000 when all units ran inside the main loop), so the units are
+    // made in the prologue, while the first ring tiles are still in flight and the MFMA pipe is
+    // idle anyway: units [0, NPRO_C) by the consumer, [NPRO_C, NPRO_C + NPRO_P) by the producer
+    // after it has issued the first NSTAGE tiles, the rest (if any) one per main-loop iteration.
+    constexpr int NUNIT = ((MODE == MODE_DL) ? 16 : 8) / KS;  // noise work units per lane and step
+    constexpr int NPRO_C = NUNIT * CCVM_NOISE_PROLOGUE_C / 16;
+    constexpr int NPRO_P = NUNIT * CCVM_NOISE_PROLOGUE_P / 16;
+    static_assert(NPRO_C + NPRO_P <= NUNIT, "noise split");
+    auto make_noise = [&](int u) {
+        if constexpr (NOISY && !(ABL & 64)) {
+            if constexpr (MODE == MODE_DL) {
+                const int r = R0 + u;
+                const NormalPair p = normal_pair(a.seed, a.row_offset + row0 + erow(r), a.step, j);
+                lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
+                lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
+            } else {
+                const int r = R0 + 2 * u;  // rows b (even) and b + 1
+                const int st = (MODE == MODE_MF) ? a.step + 1 : a.step;
+                const NormalPair p = normal_two_rows(a.seed, a.row_offset + row0 + erow(r), st, j);
+                lds_noise[r * NTHREADS + tid] = p.n0;
+                lds_noise[(r + 1) * NTHREADS + tid] = p.n1;
+            }
+        }
+    };
+
     if (producer) {
         // =========================== producer waves ====================================
         // Producers issue few instructions but each must get out promptly; at equal priority the
@@ -348,27 +388,6 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                     : "memory");
             }
         };
-        // Noise for the registers this thread's consumer twin finishes (R0 .. R0 + NR - 1).
-        // DL: one call per register (its (W_c, W_s) pair).  One-stream solvers: registers 2i and 2i+1
-        // are adjacent rows and share a call (normal_two_rows); MF generates the NEXT step's normals
-        // (this step's arrive through the carry buffer).
-        constexpr int NUNIT = ((MODE == MODE_DL) ? 16 : 8) / KS;  // noise work units per lane and step
-        auto make_noise = [&](int u) {
-            if constexpr (NOISY && !(ABL & 64)) {
-                if constexpr (MODE == MODE_DL) {
-                    const int r = R0 + u;
-                    const NormalPair p = normal_pair(a.seed, a.row_offset + row0 + erow(r), a.step, j);
-                    lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
-                    lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
-                } else {
-                    const int r = R0 + 2 * u;  // rows b (even) and b + 1
-                    const int st = (MODE == MODE_MF) ? a.step + 1 : a.step;
-                    const NormalPair p = normal_two_rows(a.seed, a.row_offset + row0 + erow(r), st, j);
-                    lds_noise[r * NTHREADS + tid] = p.n0;
-                    lds_noise[(r + 1) * NTHREADS + tid] = p.n1;
-                }
-            }
-        };
         // tile kt must have landed before the barrier that precedes its first fragment read:
         // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PMAX).  No lgkmcnt wait: the
         // noise ds_writes are only consumed behind the final barrier.
@@ -378,17 +397,22 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         };
 #pragma unroll
         for (int kt = 0; kt < NSTAGE; ++kt) dma_tile(kt);
+        if (gen_noise) {
+#pragma unroll
+            for (int u = NPRO_C; u < NPRO_C + NPRO_P; ++u) make_noise(u);
+        }
         publish();  // tiles 0, 1 visible
         // the consumers read tile 0's fragments right after that barrier: slot 0 may only be
         // refilled (with tile NSTAGE) once they are done
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nkt; ++t) {
             dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
-            if (gen_noise && t < NUNIT) make_noise(t);
+            constexpr int NLOOP = NUNIT - NPRO_C - NPRO_P;
+            if (gen_noise && t < NLOOP) make_noise(NPRO_C + NPRO_P + t);
             publish();             // tile t + 2 visible
         }
         if (gen_noise)
-            for (int u = min(nkt, NUNIT); u < NUNIT; ++u) make_noise(u);
+            for (int u = NPRO_C + NPRO_P + min(nkt, NUNIT - NPRO_C - NPRO_P); u < NUNIT; ++u) make_noise(u);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue; ring idle
         return;
@@ -469,6 +493,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     };
 
     FragsT f0, f1;
+    if (gen_noise) {  // this thread's share of the noise, under the first tiles' flight time
+#pragma unroll
+        for (int u = 0; u < NPRO_C; ++u) make_noise(u);
+    }
     __syncthreads();  // tiles 0, 1 are in the ring (fence + barrier: LDS reads stay below it)
 #pragma unroll
     for (int g = 0; g < NG; ++g) read_part(f0, 0, g);

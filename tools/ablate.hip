@@ -99,6 +99,22 @@ int main(int argc, char** argv) {
     const int it = 50;
     printf("grid %d x %d threads, N=%d B=%d ld=%d\n", a.nrb * a.ncb, WG_THREADS, N, B, ld);
     printf("full                         : %8.2f us\n", run_variant<0>(a, it));
+    {   // as the ABI runs it: ping-pong state buffers (each step reads what the previous one wrote)
+        StepArgs b = a;
+        b.a0 = c2; b.a1 = s2; b.o0 = c; b.o1 = s;
+        int flip = 0;
+        auto pp = [&] {
+            const StepArgs& x = (flip ^= 1) ? a : b;
+            hipLaunchKernelGGL((step_kernel<MODE_DL, false, 0>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, 0, x);
+        };
+        printf("full, ping-pong state        : %8.2f us\n", time_us(pp, it));
+        if ((a.nrb * a.ncb) % 64 == 0) {
+            a.xr = a.nrb / 8; a.xc = a.ncb; b.xr = a.xr; b.xc = a.xc;
+            printf("full, ping-pong, XCD %2dx%-2d   : %8.2f us\n", a.xr, a.xc, time_us(pp, it));
+            printf("full, XCD rect, no ping-pong : %8.2f us\n", run_variant<0>(a, it));
+            a.xr = a.xc = b.xr = b.xc = 0;
+        }
+    }
     printf("no epilogue            (16)  : %8.2f us\n", run_variant<16>(a, it));
     printf("no DMA loads            (1)  : %8.2f us\n", run_variant<1>(a, it));
     printf("no frag reads           (4)  : %8.2f us\n", run_variant<4>(a, it));
@@ -106,8 +122,20 @@ int main(int argc, char** argv) {
     printf("no loads, no noise     (65)  : %8.2f us\n", run_variant<65>(a, it));
     printf("no loads/reads/noise   (69)  : %8.2f us\n", run_variant<69>(a, it));
     printf("... and no epilogue    (85)  : %8.2f us\n", run_variant<85>(a, it));
+    printf("no loop barrier        (32)  : %8.2f us\n", run_variant<32>(a, it));
+    printf("no barrier, no DMA     (33)  : %8.2f us\n", run_variant<33>(a, it));
+    printf("no barrier, no noise   (96)  : %8.2f us\n", run_variant<96>(a, it));
+    printf("no barrier/noise/epi  (112)  : %8.2f us\n", run_variant<112>(a, it));
     printf("no MFMA                 (8)  : %8.2f us\n", run_variant<8>(a, it));
     printf("no MFMA, no epilogue   (24)  : %8.2f us\n", run_variant<24>(a, it));
+    printf("no MFMA, no noise      (72)  : %8.2f us\n", run_variant<72>(a, it));
+    printf("no MFMA, no DMA         (9)  : %8.2f us\n", run_variant<9>(a, it));
+    printf("no MFMA, no reads      (12)  : %8.2f us\n", run_variant<12>(a, it));
+    printf("no MFMA/noise/epilogue (88)  : %8.2f us\n", run_variant<88>(a, it));
+    printf("no MFMA/noise/epi/DMA  (89)  : %8.2f us\n", run_variant<89>(a, it));
+    printf("no MFMA/noise/epi/reads(92)  : %8.2f us\n", run_variant<92>(a, it));
+    printf("no MFMA/noise/epi/DMA/reads(93): %6.2f us\n", run_variant<93>(a, it));
+    printf("... and no barrier    (125)  : %8.2f us\n", run_variant<125>(a, it));
     {   // phase shares from the stamped build (cycles per tile, median over workgroups)
         hipLaunchKernelGGL((step_kernel<MODE_DL, false, 128>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, 0, a);
         CK(hipDeviceSynchronize());
