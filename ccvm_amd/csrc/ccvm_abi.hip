@@ -168,7 +168,7 @@ int launch_step(StepArgs a, hipStream_t st, const char* name) {
 // ---- persistent small-N path -----------------------------------------------------------------
 constexpr int PERSIST_MAX_N = 128;
 constexpr int TABLE_STEPS = 4096;  // steps per persistent launch (schedule table rows in the workspace)
-size_t table_bytes() { return (size_t)TABLE_STEPS * 8 * sizeof(float); }
+size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float); }
 
 // CCVM_AMD_KERNEL=tile|persist forces a path (tests / profiling); default: persistent when it applies.
 bool want_persist(int N) {
@@ -177,18 +177,56 @@ bool want_persist(int N) {
     return !(e && !std::strcmp(e, "tile"));
 }
 
-template <int MODE>
+// Shape by N (columns a wave covers x waves side by side) and rows in use per 4-row group: 4 when
+// that still gives (nearly) every one of the 1024 SIMDs a wave, else 2 (shorter per-step chain per
+// wave, twice the waves).  CCVM_AMD_PERSIST_RU=2|4 overrides (tuning).
+template <int MODE, bool ADAM, int CW, int NCG, int NCH>
+void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
+    constexpr int RG = 64 / CW;
+    const int br4 = ((MODE == MODE_DL) ? 2 : 4) * RG;  // batch rows per workgroup at RU = 4
+    int ru = ((a.B + br4 - 1) / br4) * NCG >= 768 ? 4 : 2;
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU")) {
+        if (e[0] == '2') ru = 2;
+        if (e[0] == '4') ru = 4;
+    }
+    const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
+    if (ru == 4) {
+        const int per = br4 * (4 / NCG);
+        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4>), dim3((a.B + per - 1) / per), block, 0, st, a);
+    } else {
+        const int per = br4 / 2 * (4 / NCG);
+        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2>), dim3((a.B + per - 1) / per), block, 0, st, a);
+    }
+}
+
+template <int MODE, bool ADAM>
 int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
-    const int rows = (MODE == MODE_DL) ? 8 : 16;
-    const dim3 grid((a.B + rows - 1) / rows), block(256);
-    const int N = a.N;
-    if (N <= 32) hipLaunchKernelGGL((persist_kernel<MODE, 2, 1>), grid, block, 0, st, a);
-    else if (N <= 64) hipLaunchKernelGGL((persist_kernel<MODE, 4, 1>), grid, block, 0, st, a);
-    else if (N <= 96) hipLaunchKernelGGL((persist_kernel<MODE, 6, 2>), grid, block, 0, st, a);
-    else if (N <= 112) hipLaunchKernelGGL((persist_kernel<MODE, 7, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((persist_kernel<MODE, 8, 2>), grid, block, 0, st, a);
+    switch ((a.N + 15) / 16) {  // K chunks of 16
+        case 1: launch_persist_shape<MODE, ADAM, 16, 1, 1>(a, st); break;
+        case 2: launch_persist_shape<MODE, ADAM, 32, 1, 2>(a, st); break;
+        case 3: launch_persist_shape<MODE, ADAM, 64, 1, 3>(a, st); break;
+        case 4: launch_persist_shape<MODE, ADAM, 64, 1, 4>(a, st); break;
+        case 5: launch_persist_shape<MODE, ADAM, 64, 2, 5>(a, st); break;
+        case 6: launch_persist_shape<MODE, ADAM, 64, 2, 6>(a, st); break;
+        case 7: launch_persist_shape<MODE, ADAM, 64, 2, 7>(a, st); break;
+        default: launch_persist_shape<MODE, ADAM, 64, 2, 8>(a, st); break;
+    }
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
+}
+
+void persist_adam(PersistArgs& pa, AdamSched& sc, const ccvm_adam* adam, bool use_adam) {
+    std::memset(&sc, 0, sizeof(sc));
+    if (!use_adam) return;
+    sc.enabled = 1;
+    sc.beta1 = adam->beta1;
+    sc.beta2 = adam->beta2;
+    sc.use_v = adam->beta2 != 1.0;
+    AdamScalars s;
+    fill_adam(s, adam, 0);
+    pa.ad = AdamConsts{s.beta1, s.one_m_beta1, s.beta2, s.one_m_beta2, s.alpha, s.eps, s.use_v, s.add_assign};
+    pa.am = adam->m;
+    pa.av = adam->v;
 }
 
 inline int ew_grid(size_t total) {
@@ -211,7 +249,7 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
         case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
-        case 1: return 3 * state + qs;                   // MF: measured-amplitude ping-pong + noise carry
+        case 1: return 3 * state + qs + table_bytes();   // MF: measured-amplitude ping-pong + noise carry
         case 2: return state + qs + table_bytes();       // Langevin: c'
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
@@ -293,7 +331,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 pa.w0 = nz->w0 + (size_t)done * N * B;
                 pa.w1 = nz->w1 + (size_t)done * N * B;
             }
-            if ((rc = launch_persist<MODE_DL>(pa, st, fn))) return rc;
+            if ((rc = launch_persist<MODE_DL, false>(pa, st, fn))) return rc;
         }
         return CCVM_OK;
     }
@@ -348,15 +386,42 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     const bool use_adam = adam && adam->enabled;
 
     const size_t state = (size_t)ccvm_rows(B) * ld;
-    float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
-    float* carry = static_cast<float*>(ws) + 2 * state;  // this step's normals (fused mode)
-    if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
-        return fail(CCVM_E_HIP, "%s: memset failed", fn);
-
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     const double sdt = std::sqrt(p->dt);
     auto j_at = [&](int i) { return p->j * std::exp(-(double)(i + 1) / (double)T * 3.0); };  // :550
     const bool replay = nz->mode == CCVM_NOISE_REPLAY;
+
+    if (want_persist(N)) {
+        // whole chunks of the trajectory in one launch each (ccvm_persist.h)
+        const float* qsum;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum))) return rc;
+        float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N));
+        PersistArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.Q = Q; pa.V = V; pa.qsum = qsum; pa.x0 = mu; pa.x1 = sigma; pa.xt = mu_tilde_out; pa.table = table;
+        pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = replay;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / p->S); pa.in_shift = (float)up;
+        pa.S = (float)p->S;
+        AdamSched asc;
+        persist_adam(pa, asc, adam, use_adam);
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, p->S, ul, p->pump_rate_flag, T, step0 + done, k, asc};
+            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            pa.step0 = step0 + done;
+            pa.nsteps = k;
+            pa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
+            if (replay) pa.w0 = nz->w0 + (size_t)done * N * B;
+            rc = use_adam ? launch_persist<MODE_MF, true>(pa, st, fn) : launch_persist<MODE_MF, false>(pa, st, fn);
+            if (rc) return rc;
+        }
+        return CCVM_OK;
+    }
+
+    float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
+    float* carry = static_cast<float*>(ws) + 2 * state;  // this step's normals (fused mode)
+    if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     // measured amplitude of the first step of this chunk (mf_solver.py:551-554)
     {
@@ -442,22 +507,26 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     a.in_scale = (float)(ul / (2.0 * p->S));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
-    if (!use_adam && want_persist(N)) {
+    if (want_persist(N)) {
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        AdamSched asc;
+        persist_adam(pa, asc, adam, use_adam);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, p->S, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
-                       step0 + done, k};
+                       step0 + done, k, asc};
             hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
             pa.step0 = step0 + done;
             pa.nsteps = k;
             if (pa.replay) pa.w0 = nz->w0 + (size_t)done * N * B;
-            if ((rc = launch_persist<MODE_LANGEVIN>(pa, st, fn))) return rc;
+            rc = use_adam ? launch_persist<MODE_LANGEVIN, true>(pa, st, fn)
+                          : launch_persist<MODE_LANGEVIN, false>(pa, st, fn);
+            if (rc) return rc;
         }
         return CCVM_OK;
     }

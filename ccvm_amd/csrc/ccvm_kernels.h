@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "ccvm_noise.h"
 

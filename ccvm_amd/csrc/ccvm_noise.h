@@ -71,6 +71,38 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, i
     return p;
 }
 
+// Two independent calls in lockstep.  A wave that is alone on its SIMD issues a DEPENDENT VALU
+// instruction only every ~8 cycles (an independent one every 4) and hipcc does not interleave two
+// calls by itself; the persistent kernel, one wave per SIMD, gets its ILP from here.  Bit-identical
+// to two normal_pair calls.
+__device__ __forceinline__ void normal_pair_x2(uint64_t seed, int64_t grow_a, int64_t grow_b, int step, int col,
+                                               NormalPair& pa, NormalPair& pb) {
+    const uint32_t k0 = static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step);
+    const uint32_t hi = static_cast<uint32_t>(seed >> 32);
+    const uint32_t k1a = hi ^ static_cast<uint32_t>(static_cast<uint64_t>(grow_a) >> 32);
+    const uint32_t k1b = hi ^ static_cast<uint32_t>(static_cast<uint64_t>(grow_b) >> 32);
+    const uint32_t ksa[3] = {k0, k1a, 0x1BD11BDAu ^ k0 ^ k1a};
+    const uint32_t ksb[3] = {k0, k1b, 0x1BD11BDAu ^ k0 ^ k1b};
+    uint32_t a0 = static_cast<uint32_t>(col) + ksa[0], a1 = static_cast<uint32_t>(grow_a) + ksa[1];
+    uint32_t b0 = static_cast<uint32_t>(col) + ksb[0], b1 = static_cast<uint32_t>(grow_b) + ksb[1];
+#define CCVM_TF_ROUND2(R) a0 += a1; b0 += b1; a1 = rotl32(a1, R); b1 = rotl32(b1, R); a1 ^= a0; b1 ^= b0
+#define CCVM_TF_KEY2(S) a0 += ksa[(S) % 3]; b0 += ksb[(S) % 3]; a1 += ksa[((S) + 1) % 3] + (S); b1 += ksb[((S) + 1) % 3] + (S)
+    CCVM_TF_ROUND2(13); CCVM_TF_ROUND2(15); CCVM_TF_ROUND2(26); CCVM_TF_ROUND2(6);  CCVM_TF_KEY2(1u);
+    CCVM_TF_ROUND2(17); CCVM_TF_ROUND2(29); CCVM_TF_ROUND2(16); CCVM_TF_ROUND2(24); CCVM_TF_KEY2(2u);
+    CCVM_TF_ROUND2(13); CCVM_TF_ROUND2(15); CCVM_TF_ROUND2(26); CCVM_TF_ROUND2(6);  CCVM_TF_KEY2(3u);
+    CCVM_TF_ROUND2(17);
+#undef CCVM_TF_ROUND2
+#undef CCVM_TF_KEY2
+    const float la = __builtin_amdgcn_logf(u01(a0)), lb = __builtin_amdgcn_logf(u01(b0));
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * la);
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * lb);
+    const float ua = u01(a1), ub = u01(b1);
+    pa.n0 = ra * __builtin_amdgcn_cosf(ua);
+    pb.n0 = rb * __builtin_amdgcn_cosf(ub);
+    pa.n1 = ra * __builtin_amdgcn_sinf(ua);
+    pb.n1 = rb * __builtin_amdgcn_sinf(ub);
+}
+
 // One-stream solvers: the normal of element (global row, col) at `step`.
 __device__ __forceinline__ float normal_single(uint64_t seed, int64_t grow, int step, int col) {
     const NormalPair p = normal_pair(seed, grow >> 1, step, col);
@@ -86,6 +118,18 @@ __device__ __forceinline__ NormalPair normal_two_rows(uint64_t seed, int64_t gro
     r.n0 = p.n1;
     r.n1 = normal_pair(seed, (grow_even_local >> 1) + 1, step, col).n0;
     return r;
+}
+
+// normal_two_rows for two row pairs at once (local rows e and e + 2 of a lane), in lockstep when the
+// shard starts at an even global row.
+__device__ __forceinline__ void normal_two_rows_x2(uint64_t seed, int64_t grow_a, int64_t grow_b, int step, int col,
+                                                   NormalPair& pa, NormalPair& pb) {
+    if (!((grow_a | grow_b) & 1)) {
+        normal_pair_x2(seed, grow_a >> 1, grow_b >> 1, step, col, pa, pb);
+    } else {
+        pa = normal_two_rows(seed, grow_a, step, col);
+        pb = normal_two_rows(seed, grow_b, step, col);
+    }
 }
 
 }  // namespace ccvm

@@ -1,32 +1,55 @@
-// Row-owner persistent kernel for small problems (N <= 128): the whole chunk of time steps in ONE
-// launch.  At these sizes a per-step launch is latency-bound (N=100, B=1000: ~0.3 us of arithmetic
-// per step against a ~10 us launch+prologue), and batch rows never interact, so a workgroup can own
-// its rows for the entire trajectory with no inter-workgroup traffic at all:
+// Row-owner persistent kernel for small problems (N <= 128): a whole chunk of time steps in ONE
+// launch, for every solver of the family (DL, MF, Langevin / pumped Langevin, Adam variants).
 //
-//   workgroup = 256 threads = 4 waves -> the 16 rows of a v_mfma_f32_16x16x4_f32 tile:
-//     DL: 8 batch rows, c stacked on s (rows 0-7 = c, rows 8-15 = s);  Langevin/PL: 16 batch rows
-//   Q fragments are loaded ONCE and stay in registers for every step (wave w owns column tiles
-//     w, w+4: KQ x NCT VGPRs); the state makes a round trip through a double-buffered 16 x Kpad LDS
-//     tile (it is the MFMA A operand); per step: fragment reads, KQ x NCT MFMAs, update, barrier.
-//   lane-quarter q of a wave owns k in [q*KQ, (q+1)*KQ) (one b128 read per four k-steps).
-//   DL epilogue: the C/D layout puts c[b,j] in lane L and s[b,j] in lane L^32; the partner value
-//     comes by one cross-half shuffle, and the pair splits the noise calls (each Threefry call yields
-//     the (W_c, W_s) pair of one element) and swaps the halves the same way.
-//   Per-step schedule scalars come from a table built on the device in fp64 (schedule kernels).
+// At these sizes a per-step launch is latency-bound (N=100, B=1000: ~0.3 us of arithmetic per step
+// against ~10 us of launch + pipeline fill) and batch rows never interact, so a workgroup can own its
+// rows for the entire trajectory with no inter-workgroup traffic at all.
 //
-// Same noise definition, same folded affine map and same pinned update arithmetic as step_kernel.
+// Matrix instruction: v_mfma_f32_4x4x1_16B_f32 -- sixteen independent 4x4 outer products per
+// instruction, D[reg r][lane l] += A[lane 4*(l/4) + r] * B[lane l] (layout probed on the chip,
+// tools/mfma4x4_probe.hip).  With B = Q[k][column of lane l] and A = X[row r][k] replicated over the
+// blocks, one instruction is one k-step of (4 rows) x (64 columns): the same 256 flop/cycle/CU as the
+// big tiles, but with M = 4, so a wave owns FEW rows and the batch spreads over all 1024 SIMDs
+// (B=1000 DL rows on the 16-row tile of v_mfma_f32_16x16x4_f32 filled 125 of 256 CUs).
+//
+//   shape (CW, NCG): a wave covers CW columns (16 / 32 / 64) and RG = 64 / CW row groups of 4 MFMA
+//     rows; N > 64 uses NCG = 2 waves side by side (128 columns) which exchange the state through a
+//     double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per workgroup.
+//   RU (2 or 4) = MFMA rows in use per group: 4 when that still gives every SIMD a wave, else 2
+//     (half the per-step VALU chain per wave, twice the waves).
+//   Rows of a group: DL (c_b0, s_b0, c_b1, s_b1) -- both quadratures of an element and its
+//     (W_c, W_s) noise pair live in ONE lane; one-stream solvers: 4 consecutive batch rows, adjacent
+//     rows sharing a generator call exactly as in the tile kernel.
+//   Q fragments (Q[k][col], k < 16 * NCH, NCH = ceil(N / 16) a template parameter) are loaded once and
+//     stay in registers; the state makes a round trip through LDS each step because it is the MFMA A
+//     operand.  The contraction is straight-line code: with run-time chunk branches hipcc shuffled
+//     the accumulators AGPR <-> VGPR around every branch.
+//   Per-step schedule scalars come from a table built on the device in fp64 (schedule kernels below).
+//
+// Same noise definition, folded affine map and pinned update arithmetic (ccvm_kernels.h helpers) as
+// step_kernel; only the summation order of the contraction differs (inside the stated tolerance).
 #pragma once
 #include "ccvm_kernels.h"
 
 namespace ccvm {
 
+constexpr int TABLE_WORDS = 16;  // fp32 words per schedule-table row: solver scalars, [12..13] Adam bias corrections
+
+struct AdamConsts {
+    float beta1, one_m_beta1, beta2, one_m_beta2, alpha, eps;
+    int use_v, add_assign;
+};
+
 struct PersistArgs {
     const float* Q;
     const float* V;
     const float* qsum;
-    float* x0;          // DL: c; Langevin: c   (pitched, in/out)
-    float* x1;          // DL: s
-    const float* table; // [nsteps] x DlScalars / LvScalars (fp32 words)
+    float* x0;          // DL: c;  MF: mu;  Langevin: c      (pitched, in/out)
+    float* x1;          // DL: s;  MF: sigma
+    float* xt;          // MF: measured amplitude fed to the LAST step of this launch (may be NULL)
+    float* am;          // Adam moments (in/out)
+    float* av;
+    const float* table; // [nsteps][TABLE_WORDS]
     const float* w0;    // REPLAY noise for the chunk: [nsteps][N][B]
     const float* w1;
     uint64_t seed;
@@ -35,177 +58,291 @@ struct PersistArgs {
     int replay;
     int B, N, ld;
     float in_scale, in_shift;
+    float k_first;      // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
+    float S;            // MF: clamp of the measured amplitude
+    AdamConsts ad;
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int MODE, int KQ4, int NCT>
+// Ablation bits for tools/persist_ablate.hip (0 in the product): 1 no MFMA, 2 no noise, 4 no update
+// arithmetic, 8 no barrier / LDS round trip.
+#ifndef CCVM_PERSIST_ABL
+#define CCVM_PERSIST_ABL 0
+#endif
+
+// acc[k & 3] += A(af[k / KC], block k % KC of each row group) x B(qf[k]) for k = 0 .. sizeof...(K) - 1
+// (CBSZ / ABID are instruction immediates, hence the pack expansion)
+template <int CBSZ, int KC, int... K>
+__device__ __forceinline__ void mfma_chain(const float* af, const float* qf, f32x4v* acc,
+                                           std::integer_sequence<int, K...>) {
+    ((acc[K & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[K / KC], qf[K], acc[K & 3], CBSZ, K % KC, 0)), ...);
+}
+
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU>
 __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
-    static_assert(MODE == MODE_DL || MODE == MODE_LANGEVIN, "persistent kernel: DL and Langevin family");
-    constexpr int KQ = 4 * KQ4;          // k values per lane quarter
-    constexpr int KPAD = 4 * KQ;         // padded K
-    constexpr int LDX = KPAD + 4;        // LDS row stride (floats)
-    constexpr int ROWS = (MODE == MODE_DL) ? 8 : 16;  // batch rows per workgroup
-    __shared__ __attribute__((aligned(16))) float xs[2 * 16 * LDX];
+    static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
+    static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
+    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG == 2 && CW == 64)), "shape");
+    static_assert(RU == 2 || RU == 4, "rows in use per group");
+    constexpr int RG = 64 / CW;                                // row groups per wave
+    static_assert(NCH >= 1 && 16 * NCH <= CW * NCG, "K chunks vs shape");
+    constexpr int KMAX = 16 * NCH;                             // K in use: 16 * ceil(N / 16), compile time so
+                                                               // that the contraction is straight-line code
+    constexpr int ROWS = RU * RG;                              // MFMA rows per workgroup
+    constexpr int NE = (MODE == MODE_DL) ? RU / 2 : RU;        // batch rows (elements) per lane
+    constexpr int BR = NE * RG;                                // batch rows per workgroup
+    constexpr int LDX = CW * NCG + 8;                          // LDS row stride: == 8 (mod 32), the 4 rows x 8 k
+                                                               // of a half-wave read hit 32 distinct banks
+    constexpr int KC = CW / 4;                                 // k-steps fed by one A register (blocks per row group)
+    constexpr int CBSZ = (CW == 64) ? 4 : (CW == 32) ? 3 : 2;  // log2(KC)
+    // Row sets per workgroup: a workgroup is always four waves = one per SIMD, i.e. two two-wave sets
+    // (N > 64) or four one-wave sets.  Smaller workgroups landed unevenly on the SIMDs (DL N=100:
+    // 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with two of these waves takes twice as
+    // long.  The sets of a workgroup share nothing (N > 64: but the barrier).
+    constexpr int RSW = 4 / NCG;
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4;      // C/D: rows 4g .. 4g+3;  A/B operands: k quarter
-    const int ci = lane & 15;     // C/D: column inside the tile;  A operand: row
-    const int row0 = blockIdx.x * ROWS;
-    const int ld = a.ld, N = a.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = wave % NCG;
+    float* const xs = xs_all + (wave / NCG) * (2 * ROWS * LDX);
+    const int rs = lane / CW;            // row group
+    const int col = cg * CW + (lane % CW);
+    const int i4 = lane & 3;             // the A-operand row this lane supplies to its block
+    const int bg = (lane % CW) >> 2;     // block inside the row group: the k residue this lane supplies
+    const int N = a.N, ld = a.ld;
+    const bool col_ok = col < N;
 
-    // ---- Q fragments, resident for the whole launch ---------------------------------------
-    float qf[NCT][KQ];
-    int col[NCT];
-    float vj[NCT], shift_j[NCT];
-    bool col_ok[NCT];
+    // ---- Q fragments, resident for the whole launch (rows >= N of the pitched Q are zero) ------
+    float qf[KMAX];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        col[ct] = 16 * (wave + 4 * ct) + ci;
-        col_ok[ct] = col[ct] < N;
+    for (int k = 0; k < KMAX; ++k) qf[k] = a.Q[(size_t)k * ld + col];
+    const float vj = col_ok ? a.V[col] : 0.0f;
+    const float shift_j = a.in_shift * a.qsum[col];  // shift * colsum(Q)[j]
+
+    // ---- this lane's elements: batch rows brow[e] at column col -------------------------------
+    const int row0 = (blockIdx.x * RSW + wave / NCG) * BR;
+    int brow[NE];
+    bool ok[NE];
+    size_t gidx[NE];
 #pragma unroll
-        for (int m = 0; m < KQ; ++m) qf[ct][m] = a.Q[(size_t)(g * KQ + m) * ld + col[ct]];  // zero padded
-        vj[ct] = col_ok[ct] ? a.V[col[ct]] : 0.0f;
-        shift_j[ct] = col_ok[ct] ? a.in_shift * a.qsum[col[ct]] : 0.0f;
+    for (int e = 0; e < NE; ++e) {
+        brow[e] = row0 + rs * NE + e;
+        ok[e] = col_ok && brow[e] < a.B;
+        gidx[e] = (size_t)brow[e] * ld + col;  // inside the padded arrays for every lane
+    }
+    float s0[NE], s1[NE];   // DL: c, s;  MF: mu, sigma;  Langevin: c, -
+    float mt[NE], wc[NE];   // MF: measured amplitude (GEMM input) and the normals that made it
+    float am[NE], av[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        s0[e] = a.x0[gidx[e]];
+        s1[e] = (MODE == MODE_LANGEVIN) ? 0.0f : a.x1[gidx[e]];
+        mt[e] = wc[e] = am[e] = av[e] = 0.0f;
+        if constexpr (ADAM) {
+            am[e] = a.am[gidx[e]];
+            av[e] = a.ad.use_v ? a.av[gidx[e]] : 0.0f;
+        }
     }
 
-    // ---- this lane's state elements: C/D register reg of tile ct is (row 4g+reg, col[ct]) ----
-    // DL: rows 0-7 are c of batch rows row0 .. row0+7, rows 8-15 are s of the same batch rows.
-    float own[NCT][4];
-    int brow[4];          // batch row (local to this call) of register reg
-    bool row_ok[4];
-    const bool second = (MODE == MODE_DL) && (g >= 2);  // this lane holds s (quadrature) elements
-    float* const arr = second ? a.x1 : a.x0;
+    // one-stream normals of this lane's rows at `step` (it = index inside the launch, for replay)
+    auto stream_normals = [&](int step, int it, float* out) {
+        if (a.replay) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int r16 = 4 * g + reg;
-        brow[reg] = row0 + ((MODE == MODE_DL) ? (r16 & 7) : r16);
-        row_ok[reg] = brow[reg] < a.B;
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) own[ct][reg] = arr[(size_t)brow[reg] * ld + col[ct]];  // padded arrays
-
-    // ---- state tile into LDS buffer 0 (zero beyond N: the arrays are zero padded) ---------------
-    for (int i = tid; i < 16 * KPAD; i += 256) {
-        const int r = i / KPAD, k = i - r * KPAD;
-        const float* src = (MODE == MODE_DL && r >= 8) ? a.x1 : a.x0;
-        const int b = row0 + ((MODE == MODE_DL) ? (r & 7) : r);
-        xs[r * LDX + k] = (k < ld) ? src[(size_t)b * ld + k] : 0.0f;
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int it = 0; it < a.nsteps; ++it) {
-        const int step = a.step0 + it;
-        // ---- GEMM: acc[ct] = X(16 x KPAD) @ Q(KPAD x 16 cols of tile ct) ---------------------
-        const float* xb = xs + cur * 16 * LDX + ci * LDX + g * KQ;
-        f32x4v af[KQ4];
-#pragma unroll
-        for (int t = 0; t < KQ4; ++t) af[t] = *reinterpret_cast<const f32x4v*>(xb + 4 * t);
-        f32x4v acc[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int m = 0; m < KQ; ++m)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m >> 2][m & 3], qf[ct][m], acc[ct], 0, 0, 0);
-
-        // ---- update -------------------------------------------------------------------------
-        float* xn = xs + (cur ^ 1) * 16 * LDX;
-        if constexpr (MODE == MODE_DL) {
-            const DlScalars k = *reinterpret_cast<const DlScalars*>(a.table + (size_t)it * 8);
-            const float pm_own = second ? k.pm_s : k.pm_c;
-            const float w_own = second ? k.w_s : k.w_c;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                if (16 * (wave + 4 * ct) >= N) continue;  // wave-uniform: a column tile entirely in the padding
-                // noise: the pair (lane, lane^32) needs the four (W_c, W_s) pairs of registers 0..3 of
-                // batch rows 4*(g&1)+reg.  The c lane computes registers 0,1, the s lane 2,3; halves swap.
-                float n_own[4];
-                if (a.replay) {
-                    const float* w = second ? a.w1 : a.w0;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        n_own[reg] = (col_ok[ct] && row_ok[reg])
-                                         ? w[((size_t)it * N + col[ct]) * a.B + brow[reg]] : 0.0f;
-                } else {
-                    const int rb = second ? 2 : 0;
-                    const NormalPair p0 = normal_pair(a.seed, a.row_offset + brow[0] + rb, step, col[ct]);
-                    const NormalPair p1 = normal_pair(a.seed, a.row_offset + brow[1] + rb, step, col[ct]);
-                    // keep my quadrature's normals, give the partner its own
-                    const float keep0 = second ? p0.n1 : p0.n0, give0 = second ? p0.n0 : p0.n1;
-                    const float keep1 = second ? p1.n1 : p1.n0, give1 = second ? p1.n0 : p1.n1;
-                    const float recv0 = __shfl_xor(give0, 32, 64), recv1 = __shfl_xor(give1, 32, 64);
-                    n_own[0] = second ? recv0 : keep0;
-                    n_own[1] = second ? recv1 : keep1;
-                    n_own[2] = second ? keep0 : recv0;
-                    n_own[3] = second ? keep1 : recv1;
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float mine = own[ct][reg];
-                    const float other = __shfl_xor(mine, 32, 64);
-                    const float qx = __builtin_fmaf(a.in_scale, acc[ct][reg], shift_j[ct]);
-                    // dl_update, symmetric in (c, s): r2 = c^2 + s^2 either way
-                    float cn, sn;
-                    DlScalars kk = k;
-                    kk.pm_c = pm_own;
-                    kk.w_c = w_own;
-                    dl_update(kk, mine, other, qx, qx, vj[ct], n_own[reg], 0.0f, cn, sn);
-                    const float nv = (col_ok[ct] && row_ok[reg]) ? cn : mine;
-                    own[ct][reg] = nv;
-                    xn[(4 * g + reg) * LDX + col[ct]] = nv;
-                }
-            }
+            for (int e = 0; e < NE; ++e) out[e] = ok[e] ? a.w0[((size_t)it * N + col) * a.B + brow[e]] : 0.0f;
         } else {
-            const LvScalars k = *reinterpret_cast<const LvScalars*>(a.table + (size_t)it * 8);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                if (16 * (wave + 4 * ct) >= N) continue;
-                // registers (0,1) and (2,3) are adjacent rows: one call per pair (ccvm_noise.h)
-                float ns[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (!a.replay) {
-                    const NormalPair pa = normal_two_rows(a.seed, a.row_offset + brow[0], step, col[ct]);
-                    const NormalPair pb = normal_two_rows(a.seed, a.row_offset + brow[2], step, col[ct]);
-                    ns[0] = pa.n0; ns[1] = pa.n1; ns[2] = pb.n0; ns[3] = pb.n1;
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const bool ok = col_ok[ct] && row_ok[reg];
-                    float n0 = 0.0f;
-                    if (a.replay) {
-                        if (ok) n0 = a.w0[((size_t)it * N + col[ct]) * a.B + brow[reg]];
-                    } else {
-                        n0 = ns[reg];
-                    }
-                    const float mine = own[ct][reg];
-                    const float qx = __builtin_fmaf(a.in_scale, acc[ct][reg], shift_j[ct]);
-                    const float gq = __builtin_fmaf(k.g_q, qx, k.g_v * vj[ct]);
-                    const float nv = ok ? lv_update(k, mine, gq, n0) : mine;
-                    own[ct][reg] = nv;
-                    xn[(4 * g + reg) * LDX + col[ct]] = nv;
-                }
+            if constexpr (NE == 4) {  // rows (0,1) and (2,3): two generator calls in lockstep
+                NormalPair pa, pb;
+                normal_two_rows_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[2], step, col, pa, pb);
+                out[0] = pa.n0; out[1] = pa.n1; out[2] = pb.n0; out[3] = pb.n1;
+            } else {                  // rows (0,1): local row 0 is even
+                const NormalPair p = normal_two_rows(a.seed, a.row_offset + brow[0], step, col);
+                out[0] = p.n0;
+                out[1] = p.n1;
             }
         }
-        cur ^= 1;
-        __syncthreads();
+    };
+
+    // ---- GEMM input of the first step into LDS buffer 0 ----------------------------------------
+    if constexpr (MODE == MODE_MF) {
+        stream_normals(a.step0, 0, wc);  // mf_solver.py:551-554 for the first step of the launch
+#pragma unroll
+        for (int e = 0; e < NE; ++e) mt[e] = ok[e] ? clampf(__builtin_fmaf(a.k_first, wc[e], s0[e]), -a.S, a.S) : 0.0f;
+    }
+    auto publish = [&](float* buf) {  // this lane's GEMM-input values into an LDS state tile
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (MODE == MODE_DL) {
+                buf[(rs * RU + 2 * e) * LDX + col] = s0[e];
+                buf[(rs * RU + 2 * e + 1) * LDX + col] = s1[e];
+            } else if constexpr (MODE == MODE_MF) {
+                buf[(rs * RU + e) * LDX + col] = mt[e];
+            } else {
+                buf[(rs * RU + e) * LDX + col] = s0[e];
+            }
+        }
+    };
+    publish(xs);
+    if constexpr (NCG > 1) __syncthreads();
+
+    const int arow = rs * RU + (i4 < RU ? i4 : 0);  // rows >= RU of a group are unused: any finite row
+    int cur = 0;
+    // schedule row of the step, fetched one step ahead (scalar loads share lgkmcnt with the LDS reads:
+    // a row requested at the top of the step would be waited for together with the A operands)
+    struct Row { float w[TABLE_WORDS]; };
+    Row rnext = *reinterpret_cast<const Row*>(a.table);
+    for (int it = 0; it < a.nsteps; ++it) {
+        const int step = a.step0 + it;
+        const Row rcur = rnext;
+        const float* trow = rcur.w;
+        // ---- acc[r] = X[row rs*RU + r][:] @ Q[:, col] ---------------------------------------------
+        const float* xb = xs + cur * ROWS * LDX + arow * LDX + bg;
+        f32x4v acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        // A operand through the broadcast controls: with CBSZ = log2(CW / 4) the blocks of a row group
+        // all take their A rows from block ABID of that group, so lane (block bg, row i4) only has to
+        // hold X[row i4][k] for the k == bg (mod KC) -- ONE ds_read_b32 per lane feeds KC MFMAs (a
+        // row-broadcast b128 per 4 k-steps left one read in flight and exposed the LDS latency 28 times).
+        float af[16 * NCH / KC];
+#pragma unroll
+        for (int c = 0; c < 16 * NCH / KC; ++c) af[c] = xb[c * KC];
+        __builtin_amdgcn_sched_barrier(0);  // all reads in flight before the first MFMA (one latency, not NCH)
+        if constexpr (!(CCVM_PERSIST_ABL & 1)) {
+            mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, 16 * NCH>{});
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16 * NCH / KC; ++c) acc[c & 3][0] += af[c] * qf[c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
+        float qx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            qx[r] = __builtin_fmaf(a.in_scale, (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]), shift_j);
+
+        AdamScalars ad;
+        if constexpr (ADAM) {
+            ad.beta1 = a.ad.beta1; ad.one_m_beta1 = a.ad.one_m_beta1; ad.inv_bc1 = trow[12];
+            ad.beta2 = a.ad.beta2; ad.one_m_beta2 = a.ad.one_m_beta2; ad.inv_bc2 = trow[13];
+            ad.alpha = a.ad.alpha; ad.eps = a.ad.eps; ad.use_v = a.ad.use_v; ad.add_assign = a.ad.add_assign;
+        }
+        auto adam = [&](float g, int e) {
+            if constexpr (ADAM) {
+                float m, v;
+                const float out = adam_precondition(ad, g, am[e], av[e], m, v);
+                am[e] = ok[e] ? m : am[e];
+                av[e] = ok[e] ? v : av[e];
+                return out;
+            } else {
+                return g;
+            }
+        };
+
+        // ---- update ------------------------------------------------------------------------------
+        // The elements of a lane are independent dependency chains and this wave is usually alone on
+        // its SIMD (a dependent VALU instruction issues every ~8 cycles, an independent one every 4):
+        // noise for all elements first, then all updates, branch-free, so the scheduler interleaves them.
+        if constexpr (MODE == MODE_DL) {
+            const DlScalars k = *reinterpret_cast<const DlScalars*>(trow);
+            float n0[NE], n1[NE];
+            if (a.replay) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const size_t w = ((size_t)it * N + col) * a.B + brow[e];
+                    n0[e] = ok[e] ? a.w0[w] : 0.0f;
+                    n1[e] = ok[e] ? a.w1[w] : 0.0f;
+                }
+            } else {
+                if constexpr (CCVM_PERSIST_ABL & 2) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) n0[e] = n1[e] = 0.25f;
+                } else if constexpr (NE == 2) {  // two generator calls in lockstep
+                    NormalPair pa, pb;
+                    normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
+                    n0[0] = pa.n0; n1[0] = pa.n1; n0[1] = pb.n0; n1[1] = pb.n1;
+                } else {
+                    const NormalPair p = normal_pair(a.seed, a.row_offset + brow[0], step, col);
+                    n0[0] = p.n0;
+                    n1[0] = p.n1;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                float cn, sn;
+                if constexpr (CCVM_PERSIST_ABL & 4) {
+                    cn = s0[e] + qx[2 * e] * n0[e];
+                    sn = s1[e] + qx[2 * e + 1] * n1[e];
+                } else {
+                    dl_update(k, s0[e], s1[e], qx[2 * e], qx[2 * e + 1], vj, n0[e], n1[e], cn, sn);
+                }
+                s0[e] = ok[e] ? cn : s0[e];
+                s1[e] = ok[e] ? sn : s1[e];
+            }
+        } else if constexpr (MODE == MODE_MF) {
+            const MfScalars k = *reinterpret_cast<const MfScalars*>(trow);
+            float wn[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) wn[e] = 0.0f;
+            if (k.has_next) stream_normals(step + 1, it + 1, wn);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float fb = adam(__builtin_fmaf(k.f_q, qx[e], k.f_v * vj), e);
+                float mun, sgn;
+                mf_update(k, s0[e], s1[e], fb, wc[e], mun, sgn);
+                s0[e] = ok[e] ? mun : s0[e];
+                s1[e] = ok[e] ? sgn : s1[e];
+                // the last step's input is what mu_tilde_out returns: no new measurement after it
+                const bool nxt = ok[e] && k.has_next;
+                mt[e] = nxt ? clampf(__builtin_fmaf(k.k_next, wn[e], s0[e]), -k.S, k.S) : mt[e];
+                wc[e] = nxt ? wn[e] : wc[e];
+            }
+        } else {
+            const LvScalars k = *reinterpret_cast<const LvScalars*>(trow);
+            float n0[NE];
+            stream_normals(step, it, n0);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float g = adam(__builtin_fmaf(k.g_q, qx[e], k.g_v * vj), e);
+                const float x = lv_update(k, s0[e], g, n0[e]);
+                s0[e] = ok[e] ? x : s0[e];
+            }
+        }
+        if constexpr (!(CCVM_PERSIST_ABL & 8)) {
+            cur ^= 1;
+            publish(xs + cur * ROWS * LDX);
+            // one-wave sets: a wave's LDS instructions execute in order, its reads see its own writes
+            if constexpr (NCG > 1) __syncthreads();
+        }
     }
 
     // ---- write the state back -----------------------------------------------------------------
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            if (col_ok[ct] && row_ok[reg]) arr[(size_t)brow[reg] * ld + col[ct]] = own[ct][reg];
+    for (int e = 0; e < NE; ++e) {
+        if (!ok[e]) continue;
+        a.x0[gidx[e]] = s0[e];
+        if constexpr (MODE != MODE_LANGEVIN) a.x1[gidx[e]] = s1[e];
+        if constexpr (MODE == MODE_MF)
+            if (a.xt) a.xt[gidx[e]] = mt[e];
+        if constexpr (ADAM) {
+            a.am[gidx[e]] = am[e];
+            if (a.ad.use_v) a.av[gidx[e]] = av[e];
+        }
+    }
 }
 
 // ---- per-step schedule tables, built on the device in fp64 (same formulas as the host side of
-// ccvm_dl_run / ccvm_langevin_run; reference lines cited there) ------------------------------------
+// ccvm_dl_run / ccvm_mf_run / ccvm_langevin_run; reference lines cited there) ------------------------
+struct AdamSched {
+    double beta1, beta2;
+    int enabled, use_v;
+};
+__device__ __forceinline__ void adam_bias(const AdamSched& ad, int i, float* row) {
+    row[12] = ad.enabled ? (float)(1.0 / (1.0 - pow(ad.beta1, (double)(i + 1)))) : 1.0f;
+    row[13] = (ad.enabled && ad.use_v) ? (float)(1.0 / (1.0 - pow(ad.beta2, (double)(i + 1)))) : 1.0f;
+}
+
 struct DlSched {
     double pump, dt, noise_ratio, feedback_scale, g, ul, Sd;
     int pump_rate_flag, T, step0, nsteps;
@@ -227,12 +364,46 @@ __global__ void dl_schedule_kernel(const DlSched p, float* table) {
     k.g2 = (float)(2.0 * p.g);
     k.w_c = (float)(sqrt(p.dt) * ratio);
     k.w_s = (float)(sqrt(p.dt) / ratio);
-    *reinterpret_cast<DlScalars*>(table + (size_t)it * 8) = k;
+    *reinterpret_cast<DlScalars*>(table + (size_t)it * TABLE_WORDS) = k;
+}
+
+struct MfSched {
+    double pump, dt, j, feedback_scale, g, S, ul;
+    int pump_rate_flag, T, step0, nsteps;
+    AdamSched ad;
+};
+__global__ void mf_schedule_kernel(const MfSched p, float* table) {
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= p.nsteps) return;
+    const int i = p.step0 + it;
+    const double sdt = sqrt(p.dt);
+    const double j_i = p.j * exp(-(double)(i + 1) / (double)p.T * 3.0);
+    const double j_n = p.j * exp(-(double)(i + 2) / (double)p.T * 3.0);
+    const double rate = p.pump_rate_flag ? (double)(i + 1) / (double)p.T : 1.0;
+    const double p_i = p.pump * rate + 1.0 + j_i;
+    const bool has_next = it + 1 < p.nsteps;
+    MfScalars k;
+    k.a0 = (float)(-(1.0 + j_i) + p_i);
+    k.g2 = (float)(p.g * p.g);
+    k.f_q = (float)(-p.feedback_scale * 0.25 * p.ul / p.S);
+    k.f_v = (float)(-p.feedback_scale * p.ul / (2.0 * p.S));
+    k.j_i = (float)j_i;
+    k.one_j = (float)(1.0 + j_i);
+    k.sqrt_j = (float)sqrt(j_i);
+    k.inv_sdt = (float)(1.0 / sdt);
+    k.dt = (float)p.dt;
+    k.k_next = has_next ? (float)(sqrt(1.0 / (4.0 * j_n)) / sdt) : 0.0f;
+    k.S = (float)p.S;
+    k.has_next = has_next;
+    float* row = table + (size_t)it * TABLE_WORDS;
+    *reinterpret_cast<MfScalars*>(row) = k;
+    adam_bias(p.ad, i, row);
 }
 
 struct LvSched {
     double dt, sigma, feedback_scale, S, pump, ul;
     int use_pump, pump_rate_flag, T, step0, nsteps;
+    AdamSched ad;
 };
 __global__ void lv_schedule_kernel(const LvSched p, float* table) {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,9 +419,12 @@ __global__ void lv_schedule_kernel(const LvSched p, float* table) {
     k.w = (float)(p.sigma * sqrt(p.dt));
     k.S = (float)p.S;
     k.use_pump = p.use_pump;
-    *reinterpret_cast<LvScalars*>(table + (size_t)it * 8) = k;
+    float* row = table + (size_t)it * TABLE_WORDS;
+    *reinterpret_cast<LvScalars*>(row) = k;
+    adam_bias(p.ad, i, row);
 }
 
-static_assert(sizeof(DlScalars) == 32 && sizeof(LvScalars) == 32, "schedule table rows are 8 words");
+static_assert(sizeof(DlScalars) == 32 && sizeof(LvScalars) == 32 && sizeof(MfScalars) == 48,
+              "schedule table rows: solver scalars in words 0..11");
 
 }  // namespace ccvm

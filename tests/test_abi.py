@@ -47,9 +47,9 @@ def test_layout_helpers_and_version(hip_lib):
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
     state = 1024 * 1024 * 4
     qs = 33 * 1024 * 4  # column sums of Q + 32 slice partials
-    table = 4096 * 8 * 4  # schedule table of the persistent small-N path
+    table = 4096 * 16 * 4  # schedule table of the persistent small-N path
     assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table
-    assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs
+    assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs + table
     assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == state + qs + table
     assert hip_lib.ccvm_workspace_bytes(3, 1000, 1000) == 32 * 1024 * 4
     assert hip_lib.ccvm_workspace_bytes(4, 1000, 1000) == 2 * state

@@ -1,0 +1,24 @@
+"""Per-step time of the persistent small-N path (developer tool).
+   python tools/time_small.py [kind:N:B ...]     kinds: dl mf langevin pl"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+cases = sys.argv[1:] or ["dl:20:1000", "dl:64:1000", "dl:100:1000", "dl:128:1000", "mf:20:1000", "mf:100:1000",
+                         "langevin:20:1000", "langevin:100:1000", "pl:100:1000", "dl:100:4000", "dl:20:100"]
+steps = 4096
+for case in cases:
+    kind, n, b = case.split(":")
+    n, b = int(n), int(b)
+    traj, _, _ = bench.make_trajectories(kind, n, b, 1 << 20, 0)
+    traj.advance(steps)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        traj.advance(steps)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    print(f"{case:20s} RU={os.environ.get('CCVM_AMD_PERSIST_RU', 'auto'):4s} {best / steps * 1e6:8.3f} us/step "
+          f"{steps * b / best:.3e} row-steps/s", flush=True)
