@@ -12,7 +12,8 @@
 
 #include "../../include/ccvm_hip.h"
 #include "ccvm_kernels.h"
-#include "ccvm_persist.h"
+#include "ccvm_persist_launch.h"
+#include "ccvm_schedule.h"
 
 using namespace ccvm;
 
@@ -166,7 +167,6 @@ int launch_step(StepArgs a, hipStream_t st, const char* name) {
 }
 
 // ---- persistent small-N path -----------------------------------------------------------------
-constexpr int PERSIST_MAX_N = 128;
 constexpr int TABLE_STEPS = 4096;  // steps per persistent launch (schedule table rows in the workspace)
 size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float); }
 
@@ -177,40 +177,11 @@ bool want_persist(int N) {
     return !(e && !std::strcmp(e, "tile"));
 }
 
-// Shape by N (columns a wave covers x waves side by side) and rows in use per 4-row group: 4 when
-// that still gives (nearly) every one of the 1024 SIMDs a wave, else 2 (shorter per-step chain per
-// wave, twice the waves).  CCVM_AMD_PERSIST_RU=2|4 overrides (tuning).
-template <int MODE, bool ADAM, int CW, int NCG, int NCH>
-void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
-    constexpr int RG = 64 / CW;
-    const int br4 = ((MODE == MODE_DL) ? 2 : 4) * RG;  // batch rows per workgroup at RU = 4
-    int ru = ((a.B + br4 - 1) / br4) * NCG >= 768 ? 4 : 2;
-    if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU")) {
-        if (e[0] == '2') ru = 2;
-        if (e[0] == '4') ru = 4;
-    }
-    const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
-    if (ru == 4) {
-        const int per = br4 * (4 / NCG);
-        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4>), dim3((a.B + per - 1) / per), block, 0, st, a);
-    } else {
-        const int per = br4 / 2 * (4 / NCG);
-        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2>), dim3((a.B + per - 1) / per), block, 0, st, a);
-    }
-}
-
 template <int MODE, bool ADAM>
 int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
-    switch ((a.N + 15) / 16) {  // K chunks of 16
-        case 1: launch_persist_shape<MODE, ADAM, 16, 1, 1>(a, st); break;
-        case 2: launch_persist_shape<MODE, ADAM, 32, 1, 2>(a, st); break;
-        case 3: launch_persist_shape<MODE, ADAM, 64, 1, 3>(a, st); break;
-        case 4: launch_persist_shape<MODE, ADAM, 64, 1, 4>(a, st); break;
-        case 5: launch_persist_shape<MODE, ADAM, 64, 2, 5>(a, st); break;
-        case 6: launch_persist_shape<MODE, ADAM, 64, 2, 6>(a, st); break;
-        case 7: launch_persist_shape<MODE, ADAM, 64, 2, 7>(a, st); break;
-        default: launch_persist_shape<MODE, ADAM, 64, 2, 8>(a, st); break;
-    }
+    if constexpr (MODE == MODE_DL) persist_launch_dl(a, st);
+    else if constexpr (MODE == MODE_MF) ADAM ? persist_launch_mf_adam(a, st) : persist_launch_mf(a, st);
+    else ADAM ? persist_launch_lv_adam(a, st) : persist_launch_lv(a, st);
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
 }

@@ -1,0 +1,136 @@
+// Shared definitions of the CCVM dynamics engine's device code (gfx950 / MI355X only): solver modes,
+// per-step scalar blocks, and the pinned per-element update arithmetic used by BOTH the per-step tile
+// kernel (ccvm_kernels.h) and the persistent small-N kernel (ccvm_persist.h).  Header-only, inline
+// device functions only, so every translation unit of the library can include it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "ccvm_noise.h"
+
+namespace ccvm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Mode : int {
+    MODE_DL = 0,        // two-state DL-CCVM step
+    MODE_MF = 1,        // mean-field step (mu, sigma) + next measured amplitude
+    MODE_LANGEVIN = 2,  // Langevin / pumped Langevin step
+    MODE_ENERGY = 3,    // row partials of 1/2 xQx + Vx
+    MODE_GD = 4,        // projected gradient step (post-processor)
+    MODE_ADAMPP = 5,    // one Adam step from zero moments (post-processor)
+    MODE_AFFINE = 6     // y = f_q * (A(x) @ Q) + f_v * V   (the bare feedback term)
+};
+
+// Per-step scalars, computed on the host in fp64 exactly where the reference uses
+// Python/numpy doubles, then rounded once to fp32.
+struct DlScalars {
+    float a_q;      // -dt * fs*(1/2+rate) * (u-l)/(4 Sd)      coefficient of (x@Q)
+    float a_v;      // -dt * fs*(1/2+rate) * (u-l)/(2 Sd)      coefficient of V
+    float pm_c;     // -1 + pump*rate
+    float pm_s;     // -1 - pump*rate
+    float dt;
+    float g2;       // 2 g
+    float w_c;      // sqrt(dt) * noise_ratio_i
+    float w_s;      // sqrt(dt) / noise_ratio_i
+};
+struct MfScalars {
+    float a0;       // -(1 + j_i) + p_i
+    float g2;       // g^2
+    float f_q;      // -fs * (u-l)/(4 S)
+    float f_v;      // -fs * (u-l)/(2 S)
+    float j_i;
+    float one_j;    // 1 + j_i
+    float sqrt_j;   // sqrt(j_i)
+    float inv_sdt;  // 1/sqrt(dt)
+    float dt;
+    float k_next;   // sqrt(1/(4 j_{i+1})) / sqrt(dt)   (measured amplitude of the NEXT step)
+    float S;
+    int has_next;
+};
+struct LvScalars {
+    float g_q;      // -(u-l)/(2S)
+    float g_v;      // -(u-l)/(2S)
+    float pm;       // -1 + p_i (pumped only)
+    float dt;
+    float dt_fs;    // dt * feedback_scale
+    float w;        // sigma * sqrt(dt)
+    float S;
+    int use_pump;
+};
+struct PpScalars {
+    float step;     // GD step size / Adam lr
+    float eps;
+    float lo, hi;
+};
+struct AdamScalars {
+    float beta1, one_m_beta1, inv_bc1;  // inv_bc1 = 1/(1-beta1^(i+1))
+    float beta2, one_m_beta2, inv_bc2;
+    float alpha;
+    float eps;
+    int use_v;       // beta2 != 1
+    int add_assign;
+};
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    return fminf(fmaxf(x, lo), hi);
+}
+
+// ---- per-element updates ---------------------------------------------------------------
+// The epilogue is unrolled over the 16 accumulator registers; with free FMA contraction the
+// compiler fuses differently for different registers and a row's rounding would depend on its
+// position in the tile (breaking "shards are bit-identical to the unsharded run").  These
+// helpers pin the operation sequence: contraction off, fmaf where fusion is intended.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float adam_precondition(const AdamScalars& ad, float g, float m_old, float v_old,
+                                                   float& m_new, float& v_new) {
+    m_new = __builtin_fmaf(ad.beta1, m_old, ad.one_m_beta1 * g);
+    const float mhat = m_new * ad.inv_bc1;
+    float upd;
+    if (ad.use_v) {
+        v_new = __builtin_fmaf(ad.beta2, v_old, ad.one_m_beta2 * (g * g));
+        const float vhat = v_new * ad.inv_bc2;
+        upd = ad.alpha * (mhat / (__builtin_sqrtf(vhat) + ad.eps));
+    } else {
+        v_new = 0.0f;
+        upd = ad.alpha * mhat;
+    }
+    return ad.add_assign ? g + upd : upd;
+}
+
+__device__ __forceinline__ void dl_update(const DlScalars& k, float c, float s, float qc, float qs, float vj,
+                                          float n0, float n1, float& cn, float& sn) {
+    const float c2 = c * c, s2 = s * s;
+    const float r2 = c2 + s2;
+    const float diff = k.g2 * __builtin_amdgcn_sqrtf(r2 + 0.5f);  // raw v_sqrt_f32 (1 ulp)
+    const float fbk = k.a_v * vj;
+    const float dc = __builtin_fmaf(k.a_q, qc, fbk) + k.dt * ((k.pm_c - r2) * c);
+    const float ds = __builtin_fmaf(k.a_q, qs, fbk) + k.dt * ((k.pm_s - r2) * s);
+    cn = c + __builtin_fmaf(diff, n0 * k.w_c, dc);
+    sn = s + __builtin_fmaf(diff, n1 * k.w_s, ds);
+}
+
+__device__ __forceinline__ void mf_update(const MfScalars& k, float mu, float sg, float fb, float n0,
+                                          float& mun, float& sgn) {
+    const float wdot = n0 * k.inv_sdt;
+    const float mu2 = mu * mu;
+    const float term1 = (k.a0 - k.g2 * mu2) * mu;
+    const float sh = sg - 0.5f;
+    const float dsig = 2.0f * (k.a0 - 3.0f * k.g2 * mu2) * sg - 2.0f * k.j_i * (sh * sh) + (k.one_j + 2.0f * k.g2 * mu2);
+    const float diffusion = k.sqrt_j * sh * wdot;
+    mun = __builtin_fmaf(k.dt, term1 + fb + diffusion, mu);
+    sgn = __builtin_fmaf(k.dt, dsig, sg);
+}
+
+__device__ __forceinline__ float lv_update(const LvScalars& k, float c, float g, float n0) {
+    float x = __builtin_fmaf(k.dt_fs, g, c) + k.w * n0;
+    if (k.use_pump) x = __builtin_fmaf(k.dt, (k.pm - c * c) * c, x);
+    return clampf(x, -k.S, k.S);
+}
+#pragma clang fp contract(fast)
+
+}  // namespace ccvm

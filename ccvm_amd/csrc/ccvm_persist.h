@@ -29,7 +29,7 @@
 // Same noise definition, folded affine map and pinned update arithmetic (ccvm_kernels.h helpers) as
 // step_kernel; only the summation order of the contraction differs (inside the stated tolerance).
 #pragma once
-#include "ccvm_kernels.h"
+#include "ccvm_common.h"
 
 namespace ccvm {
 
@@ -83,7 +83,7 @@ template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU>
 __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
-    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG == 2 && CW == 64)), "shape");
+    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || ((NCG == 2 || NCG == 4) && CW == 64)), "shape");
     static_assert(RU == 2 || RU == 4, "rows in use per group");
     constexpr int RG = 64 / CW;                                // row groups per wave
     static_assert(NCH >= 1 && 16 * NCH <= CW * NCG, "K chunks vs shape");
@@ -330,98 +330,6 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             if (a.ad.use_v) a.av[gidx[e]] = av[e];
         }
     }
-}
-
-// ---- per-step schedule tables, built on the device in fp64 (same formulas as the host side of
-// ccvm_dl_run / ccvm_mf_run / ccvm_langevin_run; reference lines cited there) ------------------------
-struct AdamSched {
-    double beta1, beta2;
-    int enabled, use_v;
-};
-__device__ __forceinline__ void adam_bias(const AdamSched& ad, int i, float* row) {
-    row[12] = ad.enabled ? (float)(1.0 / (1.0 - pow(ad.beta1, (double)(i + 1)))) : 1.0f;
-    row[13] = (ad.enabled && ad.use_v) ? (float)(1.0 / (1.0 - pow(ad.beta2, (double)(i + 1)))) : 1.0f;
-}
-
-struct DlSched {
-    double pump, dt, noise_ratio, feedback_scale, g, ul, Sd;
-    int pump_rate_flag, T, step0, nsteps;
-};
-__global__ void dl_schedule_kernel(const DlSched p, float* table) {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= p.nsteps) return;
-    const int i = p.step0 + it;
-    const double frac = (double)(i + 1) / (double)p.T;
-    const double rate = p.pump_rate_flag ? frac : 1.0;
-    const double ratio = (p.noise_ratio - 1.0) * exp(-frac * 3.0) + 1.0;
-    const double fsd = p.feedback_scale * (0.5 + rate);
-    DlScalars k;
-    k.a_q = (float)(-p.dt * fsd * 0.25 * p.ul / p.Sd);
-    k.a_v = (float)(-p.dt * fsd * p.ul / (2.0 * p.Sd));
-    k.pm_c = (float)(-1.0 + p.pump * rate);
-    k.pm_s = (float)(-1.0 - p.pump * rate);
-    k.dt = (float)p.dt;
-    k.g2 = (float)(2.0 * p.g);
-    k.w_c = (float)(sqrt(p.dt) * ratio);
-    k.w_s = (float)(sqrt(p.dt) / ratio);
-    *reinterpret_cast<DlScalars*>(table + (size_t)it * TABLE_WORDS) = k;
-}
-
-struct MfSched {
-    double pump, dt, j, feedback_scale, g, S, ul;
-    int pump_rate_flag, T, step0, nsteps;
-    AdamSched ad;
-};
-__global__ void mf_schedule_kernel(const MfSched p, float* table) {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= p.nsteps) return;
-    const int i = p.step0 + it;
-    const double sdt = sqrt(p.dt);
-    const double j_i = p.j * exp(-(double)(i + 1) / (double)p.T * 3.0);
-    const double j_n = p.j * exp(-(double)(i + 2) / (double)p.T * 3.0);
-    const double rate = p.pump_rate_flag ? (double)(i + 1) / (double)p.T : 1.0;
-    const double p_i = p.pump * rate + 1.0 + j_i;
-    const bool has_next = it + 1 < p.nsteps;
-    MfScalars k;
-    k.a0 = (float)(-(1.0 + j_i) + p_i);
-    k.g2 = (float)(p.g * p.g);
-    k.f_q = (float)(-p.feedback_scale * 0.25 * p.ul / p.S);
-    k.f_v = (float)(-p.feedback_scale * p.ul / (2.0 * p.S));
-    k.j_i = (float)j_i;
-    k.one_j = (float)(1.0 + j_i);
-    k.sqrt_j = (float)sqrt(j_i);
-    k.inv_sdt = (float)(1.0 / sdt);
-    k.dt = (float)p.dt;
-    k.k_next = has_next ? (float)(sqrt(1.0 / (4.0 * j_n)) / sdt) : 0.0f;
-    k.S = (float)p.S;
-    k.has_next = has_next;
-    float* row = table + (size_t)it * TABLE_WORDS;
-    *reinterpret_cast<MfScalars*>(row) = k;
-    adam_bias(p.ad, i, row);
-}
-
-struct LvSched {
-    double dt, sigma, feedback_scale, S, pump, ul;
-    int use_pump, pump_rate_flag, T, step0, nsteps;
-    AdamSched ad;
-};
-__global__ void lv_schedule_kernel(const LvSched p, float* table) {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= p.nsteps) return;
-    const int i = p.step0 + it;
-    LvScalars k;
-    k.g_q = (float)(-p.ul / (2.0 * p.S));
-    k.g_v = k.g_q;
-    const double p_i = p.pump_rate_flag ? p.pump * (double)(i + 1) / (double)p.T : p.pump;
-    k.pm = (float)(-1.0 + p_i);
-    k.dt = (float)p.dt;
-    k.dt_fs = (float)(p.dt * p.feedback_scale);
-    k.w = (float)(p.sigma * sqrt(p.dt));
-    k.S = (float)p.S;
-    k.use_pump = p.use_pump;
-    float* row = table + (size_t)it * TABLE_WORDS;
-    *reinterpret_cast<LvScalars*>(row) = k;
-    adam_bias(p.ad, i, row);
 }
 
 static_assert(sizeof(DlScalars) == 32 && sizeof(LvScalars) == 32 && sizeof(MfScalars) == 48,

@@ -56,8 +56,8 @@ def _run_case(g, meta, device="cpu"):
 
 @pytest.fixture(params=["auto", "tile", "tile2"])
 def kernel_path(request, monkeypatch):
-    """Every engine path: "auto" = what the library picks (persistent row-owner kernel for N <= 128
-    DL / Langevin family without Adam, else the per-step tile kernel with its automatic tile shape);
+    """Every engine path: "auto" = what the library picks (persistent row-owner kernel for
+    N <= 256, else the per-step tile kernel with its automatic tile shape);
     "tile" forces the per-step kernel with 32x128 tiles (KS=1), "tile2" with 32x64 split-K tiles."""
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
@@ -129,6 +129,7 @@ def _gate(n):
     ("dl", 100, 256, 40), ("mf", 100, 256, 40), ("langevin", 100, 256, 40), ("pl", 100, 256, 40),
     ("dl", 20, 37, 25), ("dl", 64, 9, 25), ("dl", 90, 100, 20), ("dl", 128, 70, 20), ("pl", 33, 50, 25),
     ("dl", 1, 5, 12), ("langevin", 1, 1, 12), ("mf", 7, 3, 12), ("pl", 16, 1, 12), ("dl", 129, 33, 10),
+    ("dl", 200, 300, 10), ("dl", 256, 64, 10), ("mf", 144, 50, 10), ("langevin", 177, 90, 10), ("dl", 240, 1000, 6),
     ("dl", 20, 1600, 10), ("dl", 100, 1000, 10), ("dl", 48, 1540, 10), ("langevin", 12, 3100, 10), ("dl", 16, 6200, 6),
     ("pl", 2000, 96, 3),  # largest BASELINE problem size
     ("dl", 333, 130, 12), ("mf", 500, 200, 8), ("pl", 257, 65, 12),
@@ -196,6 +197,8 @@ _ADAMS = {
     ("langevin", 48, 20, 15, "add_assign"), ("pl", 64, 100, 15, "second_moment"), ("mf", 65, 30, 12, "second_moment"),
     ("langevin", 80, 50, 12, "first_moment_only"), ("pl", 96, 64, 12, "add_assign"), ("mf", 100, 256, 12, "add_assign"),
     ("pl", 112, 10, 12, "second_moment"), ("langevin", 128, 130, 12, "second_moment"),
+    ("mf", 160, 40, 10, "add_assign"), ("pl", 200, 70, 10, "second_moment"), ("langevin", 256, 100, 8, "first_moment_only"),
+    ("mf", 250, 1100, 6, "second_moment"),
     ("mf", 20, 3100, 10, "second_moment"), ("pl", 100, 3100, 8, "add_assign"), ("mf", 64, 3100, 8, "first_moment_only"),
     # per-step tile kernel (N > 128), both tile shapes
     ("mf", 300, 200, 8, "second_moment"), ("langevin", 500, 300, 6, "add_assign"), ("pl", 1000, 96, 4, "first_moment_only"),
@@ -204,7 +207,7 @@ def test_adam_variants_match_oracle_in_fused_mode(kind, n, b, t, adam, kernel_pa
     """MF / Langevin / pumped-Langevin _solve_adam (mf_solver.py:698-764, langevin_solver.py:513-559,
     pumped_langevin_solver.py:395-447) with the fused generator, against the oracle fed with the
     host restatement of the same generator."""
-    if kernel_path != "auto" and (n > 128 or b > 1000):
+    if kernel_path != "auto" and (n > 256 or b > 1000):
         pytest.skip("shapes above the persistent range / large batches once (auto path)")
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv

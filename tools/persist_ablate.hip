@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../ccvm_amd/csrc/ccvm_persist.h"
+#include "../ccvm_amd/csrc/ccvm_schedule.h"
 using namespace ccvm;
 int main(int argc, char** argv) {
     const int N = 100, B = 1000, ld = 128, rows = 1024, steps = 4096;
