@@ -109,7 +109,7 @@ class DLSolver(CCVMSolver):
         S = self._broadcast_saturation(self.S, problem_size)
         lo, hi = self.solution_bounds
 
-        start = self._timer_start()
+        start = self._timer_start("dl", problem_size)
         samples_taken, evolution_file = self._begin_sampling(
             instance, batch_size, problem_size, iterations, evolution_step_size, evolution_file
         )
