@@ -115,6 +115,30 @@ int main(int argc, char** argv) {
             a.xr = a.xc = b.xr = b.xc = 0;
         }
     }
+    {   // the same chain as a hipGraph (does graph submission shorten the kernel-to-kernel hand-over?)
+        hipStream_t st; hipStreamCreate(&st);
+        StepArgs b = a; b.a0 = c2; b.a1 = s2; b.o0 = c; b.o1 = s;
+        hipGraph_t g; hipGraphExec_t ge;
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        for (int i = 0; i < 50; ++i)
+            hipLaunchKernelGGL((step_kernel<MODE_DL, false, 0>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, (i & 1) ? b : a);
+        hipStreamEndCapture(st, &g);
+        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int r = 0; r < 4; ++r) hipGraphLaunch(ge, st);
+        hipStreamSynchronize(st);
+        hipEventRecord(e0, st);
+        for (int r = 0; r < 20; ++r) hipGraphLaunch(ge, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("full, ping-pong, hipGraph x50: %8.2f us\n", ms * 1000.f / 1000);
+        hipEventRecord(e0, st);
+        for (int r = 0; r < 1000; ++r)
+            hipLaunchKernelGGL((step_kernel<MODE_DL, false, 0>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, (r & 1) ? b : a);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("full, ping-pong, stream x1000: %8.2f us\n", ms * 1000.f / 1000);
+    }
     printf("no epilogue            (16)  : %8.2f us\n", run_variant<16>(a, it));
     printf("no DMA loads            (1)  : %8.2f us\n", run_variant<1>(a, it));
     printf("no frag reads           (4)  : %8.2f us\n", run_variant<4>(a, it));
