@@ -46,6 +46,24 @@ def measured_traffic(workload):
     kib = 2.0 * c["FETCH_SIZE"]["mean_per_dispatch"] + c["WRITE_SIZE"]["mean_per_dispatch"]
     return kib * 1024.0
 
+
+def measured_mfma_busy(workload):
+    """Fraction of the kernel's cycles in which the matrix pipes were busy, from the committed SQ
+    counter pass (profiles/r*_bench_pmc.json): SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs,
+    SQ_BUSY_CYCLES over the 32 shader engines (its per-engine value is the kernel's length in cycles)."""
+    import glob
+
+    if workload != "dl_n1000_b1000":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        c = json.load(fh)["counters"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "SQ_BUSY_CYCLES" not in c:
+        return None
+    return (c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 1024.0) / (c["SQ_BUSY_CYCLES"]["mean_per_dispatch"] / 32.0)
+
 WORKLOADS = {
     # name: (solver kind, N, batch per GPU, flops per row-step)
     "dl_n1000_b1000": ("dl", 1000, 1000),
@@ -260,6 +278,7 @@ def main():
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
                 "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
                 "algorithmic_bytes": bytes_per_launch, "algorithmic_flops": flops_per_launch,
+                "mfma_busy_frac": measured_mfma_busy(args.workload),
                 "kernel": "ccvm::step_kernel<MODE_DL>" if kind == "dl" else "ccvm::step_kernel",
                 "avg_launch_us": kernel_ms * 1e3,
                 "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
