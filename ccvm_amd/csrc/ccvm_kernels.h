@@ -206,6 +206,133 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         }
     };
 
+    // ---- epilogue, shared by both kinds of wave -------------------------------------------------
+    // For the solver steps the producer waves, idle once the last tile is in the ring, take half of
+    // the epilogue: the consumer hands the finished sums of its upper H accumulator registers and
+    // their operands to its producer twin through the (then idle) ring, and both run
+    // `run_epilogue` on H registers.  Two waves per SIMD also hide each other's VALU dependency
+    // stalls; with the consumers alone the 16-element epilogue cost 2.2 us of the 35 us step.
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    constexpr bool SHARE = NOISY && !(ABL & 16);
+    constexpr int H = SHARE ? NR / 2 : NR;  // epilogue elements per thread
+    static_assert(H % 4 == 0, "element i uses lane offset eoff[i & 3]");
+    constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
+    constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
+    constexpr int HAND_OFF = 4096;  // floats from the ring start: behind the KS = 2 exchange area
+    constexpr int HAND_VALUES = NA * H + H + (HAS_E1 ? H : 0) + (ADAM ? 2 * H : 0) + (MODE == MODE_MF ? H : 0);
+    static_assert(!SHARE || HAND_OFF + HAND_VALUES * NTHREADS <= NSTAGE * STAGE, "hand-over area fits in the ring");
+    float* const hand = lds + HAND_OFF;  // [value][tid]
+    // element address = [uniform: array + (row0 + 8 * (r >> 2)) * ld]  +  [lane: eoff[r & 3]]
+    // (scalar base + constant 32-bit lane offset: no per-access address VALU)
+    unsigned eoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) eoff[i] = (unsigned)((i + 4 * half) * ld + j);
+    auto gofs = [&](int r) { return (size_t)(row0 + 8 * (r >> 2)) * ld; };  // uniform part
+    const float vj = col_ok ? a.V[j] : 0.0f;
+    const float shift_j = a.in_shift * a.qsum[j];  // shift * colsum(Q)[j]
+
+    // Registers R0 + ibase + ii, ii = 0 .. H - 1.  hf: affine-folded GEMM sums; he0/he1: old state;
+    // he2/he3: Adam moments; hcar: MF's normals of this step.
+    auto run_epilogue = [&](const float (&hf)[NA][H], const float (&he0)[H], const float (&he1)[H],
+                            const float (&he2)[H], const float (&he3)[H], const float (&hcar)[H], int ibase) {
+        // every operand is already in registers, so each result is stored as soon as it is
+        // computed: no load ever waits behind a store.  `element(ii, ok, fused)` handles one
+        // register; the common case (whole row block inside the batch, fused noise) runs it under
+        // ONE column mask with no per-element branches, edge blocks and replay mode take the
+        // general path.
+        auto element = [&](int ii, bool ok, auto fused_tag) {
+            constexpr bool FUSED = decltype(fused_tag)::value;
+            const int r = R0 + ibase + ii;
+            const size_t gb = gofs(r);        // uniform
+            const unsigned lo = eoff[ii & 3];  // per lane (H and ibase are multiples of 4)
+            float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
+            if constexpr (NOISY) {
+                if constexpr (FUSED) {
+                    // written in the prologue by this thread or its twin
+                    if constexpr (MODE == MODE_MF) {
+                        n0 = hcar[ii];  // this step's normal, generated one step ago
+                        n0n = a.s.mf.has_next ? lds_noise[r * NTHREADS + tid] : 0.0f;
+                    } else {
+                        n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
+                        if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                    }
+                } else if (ok) {
+                    const size_t widx = (size_t)j * a.B + row0 + erow(r);
+                    n0 = a.w0[widx];
+                    if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
+                    if constexpr (MODE == MODE_MF)
+                        if (a.s.mf.has_next) n0n = a.w0n[widx];
+                }
+            }
+
+            // Adam preconditioning of the feedback term g (MF / Langevin variants)
+            auto adam = [&](float g) {
+                if constexpr (ADAM) {
+                    float m, v;
+                    const float out = adam_precondition(a.ad, g, he2[ii], he3[ii], m, v);
+                    if (ok) {
+                        (a.am + gb)[lo] = m;
+                        if (a.ad.use_v) (a.av + gb)[lo] = v;
+                    }
+                    return out;
+                } else {
+                    return g;
+                }
+            };
+
+            if constexpr (MODE == MODE_DL) {
+                float cn, sn;
+                dl_update(a.s.dl, he0[ii], he1[ii], hf[0][ii], hf[NA - 1][ii], vj, n0, n1, cn, sn);
+                if (ok) {
+                    (a.o0 + gb)[lo] = cn;
+                    (a.o1 + gb)[lo] = sn;
+                }
+            } else if constexpr (MODE == MODE_MF) {
+                const MfScalars& k = a.s.mf;
+                const float fb = adam(__builtin_fmaf(k.f_q, hf[0][ii], k.f_v * vj));
+                float mun, sgn;
+                mf_update(k, he0[ii], he1[ii], fb, n0, mun, sgn);
+                if (ok) {
+                    (a.st0 + gb)[lo] = mun;
+                    (a.st1 + gb)[lo] = sgn;
+                    if (k.has_next) {
+                        (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
+                        if constexpr (FUSED) (a.carry + gb)[lo] = n0n;  // next step's normal
+                    }
+                }
+            } else if constexpr (MODE == MODE_LANGEVIN) {
+                const LvScalars& k = a.s.lv;
+                const float g = adam(__builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj));
+                const float x = lv_update(k, he0[ii], g, n0);
+                if (ok) (a.o0 + gb)[lo] = x;
+            } else if constexpr (MODE == MODE_GD) {
+                const PpScalars& k = a.s.pp;
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, hf[0][ii] + vj, he0[ii]), k.lo, k.hi);
+            } else if constexpr (MODE == MODE_ADAMPP) {
+                const PpScalars& k = a.s.pp;
+                const float g = hf[0][ii] + vj;
+                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), he0[ii]), k.lo, k.hi);
+            } else if constexpr (MODE == MODE_AFFINE) {
+                const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
+                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, hf[0][ii], k.eps * vj);
+            }
+        };
+        const bool whole_block = row0 + BM <= a.B;  // wave-uniform
+        if (whole_block && (fused || !NOISY)) {
+            if (col_ok) {
+#pragma unroll
+                for (int ii = 0; ii < H; ++ii) element(ii, true, Yes{});
+            }
+        } else if (fused || !NOISY) {
+#pragma unroll
+            for (int ii = 0; ii < H; ++ii) element(ii, col_ok && (row0 + erow(R0 + ibase + ii) < a.B), Yes{});
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < H; ++ii) element(ii, col_ok && (row0 + erow(R0 + ibase + ii) < a.B), No{});
+        }
+    };
+
     if (producer) {
         // =========================== producer waves ====================================
         // Producers issue few instructions but each must get out promptly; at equal priority the
@@ -291,25 +418,34 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             for (int u = NPRO_C + NPRO_P + min(nkt, NUNIT - NPRO_C - NPRO_P); u < NUNIT; ++u) make_noise(u);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // noise visible to the consumers' epilogue; ring idle
+        if constexpr (SHARE) {
+            if constexpr (KS == 2) __builtin_amdgcn_s_barrier();  // the consumers' K-half exchange
+            __syncthreads();  // the consumers' hand-over is in the ring (fence + barrier)
+            float hf[NA][H], he0[H], he1[H], he2[H], he3[H], hcar[H];
+            int v = 0;
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int ii = 0; ii < H; ++ii) hf[n][ii] = hand[(v++) * NTHREADS + tid];
+#pragma unroll
+            for (int ii = 0; ii < H; ++ii) {
+                he0[ii] = hand[(v++) * NTHREADS + tid];
+                he1[ii] = HAS_E1 ? hand[(v++) * NTHREADS + tid] : 0.0f;
+                he2[ii] = ADAM ? hand[(v++) * NTHREADS + tid] : 0.0f;
+                he3[ii] = ADAM ? hand[(v++) * NTHREADS + tid] : 0.0f;
+                hcar[ii] = (MODE == MODE_MF) ? hand[(v++) * NTHREADS + tid] : 0.0f;
+            }
+            run_epilogue(hf, he0, he1, he2, he3, hcar, H);
+        }
         return;
     }
 
     // ============================= consumer waves =======================================
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
     // ---- epilogue operands, fetched now so their latency hides under the whole GEMM -----
     // e0/e1: old state at the element (DL: c, s; MF: mu, sigma; others: x); e2/e3: Adam moments;
     // ecar: MF's normals of this step.  Index i is accumulator register R0 + i.  Rows >= B and
     // columns >= N are inside the padded arrays.
-    constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
-    constexpr bool HAS_E1 = (MODE == MODE_DL || MODE == MODE_MF);
     float e0[NR], e1[NR], e2[NR], e3[NR], ecar[NR];
-    // element address = [uniform: array + (row0 + 8 * (r >> 2)) * ld]  +  [lane: eoff[r & 3]]
-    // (scalar base + constant 32-bit lane offset: no per-access address VALU)
-    unsigned eoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) eoff[i] = (unsigned)((i + 4 * half) * ld + j);
-    auto gofs = [&](int r) { return (size_t)(row0 + 8 * (r >> 2)) * ld; };  // uniform part
     {
         const float* p0 = (MODE == MODE_MF) ? a.st0 : a.a0;
         const float* p1 = (MODE == MODE_MF) ? a.st1 : a.a1;
@@ -321,9 +457,6 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             if constexpr (MODE == MODE_MF) ecar[i] = a.replay ? 0.0f : (a.carry + gofs(r))[eoff[i & 3]];
         }
     }
-    const float vj = col_ok ? a.V[j] : 0.0f;
-    const float shift_j = a.in_shift * a.qsum[j];  // shift * colsum(Q)[j]
-
     // fragment read offsets inside a stage (A: swizzled chunk position)
     const int sw = (l31 >> 1) & 7;
     const int fa = l31 * KT;
@@ -520,101 +653,38 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         }
         return;
     } else {
-        // every operand is already in registers (prefetch above), so each result is stored
-        // as soon as it is computed: no load ever waits behind a store.
-        // `element(i, ok, fused)` handles accumulator register R0 + i; the common case (whole row
-        // block inside the batch, fused noise) runs it under ONE column mask with no per-element
-        // branches, edge blocks and replay mode take the general path.
-        auto element = [&](int i, bool ok, auto fused_tag) {
-            constexpr bool FUSED = decltype(fused_tag)::value;
-            const int r = R0 + i;
-            const size_t gb = gofs(r);       // uniform
-            const unsigned lo = eoff[i & 3];  // per lane
-            float n0 = 0.0f, n1 = 0.0f, n0n = 0.0f;
-            if constexpr (NOISY) {
-                if constexpr (FUSED) {
-                    // written by this thread's producer twin, behind the final barrier
-                    if constexpr (MODE == MODE_MF) {
-                        n0 = ecar[i];  // this step's normal, generated one step ago
-                        n0n = a.s.mf.has_next ? lds_noise[r * NTHREADS + tid] : 0.0f;
-                    } else {
-                        n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
-                        if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
-                    }
-                } else if (ok) {
-                    const size_t widx = (size_t)j * a.B + row0 + erow(r);
-                    n0 = a.w0[widx];
-                    if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
-                    if constexpr (MODE == MODE_MF)
-                        if (a.s.mf.has_next) n0n = a.w0n[widx];
-                }
-            }
-
-            // Adam preconditioning of the feedback term g (MF / Langevin variants)
-            auto adam = [&](float g) {
-                if constexpr (ADAM) {
-                    float m, v;
-                    const float out = adam_precondition(a.ad, g, e2[i], e3[i], m, v);
-                    if (ok) {
-                        (a.am + gb)[lo] = m;
-                        if (a.ad.use_v) (a.av + gb)[lo] = v;
-                    }
-                    return out;
-                } else {
-                    return g;
-                }
-            };
-
-            if constexpr (MODE == MODE_DL) {
-                float cn, sn;
-                dl_update(a.s.dl, e0[i], e1[i], fin[0][i], fin[NA - 1][i], vj, n0, n1, cn, sn);
-                if (ok) {
-                    (a.o0 + gb)[lo] = cn;
-                    (a.o1 + gb)[lo] = sn;
-                }
-            } else if constexpr (MODE == MODE_MF) {
-                const MfScalars& k = a.s.mf;
-                const float fb = adam(__builtin_fmaf(k.f_q, fin[0][i], k.f_v * vj));
-                float mun, sgn;
-                mf_update(k, e0[i], e1[i], fb, n0, mun, sgn);
-                if (ok) {
-                    (a.st0 + gb)[lo] = mun;
-                    (a.st1 + gb)[lo] = sgn;
-                    if (k.has_next) {
-                        (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
-                        if constexpr (FUSED) (a.carry + gb)[lo] = n0n;  // next step's normal
-                    }
-                }
-            } else if constexpr (MODE == MODE_LANGEVIN) {
-                const LvScalars& k = a.s.lv;
-                const float g = adam(__builtin_fmaf(k.g_q, fin[0][i], k.g_v * vj));
-                const float x = lv_update(k, e0[i], g, n0);
-                if (ok) (a.o0 + gb)[lo] = x;
-            } else if constexpr (MODE == MODE_GD) {
-                const PpScalars& k = a.s.pp;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, fin[0][i] + vj, e0[i]), k.lo, k.hi);
-            } else if constexpr (MODE == MODE_ADAMPP) {
-                const PpScalars& k = a.s.pp;
-                const float g = fin[0][i] + vj;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), e0[i]), k.lo, k.hi);
-            } else if constexpr (MODE == MODE_AFFINE) {
-                const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, fin[0][i], k.eps * vj);
-            }
-        };
-        const bool whole_block = row0 + BM <= a.B;  // wave-uniform
-        if (whole_block && (fused || !NOISY)) {
-            if (col_ok) {
+        float hf[NA][H], he0[H], he1[H], he2[H], he3[H], hcar[H];
 #pragma unroll
-                for (int i = 0; i < NR; ++i) element(i, true, Yes{});
-            }
-        } else if (fused || !NOISY) {
+        for (int ii = 0; ii < H; ++ii) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) element(i, col_ok && (row0 + erow(R0 + i) < a.B), Yes{});
-        } else {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) element(i, col_ok && (row0 + erow(R0 + i) < a.B), No{});
+            for (int n = 0; n < NA; ++n) hf[n][ii] = fin[n][ii];
+            he0[ii] = HAS_E0 ? e0[ii] : 0.0f;
+            he1[ii] = HAS_E1 ? e1[ii] : 0.0f;
+            he2[ii] = ADAM ? e2[ii] : 0.0f;
+            he3[ii] = ADAM ? e3[ii] : 0.0f;
+            hcar[ii] = (MODE == MODE_MF) ? ecar[ii] : 0.0f;
         }
+        if constexpr (SHARE) {
+            // registers R0 + H .. R0 + 2H - 1 and their operands go to the producer twin (same tid
+            // mapping), in the order it reads them back
+            int v = 0;
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int ii = 0; ii < H; ++ii) hand[(v++) * NTHREADS + tid] = fin[n][H + ii];
+#pragma unroll
+            for (int ii = 0; ii < H; ++ii) {
+                hand[(v++) * NTHREADS + tid] = e0[H + ii];
+                if constexpr (HAS_E1) hand[(v++) * NTHREADS + tid] = e1[H + ii];
+                if constexpr (ADAM) {
+                    hand[(v++) * NTHREADS + tid] = e2[H + ii];
+                    hand[(v++) * NTHREADS + tid] = e3[H + ii];
+                }
+                if constexpr (MODE == MODE_MF) hand[(v++) * NTHREADS + tid] = ecar[H + ii];
+            }
+            __syncthreads();
+        }
+        run_epilogue(hf, he0, he1, he2, he3, hcar, 0);
     }
 }
 

@@ -41,7 +41,7 @@ float time_us(F&& launch, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) launch();
+    for (int i = 0; i < 200; ++i) launch();
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
     for (int i = 0; i < iters; ++i) launch();
@@ -96,7 +96,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dbg, 256 * 8 * 8));
     CK(hipMemset(dbg, 0, 256 * 8 * 8));
     a.dbg = dbg;
-    const int it = 50;
+    // steady-state clocks: the chip needs ~15 ms of load to leave its idle clocks, and a variant that
+    // runs for 2 ms is timed in whatever state the previous one left (run-to-run +-1 us): spin first,
+    // then 1000 launches per variant behind 200 warm-up launches
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int r = 0; r < 6000; ++r)
+            hipLaunchKernelGGL((step_kernel<MODE_DL, false, 0>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, 0, a);
+        hipDeviceSynchronize();
+    }
+    const int it = 1000;
     printf("grid %d x %d threads, N=%d B=%d ld=%d\n", a.nrb * a.ncb, WG_THREADS, N, B, ld);
     printf("full                         : %8.2f us\n", run_variant<0>(a, it));
     {   // as the ABI runs it: ping-pong state buffers (each step reads what the previous one wrote)
