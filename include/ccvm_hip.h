@@ -50,7 +50,7 @@ typedef enum ccvm_status {
 
 /* Wiener-noise source for one call. */
 typedef enum ccvm_noise_mode {
-    CCVM_NOISE_PHILOX = 0, /* counter-based generator (Threefry2x32-20 + Box-Muller) fused
+    CCVM_NOISE_PHILOX = 0, /* counter-based generator (Threefry2x32-13 + Box-Muller) fused
                               into the step kernel; the name is historical               */
     CCVM_NOISE_REPLAY = 1  /* read standard normals the caller generated (parity mode) */
 } ccvm_noise_mode;

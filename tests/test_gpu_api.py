@@ -126,3 +126,20 @@ def test_all_solvers_demo_runs():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if "TTS99" in ln]
     assert len(lines) == 6 and all("best" in ln for ln in lines)
+
+
+def test_c_abi_from_a_plain_cpp_client(tmp_path):
+    """The C ABI without Python or torch in the process (tests/abi_client.cpp): what a cgo / JNI /
+    ctypes binding does.  Compiled here with hipcc against include/ccvm_hip.h and the in-tree library."""
+    import shutil
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "abi_client"
+    lib_dir = os.path.join(ROOT, "ccvm_amd")
+    build = subprocess.run(
+        [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+         os.path.join(ROOT, "tests", "abi_client.cpp"), "-L", lib_dir, "-lccvm_hip", f"-Wl,-rpath,{lib_dir}",
+         "-o", str(exe)], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ABI_CLIENT_OK" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])
