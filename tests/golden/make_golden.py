@@ -88,8 +88,26 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     return arrays, meta
 
 
+def anchors():
+    # the DL example exactly as shipped: B=1000, T=1500, seed 1234 (SURVEY.md 8c anchor)
+    arrays, meta = run_case("dl", INSTANCES["tuningH020"], 1500, batch=1000, seed=1234)
+    with open(os.path.join(OUT, "dl_example_anchor.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    print("anchor", meta["best_objective_value"], meta["solution_performance"])
+    # BASELINE.json configs[0]: DLSolver on test020-100-10.in, batch 100, 15000 iterations
+    # (example parameters, g = 0.05, seed 1234)
+    arrays, meta = run_case("dl", INSTANCES["test020"], 15000, batch=100, seed=1234)
+    with open(os.path.join(OUT, "baseline_config1_anchor.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "baseline_config1_anchor.npz"), **arrays)
+    print("config 1", meta["best_objective_value"], meta["solution_performance"])
+
+
 def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
+    if "--only-anchors" in sys.argv:
+        anchors()
+        return
     for tag, path in INSTANCES.items():
         inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu")
         store = {
@@ -134,11 +152,7 @@ def main():
         with open(os.path.join(OUT, f"{tag}.json"), "w") as fh:
             json.dump(manifest, fh, indent=1, sort_keys=True)
 
-    # the DL example exactly as shipped: B=1000, T=1500, seed 1234 (SURVEY.md 8c anchor)
-    arrays, meta = run_case("dl", INSTANCES["tuningH020"], 1500, batch=1000, seed=1234)
-    with open(os.path.join(OUT, "dl_example_anchor.json"), "w") as fh:
-        json.dump(meta, fh, indent=1, sort_keys=True)
-    print("anchor", meta["best_objective_value"], meta["solution_performance"])
+    anchors()
 
 
 if __name__ == "__main__":

@@ -107,6 +107,30 @@ def test_dl_example_anchor():
         assert abs(sol.solution_performance[key] - frac) <= 2.0 / meta["batch"]
 
 
+def test_baseline_config_1():
+    """BASELINE.json configs[0]: DLSolver on test020-100-10, batch 100, 15000 iterations, seed 1234,
+    through the public API in replay mode, against the reference's own output (best 142.6326)."""
+    import json
+    import os
+
+    import numpy as np
+
+    from golden_util import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "baseline_config1_anchor.json")) as fh:
+        meta = json.load(fh)
+    arrays = np.load(os.path.join(GOLDEN_DIR, "baseline_config1_anchor.npz"))
+    g = golden("test020")
+    sol = _run_case(g, meta)
+    want_x = torch.from_numpy(arrays["problem_variables"].copy())
+    want_obj = torch.from_numpy(arrays["objective_values"].copy())
+    assert float((sol.variables["problem_variables"].cpu() - want_x).abs().max()) <= ATOL_X
+    assert float((sol.objective_values.cpu() - want_obj).abs().max()) <= ATOL_OBJ
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * meta["best_objective_value"]
+    for key, frac in meta["solution_performance"].items():
+        assert abs(sol.solution_performance[key] - frac) <= 1.0 / meta["batch"] + 1e-9
+
+
 def test_cuda_resident_instance_matches_host_resident():
     """device="cuda" (tensors stay on the GPU) and device="cpu" (staged) are the same engine."""
     g = golden("test020")

@@ -59,6 +59,36 @@ def test_oracle_reproduces_reference(tag, case):
         assert abs(out["solution_performance"][key] - frac) <= 1.0 / meta["batch"] + 1e-9
 
 
+def test_oracle_reproduces_baseline_config_1():
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): DLSolver on test020-100-10,
+    batch 100, 15000 iterations, example parameters, seed 1234 -> best 142.6326.
+    Fixture: tests/golden/baseline_config1_anchor.{json,npz}, produced by the reference itself."""
+    import json
+    import os
+
+    import numpy as np
+
+    from golden_util import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "baseline_config1_anchor.json")) as fh:
+        meta = json.load(fh)
+    arrays = np.load(os.path.join(GOLDEN_DIR, "baseline_config1_anchor.npz"))
+    g = golden("test020")
+    assert meta["iterations"] == 15000 and meta["batch"] == 100 and abs(meta["best_objective_value"] - 142.6326) < 1e-4
+    check_noise_checksum(meta, g.instance["problem_size"], meta["batch"])
+    q, v, f = g.scaled("dl")
+    p = meta["params"]
+    torch.manual_seed(meta["seed"])
+    out = oracle.solve_dl(q, v, meta["batch"], p["iterations"], p["pump"], p["dt"], p["noise_ratio"],
+                          p["feedback_scale"], optimal_value=g.instance["optimal_sol"], scaled_by=float(f),
+                          pump_rate_flag=meta["pump_rate_flag"])
+    assert np.array_equal(out["problem_variables"].numpy(), arrays["problem_variables"])
+    assert np.array_equal(out["s"].numpy(), arrays["s"])
+    assert np.array_equal(out["objective_values"].numpy(), arrays["objective_values"])
+    assert out["best_objective_value"] == meta["best_objective_value"]
+    assert out["solution_performance"] == meta["solution_performance"]
+
+
 def test_scaling_factor_matches_reference():
     for tag in ("test020", "tuningH020"):
         g = golden(tag)
