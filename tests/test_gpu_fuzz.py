@@ -1,0 +1,92 @@
+"""Seeded random sweep of the engine against the oracle (fused generator): awkward problem sizes
+(around every tile / shape boundary), tiny and ragged batches, odd shard offsets, random chunking,
+every solver and Adam variant.  One process, ~50 cases, each finishes in well under a second."""
+import math
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 96, 100, 127, 128, 129, 144, 200, 255, 256,
+         257, 300, 383, 385, 511, 513, 640]
+BATCHES = [1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 100, 257, 1000]
+ADAMS = [None,
+         {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False},
+         {"alpha": 0.01, "beta1": 0.8, "beta2": 0.99, "add_assign": True},
+         {"alpha": 0.002, "beta1": 0.9, "beta2": 1.0, "add_assign": True}]
+ATOL_X = 5e-4
+
+
+def _cases(count=96, seed=20240607):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        kind = rng.choice(["dl", "mf", "langevin", "pl"])
+        n, b, t = rng.choice(SIZES), rng.choice(BATCHES), rng.choice([1, 2, 5, 9])
+        if n * n * b > 4.2e8:  # keep the oracle side in seconds
+            b = max(1, int(4.2e8 / (n * n)))
+        adam = None if kind == "dl" else rng.choice(ADAMS)
+        offset = rng.choice([0, 1, 64, 4097, 123456])
+        cuts = sorted(rng.sample(range(1, t), min(t - 1, rng.choice([0, 1, 2])))) if t > 1 else []
+        replay = rng.random() < 0.3  # parity mode: torch's CPU stream in the reference's order
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay))
+    return out
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay", _cases())
+def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay):
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from oracle import ccvm_oracle as oracle
+    from oracle.noise_ref import FusedNoise
+
+    adam = ADAMS[adam_i]
+    q, v, _ = scaled_qv(n, kind)
+    p = dict(EXAMPLE_PARAMS[kind])
+    seed = 0xABCDEF12345 + 7919 * n + b
+    if replay:
+        noise = engine.NoiseSpec(mode="replay")
+        ref_noise = None  # the oracle's default: torch's global CPU stream, as the reference draws it
+        torch.manual_seed(seed)
+    else:
+        noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=offset)
+        ref_noise = FusedNoise(seed, offset, single=kind != "dl")
+    prob = engine.DeviceProblem(q, v)
+    if kind == "dl":
+        traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)
+        c, s = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05,
+                              (0.0, 1.0), True, ref_noise)
+        want = {"c": c, "s": s}
+    elif kind == "mf":
+        traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=0.01), (0.0, 1.0), noise, adam=adam)
+        mu, mu_tilde, sigma = oracle.mf_loop(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"],
+                                             0.01, (0.0, 1.0), True, adam, ref_noise)
+        want = {"mu": mu, "sigma": sigma, "mu_tilde": mu_tilde}
+    else:
+        traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl"), (0.0, 1.0), noise,
+                                   adam=adam)
+        if kind == "pl":
+            c = oracle.pl_loop(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], (0.0, 1.0),
+                               True, adam, ref_noise)
+        else:
+            c = oracle.langevin_loop(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], (0.0, 1.0), adam,
+                                     ref_noise)
+        want = {"c": c}
+    if replay:
+        torch.manual_seed(seed)  # the engine's feeder consumes the same stream from the same point
+    done = 0
+    for cut in list(cuts) + [t]:
+        traj.advance(cut - done)
+        done = cut
+    gate = ATOL_X * math.sqrt(max(n, 20) / 20.0)
+    for name, ref in want.items():
+        got = traj.compact(name).cpu()
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((got - ref).abs().max())
+        assert err <= gate * scale, (f"{kind} N={n} B={b} T={t} adam={adam_i} offset={offset} cuts={cuts} "
+                                     f"replay={replay} {name}: {err:.3e}")
+    for name, arr in traj.state.items():  # padding stays zero
+        assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
+        assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
