@@ -234,6 +234,9 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
 
     // Registers R0 + ibase + ii, ii = 0 .. H - 1.  hf: affine-folded GEMM sums; he0/he1: old state;
     // he2/he3: Adam moments; hcar: MF's normals of this step.
+    // The new state is written once and next read by the following launch (mostly from other CUs):
+    // non-temporal stores shorten the drain of the tail (-0.5 us per step at the headline shape).
+    auto st_nt = [](float* p, float x) { __builtin_nontemporal_store(x, p); };
     auto run_epilogue = [&](const float (&hf)[NA][H], const float (&he0)[H], const float (&he1)[H],
                             const float (&he2)[H], const float (&he3)[H], const float (&hcar)[H], int ibase) {
         // every operand is already in registers, so each result is stored as soon as it is
@@ -272,8 +275,8 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                     float m, v;
                     const float out = adam_precondition(a.ad, g, he2[ii], he3[ii], m, v);
                     if (ok) {
-                        (a.am + gb)[lo] = m;
-                        if (a.ad.use_v) (a.av + gb)[lo] = v;
+                        st_nt(&(a.am + gb)[lo], m);
+                        if (a.ad.use_v) st_nt(&(a.av + gb)[lo], v);
                     }
                     return out;
                 } else {
@@ -285,8 +288,8 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 float cn, sn;
                 dl_update(a.s.dl, he0[ii], he1[ii], hf[0][ii], hf[NA - 1][ii], vj, n0, n1, cn, sn);
                 if (ok) {
-                    (a.o0 + gb)[lo] = cn;
-                    (a.o1 + gb)[lo] = sn;
+                    st_nt(&(a.o0 + gb)[lo], cn);
+                    st_nt(&(a.o1 + gb)[lo], sn);
                 }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
@@ -294,28 +297,28 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 float mun, sgn;
                 mf_update(k, he0[ii], he1[ii], fb, n0, mun, sgn);
                 if (ok) {
-                    (a.st0 + gb)[lo] = mun;
-                    (a.st1 + gb)[lo] = sgn;
+                    st_nt(&(a.st0 + gb)[lo], mun);
+                    st_nt(&(a.st1 + gb)[lo], sgn);
                     if (k.has_next) {
-                        (a.o0 + gb)[lo] = clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S);
-                        if constexpr (FUSED) (a.carry + gb)[lo] = n0n;  // next step's normal
+                        st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S));
+                        if constexpr (FUSED) st_nt(&(a.carry + gb)[lo], n0n);  // next step's normal
                     }
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
                 const float g = adam(__builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj));
                 const float x = lv_update(k, he0[ii], g, n0);
-                if (ok) (a.o0 + gb)[lo] = x;
+                if (ok) st_nt(&(a.o0 + gb)[lo], x);
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, hf[0][ii] + vj, he0[ii]), k.lo, k.hi);
+                if (ok) st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(-k.step, hf[0][ii] + vj, he0[ii]), k.lo, k.hi));
             } else if constexpr (MODE == MODE_ADAMPP) {
                 const PpScalars& k = a.s.pp;
                 const float g = hf[0][ii] + vj;
-                if (ok) (a.o0 + gb)[lo] = clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), he0[ii]), k.lo, k.hi);
+                if (ok) st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), he0[ii]), k.lo, k.hi));
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
-                if (ok) (a.o0 + gb)[lo] = __builtin_fmaf(k.step, hf[0][ii], k.eps * vj);
+                if (ok) st_nt(&(a.o0 + gb)[lo], __builtin_fmaf(k.step, hf[0][ii], k.eps * vj));
             }
         };
         const bool whole_block = row0 + BM <= a.B;  // wave-uniform
