@@ -159,8 +159,8 @@ def _gate(n):
     ("dl", 333, 130, 12), ("mf", 500, 200, 8), ("pl", 257, 65, 12),
     ("dl", 1000, 1000, 6),  # BASELINE headline shape
     # maximum sizes: a batch of 20000 rows (2500 persistent workgroups), 5000 rows on the tile path
-    # (157 row blocks), and a 64 MB coupling matrix
-    ("dl", 20, 20000, 30), ("pl", 300, 5000, 5), ("langevin", 4096, 64, 2),
+    # (157 row blocks), and 64 MB / 256 MB coupling matrices
+    ("dl", 20, 20000, 30), ("pl", 300, 5000, 5), ("langevin", 4096, 64, 2), ("pl", 8192, 32, 1),
 ])
 def test_philox_mode_matches_oracle(kind, n, b, t, kernel_path):
     if kernel_path != "auto" and n * b >= 500000:
