@@ -143,3 +143,34 @@ def test_c_abi_from_a_plain_cpp_client(tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ABI_CLIENT_OK" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])
+
+
+def test_integration_md_ctypes_stub_runs_and_matches_the_engine():
+    """The ctypes stub INTEGRATION.md shows to a reference maintainer (the body that would replace
+    DLSolver._solve) is executed as written -- only the library path is made absolute -- and must give
+    the engine's own result for the same key."""
+    import re
+    import types
+
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def _solve(self" in b)
+    block = block.replace('ctypes.CDLL("libccvm_hip.so")', f'ctypes.CDLL("{os.path.join(ROOT, "ccvm_amd", "libccvm_hip.so")}")')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+
+    n, b, t = 20, 50, 30
+    q, v, _ = scaled_qv(n, "dl")
+    p = EXAMPLE_PARAMS["dl"]
+    me = types.SimpleNamespace(q_matrix=q, v_vector=v, solution_bounds=(0.0, 1.0))
+    torch.manual_seed(4242)
+    c, s = ns["_solve"](me, n, b, "cuda", 1.0, p["pump"], p["dt"], t, p["noise_ratio"], p["feedback_scale"], True, 0.05,
+                        None, 0)
+    torch.cuda.synchronize()
+    traj = engine.Trajectories(engine.DeviceProblem(q, v), b, "dl", t, dict(p, g=0.05), (0.0, 1.0),
+                               engine.NoiseSpec(mode="philox", seed=4242))
+    traj.advance(t)
+    traj.clamp("c", -1.0, 1.0)
+    assert c.shape == (b, n) and torch.equal(c.cpu(), traj.compact("c").cpu()) and torch.equal(s.cpu(), traj.compact("s").cpu())
