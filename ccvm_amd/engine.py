@@ -352,6 +352,14 @@ def _to_gpu(t):
     return t.detach().to(device=dev, dtype=torch.float32), dev
 
 
+def _rows_of_problem(xg, q_matrix, what):
+    """(batch, N) of a (batch, N) variable array that must match the N x N coupling matrix."""
+    if xg.ndim != 2 or q_matrix.ndim != 2 or xg.shape[1] != q_matrix.shape[0]:
+        raise ValueError(f"{what}: variables of shape {tuple(xg.shape)} do not match a coupling matrix of "
+                         f"shape {tuple(q_matrix.shape)}")
+    return int(xg.shape[0]), int(xg.shape[1])
+
+
 def change_variables(x, S, lower, upper):
     """0.5 * x / S * (upper - lower) + 0.5 * (upper + lower) on the GPU."""
     lib = _lib.load()
@@ -384,7 +392,7 @@ def feedback(x, q_matrix, v_vector, in_scale, in_shift, f_q, f_v):
     """f_q * ((x * in_scale + in_shift) @ Q) + f_v * V  -- the bare feedback term."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
-    b, n = xg.shape
+    b, n = _rows_of_problem(xg, q_matrix, "feedback")
     with torch.cuda.device(dev):
         prob = DeviceProblem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
@@ -402,7 +410,7 @@ def energy(confs, q_matrix, v_vector, scaled_by=1.0):
     """(1/2 x Q x + V x) * scaled_by for every row of ``confs``."""
     lib = _lib.load()
     xg, dev = _to_gpu(confs)
-    b, n = xg.shape
+    b, n = _rows_of_problem(xg, q_matrix, "energy")
     with torch.cuda.device(dev):
         prob = DeviceProblem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
@@ -422,7 +430,7 @@ def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, s
     """On-device grad-descent / adam post-processor; returns (x', seconds)."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
-    b, n = xg.shape
+    b, n = _rows_of_problem(xg, q_matrix, f"post-processor {method!r}")
     with torch.cuda.device(dev):
         prob = DeviceProblem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)

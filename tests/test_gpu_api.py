@@ -174,3 +174,22 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_engine():
     traj.advance(t)
     traj.clamp("c", -1.0, 1.0)
     assert c.shape == (b, n) and torch.equal(c.cpu(), traj.compact("c").cpu()) and torch.equal(s.cpu(), traj.compact("s").cpu())
+
+
+def test_post_processors_reject_mismatched_shapes():
+    """Reference unit tests test_postprocess_error_for_invalid_c_dimension / _invalid_v_vector_shape
+    (tests/unit/postprocessor/test_adam.py, test_grad_descent.py): any exception; here a ValueError
+    before anything reaches the GPU."""
+    from ccvm_amd.post_processor.factory import PostProcessorFactory
+
+    n, m = 12, 5
+    q, v, c = torch.rand(n, n), torch.rand(n), torch.rand(m, n)
+    for method in ("adam", "grad-descent"):
+        pp = PostProcessorFactory.create_postprocessor(method)
+        assert tuple(pp.postprocess(c, q, v).shape) == (m, n)
+        with pytest.raises(ValueError):
+            pp.postprocess(torch.rand(m, 9), q, v)
+        with pytest.raises(ValueError):
+            pp.postprocess(c, q, torch.rand(n, n))
+        with pytest.raises(TypeError, match="parameter c must be a tensor"):
+            pp.postprocess("dummy-c", q, v)
