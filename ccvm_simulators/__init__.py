@@ -31,7 +31,8 @@ _ALIASES = {
 for _name, _target in _ALIASES.items():
     _module = importlib.import_module(_target)
     sys.modules[f"{__name__}.{_name}"] = _module
-    if "." not in _name:
-        setattr(sys.modules[__name__], _name, _module)
+    # `import ccvm_simulators.a.b as m` binds through getattr(parent, "b"): set the attribute too
+    _parent, _, _child = _name.rpartition(".")
+    setattr(sys.modules[f"{__name__}.{_parent}"] if _parent else sys.modules[__name__], _child, _module)
 
 from ccvm_amd import __version__  # noqa: E402,F401

@@ -28,6 +28,17 @@ def test_reference_import_paths_resolve():
     import ccvm_amd.solvers as s
 
     assert DLSolver is s.DLSolver and ProblemInstance.__module__.startswith("ccvm_amd")
+    # the reference's per-class module paths, in both import spellings
+    import ccvm_simulators.post_processor.grad_descent as gd
+    import ccvm_simulators.problem_classes.boxqp.problem_instance as pi
+    import ccvm_simulators.solvers.dl_solver as dl
+    import ccvm_simulators.solvers.pumped_langevin_solver as pl
+    from ccvm_simulators.solvers.ccvm_solver import DeviceType  # noqa: F401
+    from ccvm_simulators.solvers.langevin_solver import LangevinSolver  # noqa: F401
+    from ccvm_simulators.solvers.mf_solver import MFSolver  # noqa: F401
+
+    assert dl.DLSolver is DLSolver and pl.PumpedLangevinSolver is s.PumpedLangevinSolver
+    assert pi.ProblemInstance is ProblemInstance and gd.PostProcessorGradDescent is not None
 
 
 def test_device_and_category_validation():
