@@ -282,7 +282,7 @@ def main():
                 "kernel": "ccvm::step_kernel<MODE_DL>" if kind == "dl" else "ccvm::step_kernel",
                 "avg_launch_us": kernel_ms * 1e3,
                 "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
-                             "sustains ~137 TFLOP/s on this chip (tools/ablate.hip)",
+                             "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip)",
                 "hbm_algorithmic_GBps": bytes_per_launch / (kernel_ms * 1e-3) / 1e9,
                 "hbm_frac": bytes_per_launch / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
