@@ -1,0 +1,18 @@
+"""Long fused-noise runs with odd chunking (developer tool): stays finite, per-step time holds."""
+import sys, time, torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+for kind, n, b, t in (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 300, 512, 20000), ("dl", 200, 256, 30000)):
+    traj, q, v = bench.make_trajectories(kind, n, b, t, 0)
+    t0 = time.time()
+    done = 0
+    while done < t:
+        k = min(7777, t - done)   # odd chunking on purpose
+        traj.advance(k); done += k
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    ok = all(bool(torch.isfinite(a).all()) for a in traj.state.values())
+    name = "mu" if kind == "mf" else "c"
+    x = traj.compact(name)
+    print(f"{kind} N={n} B={b} T={t}: {dt:.2f} s ({dt/t*1e6:.2f} us/step) finite={ok} |x|max={float(x.abs().max()):.4f} mean={float(x.mean()):.4f}", flush=True)
