@@ -299,6 +299,38 @@ def test_philox_normals_match_host_restatement_and_are_gaussian():
     assert abs(float((big0.double() * nxt.double()).mean())) < 4e-3
 
 
+def test_fused_generator_statistics():
+    """A stronger battery on the fused generator's output (2 M normals per stream): Kolmogorov-Smirnov
+    against N(0, 1), a 64-bin chi-square, tail mass, and lag correlations along rows, columns and
+    steps (the three coordinates of the counter / key)."""
+    import numpy as np
+    from scipy import stats
+
+    from ccvm_amd import engine
+
+    seed, b, n = 0x0123456789ABCDEF, 2048, 1024
+    w0, w1 = engine.philox_normals(seed, 0, 5, b, n, two=True)      # (N, B) blocks of step 5
+    single = engine.philox_normals(seed, 0, 5, b, n)                # one-stream view (rows share calls)
+    w0n, _ = engine.philox_normals(seed, 0, 6, b, n, two=True)      # next step
+    for w in (w0, w1, single):
+        x = w.double().cpu().numpy().ravel()
+        assert stats.kstest(x, "norm").pvalue > 1e-3
+        edges = stats.norm.ppf(np.linspace(0, 1, 65)[1:-1])
+        counts = np.bincount(np.searchsorted(edges, x), minlength=64)
+        assert stats.chisquare(counts).pvalue > 1e-3
+        tail = float((np.abs(x) > 3.0).mean())
+        assert abs(tail - 2.6998e-3) < 3e-4          # P(|z| > 3)
+        assert np.abs(x).max() < 6.5                  # 24-bit uniforms: |z| <= sqrt(2 ln 2^25) = 5.9
+    a = w0.double().cpu().numpy()                     # [col][row]
+    bound = 5.0 / np.sqrt(a.size)                     # 5 sigma of a sample correlation
+    for lagged in (a[:, 1:] * a[:, :-1], a[1:, :] * a[:-1, :], a[:, 2:] * a[:, :-2], a[2:, :] * a[:-2, :]):
+        assert abs(float(lagged.mean())) < bound      # adjacent / next-adjacent rows and columns
+    assert abs(float((a * w0n.double().cpu().numpy()).mean())) < bound      # consecutive steps
+    assert abs(float((a * w1.double().cpu().numpy()).mean())) < bound       # the two streams of an element
+    s1 = single.double().cpu().numpy()
+    assert abs(float((s1[:, 0::2] * s1[:, 1::2]).mean())) < 5.0 / np.sqrt(s1.size / 2)   # rows sharing a call
+
+
 # ------------------------------------------------------------------------------------------
 # C-ABI level invariances
 # ------------------------------------------------------------------------------------------
