@@ -59,9 +59,10 @@ ADAMS = {
 }
 
 
-def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED):
+def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0)):
     solver = SOLVERS[kind](device="cpu", batch_size=batch)
-    inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu")
+    inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu",
+                           solution_bounds=bounds)
     key = dict(PARAMS[kind], iterations=iterations)
     solver.parameter_key = {inst.problem_size: key}
     inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
@@ -78,7 +79,7 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     arrays["objective_values"] = sol.objective_values.detach().numpy().copy()
     meta = {
         "kind": kind, "iterations": iterations, "adam": ADAMS[adam] if adam else None, "post": post,
-        "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": key,
+        "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": key, "bounds": list(bounds),
         "best_objective_value": sol.best_objective_value,
         "solution_performance": sol.solution_performance,
         "scaled_by": float(inst.scaled_by),
@@ -103,10 +104,30 @@ def anchors():
     print("config 1", meta["best_objective_value"], meta["solution_performance"])
 
 
+def bounds_cases():
+    """Non-default solution_bounds (the affine maps (u - l), (u + l) of every drift / grads function)."""
+    store, manifest = {}, {"cases": {}}
+    for bounds in ((-0.5, 2.0), (1.0, 3.0)):
+        for kind in SOLVERS:
+            for adam in (None, "adamA") if kind != "dl" else (None,):
+                name = f"{kind}_T20_b{bounds[0]}_{bounds[1]}" + (f"_{adam}" if adam else "")
+                arrays, meta = run_case(kind, INSTANCES["test020"], 20, adam=adam, batch=40, bounds=bounds)
+                for k, v in arrays.items():
+                    store[f"{name}/{k}"] = v
+                manifest["cases"][name] = meta
+                print("bounds", name, meta["best_objective_value"])
+    np.savez_compressed(os.path.join(OUT, "test020_bounds.npz"), **store)
+    with open(os.path.join(OUT, "test020_bounds.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
     if "--only-anchors" in sys.argv:
         anchors()
+        return
+    if "--only-bounds" in sys.argv:
+        bounds_cases()
         return
     for tag, path in INSTANCES.items():
         inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu")
@@ -153,6 +174,7 @@ def main():
             json.dump(manifest, fh, indent=1, sort_keys=True)
 
     anchors()
+    bounds_cases()
 
 
 if __name__ == "__main__":

@@ -39,6 +39,17 @@ class Golden:
         return [k[len(prefix):] for k in self.arrays.files if k.startswith(prefix)]
 
 
+def bounds_cases():
+    """Cases of tests/golden/test020_bounds.{npz,json}: test020's instance with non-default
+    solution_bounds (made by make_golden.py --only-bounds from the reference)."""
+    with open(os.path.join(GOLDEN_DIR, "test020_bounds.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def bounds_arrays():
+    return np.load(os.path.join(GOLDEN_DIR, "test020_bounds.npz"))
+
+
 _cache = {}
 
 

@@ -29,11 +29,12 @@ def _solver_for(kind, batch, device="cpu"):
     return solver
 
 
-def _instance(g, device="cpu"):
+def _instance(g, device="cpu", bounds=(0.0, 1.0)):
     from ccvm_amd.problem_classes.boxqp import ProblemInstance
 
     inst = ProblemInstance.from_arrays(g.q(), g.v(), device=device, name=g.instance["name"],
-                                       optimal_sol=g.instance["optimal_sol"], best_sol=g.instance["best_sol"])
+                                       optimal_sol=g.instance["optimal_sol"], best_sol=g.instance["best_sol"],
+                                       solution_bounds=tuple(bounds))
     return inst
 
 
@@ -42,7 +43,7 @@ def _run_case(g, meta, device="cpu"):
 
     kind = meta["kind"]
     solver = _solver_for(kind, meta["batch"], device)
-    inst = _instance(g, device)
+    inst = _instance(g, device, meta.get("bounds", (0.0, 1.0)))
     solver.parameter_key = {inst.problem_size: dict(meta["params"])}
     inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
     kwargs = {}
@@ -88,6 +89,31 @@ def test_solver_matches_reference_golden(tag, case, kernel_path):
     slack = (2.0 if meta["post"] else 1.0) / meta["batch"] + 1e-9
     for key, frac in meta["solution_performance"].items():
         assert abs(sol.solution_performance[key] - frac) <= slack, (key, sol.solution_performance, frac)
+
+
+def _bounds_case_names():
+    from golden_util import bounds_cases
+
+    return sorted(bounds_cases())
+
+
+@pytest.mark.parametrize("case", _bounds_case_names())
+def test_solver_matches_reference_with_other_bounds(case, kernel_path):
+    """solution_bounds (-0.5, 2) and (1, 3): the folded affine input map has a non-trivial scale AND shift."""
+    from golden_util import bounds_arrays, bounds_cases
+
+    g, meta, arrays = golden("test020"), bounds_cases()[case], bounds_arrays()
+    sol = _run_case(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        tol = ATOL_OBJ * max(1.0, float(want.abs().max()) / 150.0) if field == "objective_values" else ATOL_X * max(
+            1.0, float(want.abs().max()))
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol, f"{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
 
 
 def test_dl_example_anchor():

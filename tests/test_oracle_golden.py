@@ -9,7 +9,7 @@ differently still passes, and far tighter than the GPU parity tolerance.
 import pytest
 import torch
 
-from golden_util import all_cases, check_noise_checksum, golden
+from golden_util import all_cases, bounds_arrays, bounds_cases, check_noise_checksum, golden
 from oracle import ccvm_oracle as oracle
 
 ATOL_STATE = 1e-5
@@ -19,7 +19,7 @@ RTOL_OBJ = 1e-5
 def run_oracle(g, meta):
     kind, p = meta["kind"], meta["params"]
     q, v, f = g.scaled(kind)
-    common = dict(bounds=(0.0, 1.0), scaled_by=f, optimal_value=g.instance["optimal_sol"],
+    common = dict(bounds=tuple(meta.get("bounds", (0.0, 1.0))), scaled_by=f, optimal_value=g.instance["optimal_sol"],
                   post_processor=meta["post"])
     b, t = meta["batch"], meta["iterations"]
     torch.manual_seed(meta["seed"])
@@ -57,6 +57,23 @@ def test_oracle_reproduces_reference(tag, case):
         meta["best_objective_value"]) + 1e-6
     for key, frac in meta["solution_performance"].items():
         assert abs(out["solution_performance"][key] - frac) <= 1.0 / meta["batch"] + 1e-9
+
+
+@pytest.mark.parametrize("case", sorted(bounds_cases()))
+def test_oracle_reproduces_reference_with_other_bounds(case):
+    """solution_bounds other than (0, 1): the (u - l), (u + l) maps of every drift / grads function."""
+    g, meta, arrays = golden("test020"), bounds_cases()[case], bounds_arrays()
+    assert tuple(meta["bounds"]) != (0.0, 1.0)
+    out = run_oracle(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        tol = (RTOL_OBJ if field == "objective_values" else ATOL_STATE) * max(1.0, float(want.abs().max()))
+        assert float((out[field] - want).abs().max()) <= tol, f"{case}/{field}"
+    assert abs(out["best_objective_value"] - meta["best_objective_value"]) <= RTOL_OBJ * abs(
+        meta["best_objective_value"]) + 1e-6
 
 
 def test_oracle_reproduces_baseline_config_1():
