@@ -59,8 +59,9 @@ ADAMS = {
 }
 
 
-def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0)):
-    solver = SOLVERS[kind](device="cpu", batch_size=batch)
+def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0),
+             dl_S=None):
+    solver = SOLVERS[kind](device="cpu", batch_size=batch, **({"S": dl_S} if dl_S is not None else {}))
     inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu",
                            solution_bounds=bounds)
     key = dict(PARAMS[kind], iterations=iterations)
@@ -80,6 +81,7 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     meta = {
         "kind": kind, "iterations": iterations, "adam": ADAMS[adam] if adam else None, "post": post,
         "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": key, "bounds": list(bounds),
+        "dl_S": dl_S,
         "best_objective_value": sol.best_objective_value,
         "solution_performance": sol.solution_performance,
         "scaled_by": float(inst.scaled_by),
@@ -116,6 +118,16 @@ def bounds_cases():
                     store[f"{name}/{k}"] = v
                 manifest["cases"][name] = meta
                 print("bounds", name, meta["best_objective_value"])
+    # DLSolver(S=...): the saturation of the constructor only enters the final clamp and the change of
+    # variables (dl_solver.py:567, 219-235) -- the drift ignores it
+    for dl_S in (2.0, 0.5):
+        for post in (None, "grad-descent"):
+            name = f"dl_T50_S{dl_S}" + (f"_{post}" if post else "")
+            arrays, meta = run_case("dl", INSTANCES["test020"], 50, post=post, batch=40, dl_S=dl_S)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print("S", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_bounds.npz"), **store)
     with open(os.path.join(OUT, "test020_bounds.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)

@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 ATOL_X, ATOL_OBJ = 5e-4, 2e-3
 
 
-def _solver_for(kind, batch, device="cpu"):
+def _solver_for(kind, batch, device="cpu", dl_S=None):
     from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
 
     cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
-    solver = cls(device=device, batch_size=batch)
+    solver = cls(device=device, batch_size=batch, **({"S": dl_S} if dl_S is not None else {}))
     solver.noise_mode = "replay"
     return solver
 
@@ -42,7 +42,7 @@ def _run_case(g, meta, device="cpu"):
     from ccvm_amd.solvers.algorithms import AdamParameters
 
     kind = meta["kind"]
-    solver = _solver_for(kind, meta["batch"], device)
+    solver = _solver_for(kind, meta["batch"], device, meta.get("dl_S"))
     inst = _instance(g, device, meta.get("bounds", (0.0, 1.0)))
     solver.parameter_key = {inst.problem_size: dict(meta["params"])}
     inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
@@ -99,7 +99,8 @@ def _bounds_case_names():
 
 @pytest.mark.parametrize("case", _bounds_case_names())
 def test_solver_matches_reference_with_other_bounds(case, kernel_path):
-    """solution_bounds (-0.5, 2) and (1, 3): the folded affine input map has a non-trivial scale AND shift."""
+    """solution_bounds (-0.5, 2) and (1, 3): the folded affine input map has a non-trivial scale AND shift;
+    DLSolver(S=2.0 / 0.5): the constructor's saturation in the final clamp and the change of variables."""
     from golden_util import bounds_arrays, bounds_cases
 
     g, meta, arrays = golden("test020"), bounds_cases()[case], bounds_arrays()
