@@ -32,12 +32,14 @@ def _cases(count=96, seed=20240607):
         cuts = sorted(rng.sample(range(1, t), min(t - 1, rng.choice([0, 1, 2])))) if t > 1 else []
         replay = rng.random() < 0.3  # parity mode: torch's CPU stream in the reference's order
         bounds = rng.choice([(0.0, 1.0), (0.0, 1.0), (-1.0, 1.0), (-0.5, 2.0), (1.0, 3.0)])  # solution_bounds
-        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, bounds))
+        g = rng.choice([None, None, 0.1, 0.002])      # __call__(g=...) of DL / MF
+        ramp = rng.random() < 0.7                     # pump_rate_flag
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, bounds, g, ramp))
     return out
 
 
-@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds", _cases())
-def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds):
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp", _cases())
+def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp):
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
     from oracle import ccvm_oracle as oracle
@@ -56,21 +58,23 @@ def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts
         ref_noise = FusedNoise(seed, offset, single=kind != "dl")
     prob = engine.DeviceProblem(q, v)
     if kind == "dl":
-        traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), bounds, noise)
-        c, s = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05,
-                              bounds, True, ref_noise)
+        g = 0.05 if g is None else g
+        traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=g, pump_rate_flag=ramp), bounds, noise)
+        c, s = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], g,
+                              bounds, ramp, ref_noise)
         want = {"c": c, "s": s}
     elif kind == "mf":
-        traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=0.01), bounds, noise, adam=adam)
+        g = 0.01 if g is None else g
+        traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=g, pump_rate_flag=ramp), bounds, noise, adam=adam)
         mu, mu_tilde, sigma = oracle.mf_loop(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"],
-                                             0.01, bounds, True, adam, ref_noise)
+                                             g, bounds, ramp, adam, ref_noise)
         want = {"mu": mu, "sigma": sigma, "mu_tilde": mu_tilde}
     else:
-        traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl"), bounds, noise,
-                                   adam=adam)
+        traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl", pump_rate_flag=ramp),
+                                   bounds, noise, adam=adam)
         if kind == "pl":
             c = oracle.pl_loop(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds,
-                               True, adam, ref_noise)
+                               ramp, adam, ref_noise)
         else:
             c = oracle.langevin_loop(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds, adam,
                                      ref_noise)
@@ -87,7 +91,7 @@ def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts
         scale = max(1.0, float(ref.abs().max()))
         err = float((got - ref).abs().max())
         assert err <= gate * scale, (f"{kind} N={n} B={b} T={t} adam={adam_i} offset={offset} cuts={cuts} "
-                                     f"replay={replay} bounds={bounds} {name}: {err:.3e}")
+                                     f"replay={replay} bounds={bounds} g={g} ramp={ramp} {name}: {err:.3e}")
     for name, arr in traj.state.items():  # padding stays zero
         assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
         assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
