@@ -76,8 +76,11 @@ struct AdamScalars {
     int add_assign;
 };
 
+// torch.clamp semantics: NaN propagates (fminf / fmaxf would turn a diverged amplitude into a bound
+// and hide the divergence the reference reports as NaN objective values).
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
-    return fminf(fmaxf(x, lo), hi);
+    const float c = fminf(fmaxf(x, lo), hi);
+    return x != x ? x : c;
 }
 
 // ---- per-element updates ---------------------------------------------------------------

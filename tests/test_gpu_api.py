@@ -193,3 +193,35 @@ def test_post_processors_reject_mismatched_shapes():
             pp.postprocess(c, q, torch.rand(n, n))
         with pytest.raises(TypeError, match="parameter c must be a tensor"):
             pp.postprocess("dummy-c", q, v)
+
+
+def test_diverged_runs_report_nan_like_the_reference():
+    """The README snippet's parameters (pump 2.0, dt 0.005) with feedback_scale 100 diverge (SURVEY.md 8d,
+    config 1 note): the reference's amplitudes become NaN and torch.clamp keeps them NaN, so the
+    objective values are NaN.  The engine must not turn them into bounds and report finite garbage."""
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import scaled_qv
+    from oracle import ccvm_oracle as oracle
+    from oracle.noise_ref import FusedNoise
+
+    n, b, t, seed = 20, 64, 400, 99
+    q, v, f = scaled_qv(n, "dl")
+    p = {"pump": 2.0, "dt": 0.005, "noise_ratio": 10, "feedback_scale": 100}
+    c, _ = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05, (0.0, 1.0),
+                          True, FusedNoise(seed, 0, single=False))
+    want = int(torch.isnan(torch.clamp(c, -1, 1)).any(1).sum())
+    assert want > 10  # the configuration does diverge
+    for path in ("persist", "tile"):
+        os.environ["CCVM_AMD_KERNEL"] = path
+        try:
+            traj = engine.Trajectories(engine.DeviceProblem(q, v), b, "dl", t, dict(p, g=0.05), (0.0, 1.0),
+                                       engine.NoiseSpec(mode="philox", seed=seed))
+            traj.advance(t)
+            traj.clamp("c", -1.0, 1.0)
+            x = traj.compact("c")
+            got = int(torch.isnan(x).any(1).sum())
+            assert abs(got - want) <= 6, (path, got, want)  # which rows blow up is chaotic at the margin
+            obj = engine.energy(engine.change_variables(x, 1.0, 0.0, 1.0), q, v, float(f))
+            assert int(torch.isnan(obj).sum()) == got
+        finally:
+            os.environ.pop("CCVM_AMD_KERNEL", None)
