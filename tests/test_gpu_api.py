@@ -225,3 +225,49 @@ def test_diverged_runs_report_nan_like_the_reference():
             assert int(torch.isnan(obj).sum()) == got
         finally:
             os.environ.pop("CCVM_AMD_KERNEL", None)
+
+
+def test_concurrent_host_threads_on_their_own_streams():
+    """No global mutable state in the library (include/ccvm_hip.h): four host threads, each on its own
+    HIP stream, run different solves at the same time; every result equals the same solve run alone."""
+    import threading
+
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    jobs = [("dl", 40, 96, 60), ("mf", 130, 64, 40), ("langevin", 300, 128, 25), ("dl", 20, 200, 80)]
+
+    def solve(kind, n, b, t, stream=None):
+        q, v, _ = scaled_qv(n, "pl" if kind == "langevin" else kind)
+        p = dict(EXAMPLE_PARAMS["pl" if kind == "langevin" else kind], g=0.03, use_pump=True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            traj = engine.Trajectories(engine.DeviceProblem(q, v), b, kind, t, p, (0.0, 1.0),
+                                       engine.NoiseSpec(mode="philox", seed=1000 + n))
+            for _ in range(t // 5):
+                traj.advance(5)
+            out = {k: traj.compact(k) for k in traj.state}
+        if stream is not None:
+            stream.synchronize()
+        else:
+            torch.cuda.synchronize()
+        return {k: x.cpu() for k, x in out.items()}
+
+    alone = [solve(*job) for job in jobs]
+    results, errors = [None] * len(jobs), []
+
+    def worker(i):
+        try:
+            results[i] = solve(*jobs[i], stream=torch.cuda.Stream())
+        except Exception as exc:  # surfaced below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for want, got in zip(alone, results):
+        for key in want:
+            assert torch.equal(want[key], got[key]), key
