@@ -230,6 +230,34 @@ class DeviceProblem:
             self.v = pack(v_vector.detach().to(self.device), 1, self.ld).reshape(-1)
 
 
+_problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device index, DeviceProblem, ready event)
+
+
+def device_problem(q_matrix, v_vector):
+    """``DeviceProblem(q, v)``, reused while the SAME tensor objects are passed unmodified: a solver
+    call stages Q for the loop, again for the energy evaluation and again for a post-processor
+    (3 x 16 MB at N = 2000), and benchmark loops solve one instance many times.  Identity is the
+    Python object (weak reference) plus torch's in-place version counter, so a new tensor that
+    happens to reuse the address, or an in-place edit, is never served a stale copy."""
+    import weakref
+
+    dev = gpu_device()
+    for entry in _problem_cache:
+        wq, wv, qver, vver, index, prob, ready = entry
+        if wq() is q_matrix and wv() is v_vector and qver == q_matrix._version and vver == v_vector._version \
+                and index == dev.index:
+            torch.cuda.current_stream(dev).wait_event(ready)  # staged on another stream, perhaps
+            return prob
+    prob = DeviceProblem(q_matrix, v_vector)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    _problem_cache.append((weakref.ref(q_matrix), weakref.ref(v_vector), q_matrix._version, v_vector._version,
+                           dev.index, prob, ready))
+    while len(_problem_cache) > 4:
+        _problem_cache.pop(0)
+    return prob
+
+
 def _adam_struct(adam, m, v):
     st = _lib.Adam()
     if adam is None:
@@ -394,7 +422,7 @@ def feedback(x, q_matrix, v_vector, in_scale, in_shift, f_q, f_v):
     xg, dev = _to_gpu(x)
     b, n = _rows_of_problem(xg, q_matrix, "feedback")
     with torch.cuda.device(dev):
-        prob = DeviceProblem(q_matrix, v_vector)
+        prob = device_problem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
         yp = torch.zeros_like(xp)
         ws = torch.empty((max(lib.ccvm_workspace_bytes(_lib.WS_FEEDBACK, b, n), 16),), dtype=torch.uint8, device=dev)
@@ -412,7 +440,7 @@ def energy(confs, q_matrix, v_vector, scaled_by=1.0):
     xg, dev = _to_gpu(confs)
     b, n = _rows_of_problem(xg, q_matrix, "energy")
     with torch.cuda.device(dev):
-        prob = DeviceProblem(q_matrix, v_vector)
+        prob = device_problem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
         obj = torch.empty((b,), dtype=torch.float32, device=dev)
         ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_ENERGY, b, n)
@@ -432,7 +460,7 @@ def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, s
     xg, dev = _to_gpu(x)
     b, n = _rows_of_problem(xg, q_matrix, f"post-processor {method!r}")
     with torch.cuda.device(dev):
-        prob = DeviceProblem(q_matrix, v_vector)
+        prob = device_problem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
         ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_POSTPROCESS, b, n)
         ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)

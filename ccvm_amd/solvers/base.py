@@ -210,7 +210,7 @@ class CCVMSolver(ABC):
 
     def _new_trajectories(self, kind, batch_size, iterations, params, adam=None):
         self._require_fused_hooks()
-        problem = engine.DeviceProblem(self.q_matrix, self.v_vector)
+        problem = engine.device_problem(self.q_matrix, self.v_vector)
         noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset, seed=self.noise_seed)
         return engine.Trajectories(
             problem, batch_size, kind, iterations, params, self.solution_bounds, noise, adam=adam

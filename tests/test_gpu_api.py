@@ -271,3 +271,19 @@ def test_concurrent_host_threads_on_their_own_streams():
     for want, got in zip(alone, results):
         for key in want:
             assert torch.equal(want[key], got[key]), key
+
+
+def test_staged_problem_cache_never_serves_stale_data():
+    from ccvm_amd import engine
+
+    q, v, x = torch.rand(12, 12), torch.rand(12), torch.rand(7, 12)
+    first = engine.device_problem(q, v)
+    assert engine.device_problem(q, v) is first                     # same objects, unmodified: reused
+    e1 = engine.energy(x, q, v)
+    q.mul_(2.0)                                                     # in-place edit: version counter moves
+    assert engine.device_problem(q, v) is not first
+    e2 = engine.energy(x, q, v)
+    want = (0.5 * torch.einsum("bi,ij,bj->b", x, q, x) + x @ v)
+    assert torch.allclose(e2, want, rtol=1e-5, atol=1e-5) and not torch.allclose(e1, e2)
+    q2 = q.clone()                                                  # equal values, different object
+    assert engine.device_problem(q2, v) is not engine.device_problem(q, v)
