@@ -1,7 +1,10 @@
 """Seeded random sweep of the engine against the oracle (fused generator): awkward problem sizes
 (around every tile / shape boundary), tiny and ragged batches, odd shard offsets, random chunking,
-every solver and Adam variant.  One process, ~50 cases, each finishes in well under a second."""
+every solver and Adam variant, fused and replayed noise, non-default bounds / g / pump ramp.  One
+process, 96 cases by default (CCVM_FUZZ_SEED / CCVM_FUZZ_COUNT select another sweep), each finishes
+in well under a second."""
 import math
+import os
 import random
 
 import pytest
@@ -19,7 +22,7 @@ ADAMS = [None,
 ATOL_X = 5e-4
 
 
-def _cases(count=96, seed=20240607):
+def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "96")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
     rng = random.Random(seed)
     out = []
     for _ in range(count):
