@@ -38,6 +38,32 @@ __global__ __launch_bounds__(64) void kb(float* out, int n, float x) {
     for (int p = 0; p < 4; ++p) s += acc[p][0] + acc[p][1] + acc[p][2] + acc[p][3];
     if (threadIdx.x == 0) { out[blockIdx.x * 2] = (float)(t1 - t0); out[blockIdx.x * 2 + 1] = s; }
 }
+// NV independent VALU instructions (integer add / rotate / xor, as the generator's) after every MFMA:
+// does a wave that is alone on its SIMD overlap them with the matrix pipe?
+template <int NV>
+__global__ __launch_bounds__(64) void kmix(float* out, int n, float x) {
+    f4 acc[4];
+    for (int p = 0; p < 4; ++p) acc[p] = f4{0, 0, 0, 0};
+    float a = x + threadIdx.x, b = x - threadIdx.x;
+    unsigned u0 = threadIdx.x * 2654435761u, u1 = threadIdx.x + 12345u, u2 = u0 ^ 77u, u3 = u1 + 99u;
+    long long t0 = clock64();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            acc[m & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {  // four independent chains: add, rotate, xor
+                unsigned& w = (v & 3) == 0 ? u0 : (v & 3) == 1 ? u1 : (v & 3) == 2 ? u2 : u3;
+                w = (v % 3 == 0) ? w + 0x9E3779B9u : (v % 3 == 1) ? __builtin_amdgcn_alignbit(w, w, 19) : (w ^ (unsigned)m);
+                asm volatile("" : "+v"(w));
+            }
+        }
+    }
+    long long t1 = clock64();
+    float s = (float)(u0 ^ u1 ^ u2 ^ u3);
+    for (int p = 0; p < 4; ++p) s += acc[p][0] + acc[p][1] + acc[p][2] + acc[p][3];
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = (float)(t1 - t0); out[blockIdx.x * 2 + 1] = s; }
+}
 template <int NACC>
 __global__ __launch_bounds__(64) void k16(float* out, int n, float x) {
     f4 acc[NACC];
@@ -74,6 +100,7 @@ int main() {
     float* d; hipMalloc(&d, 2048 * 8);
     run("4x4x1 NACC=1", k4<1>, d); run("4x4x1 NACC=2", k4<2>, d); run("4x4x1 NACC=4", k4<4>, d); run("4x4x1 NACC=8", k4<8>, d);
     run("4x4x1 cbsz=4 abid=k", kb<4>, d);
+    run("4x4x1 + 0 VALU per MFMA", kmix<0>, d); run("4x4x1 + 1 VALU per MFMA", kmix<1>, d); run("4x4x1 + 2 VALU per MFMA", kmix<2>, d); run("4x4x1 + 4 VALU per MFMA", kmix<4>, d);
     run("16x16x4 NACC=1", k16<1>, d); run("16x16x4 NACC=2", k16<2>, d); run("16x16x4 NACC=4", k16<4>, d);
     return 0;
 }
