@@ -60,11 +60,17 @@ ADAMS = {
 
 
 def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0),
-             dl_S=None):
+             dl_S=None, s_vector=None):
+    """``s_vector``: per-variable saturation (1-D tensor of length N) -- DL takes it in the constructor,
+    the other solvers in the parameter key, scaled to the magnitude of their scalar default."""
+    if kind == "dl" and s_vector is not None:
+        dl_S = s_vector
     solver = SOLVERS[kind](device="cpu", batch_size=batch, **({"S": dl_S} if dl_S is not None else {}))
     inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu",
                            solution_bounds=bounds)
     key = dict(PARAMS[kind], iterations=iterations)
+    if kind != "dl" and s_vector is not None:
+        key["S"] = s_vector * PARAMS[kind]["S"]
     solver.parameter_key = {inst.problem_size: key}
     inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
     kwargs = {}
@@ -78,10 +84,11 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     sol = solver(instance=inst, post_processor=post, **kwargs)
     arrays = {k: v.detach().numpy().copy() for k, v in sol.variables.items()}
     arrays["objective_values"] = sol.objective_values.detach().numpy().copy()
+    params_out = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in key.items()}
     meta = {
         "kind": kind, "iterations": iterations, "adam": ADAMS[adam] if adam else None, "post": post,
-        "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": key, "bounds": list(bounds),
-        "dl_S": dl_S,
+        "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": params_out, "bounds": list(bounds),
+        "dl_S": dl_S.tolist() if torch.is_tensor(dl_S) else dl_S,
         "best_objective_value": sol.best_objective_value,
         "solution_performance": sol.solution_performance,
         "scaled_by": float(inst.scaled_by),
@@ -133,8 +140,31 @@ def bounds_cases():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
+def vector_s_cases():
+    """Per-variable saturation S (a 1-D tensor of length N; dl_solver.py:843-848, mf_solver.py:834-839,
+    langevin_solver.py:630-635, pumped_langevin_solver.py:519-524)."""
+    store, manifest = {}, {"cases": {}}
+    g = torch.Generator().manual_seed(5)
+    s_vector = 0.5 + 1.5 * torch.rand(20, generator=g)  # x the solver's scalar default
+    for kind in SOLVERS:
+        variants = [(None, None), (None, "grad-descent")] + ([("adamA", None), ("adamC", None)] if kind != "dl" else [])
+        for adam, post in variants:
+            name = f"{kind}_T30_vecS" + (f"_{adam}" if adam else "") + (f"_{post}" if post else "")
+            arrays, meta = run_case(kind, INSTANCES["test020"], 30, adam=adam, post=post, batch=40, s_vector=s_vector)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print("vecS", name, meta["best_objective_value"])
+    np.savez_compressed(os.path.join(OUT, "test020_vecS.npz"), **store)
+    with open(os.path.join(OUT, "test020_vecS.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
+    if "--only-vector-s" in sys.argv:
+        vector_s_cases()
+        return
     if "--only-anchors" in sys.argv:
         anchors()
         return
@@ -187,6 +217,7 @@ def main():
 
     anchors()
     bounds_cases()
+    vector_s_cases()
 
 
 if __name__ == "__main__":

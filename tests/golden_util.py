@@ -50,6 +50,17 @@ def bounds_arrays():
     return np.load(os.path.join(GOLDEN_DIR, "test020_bounds.npz"))
 
 
+def vector_s_cases():
+    """Cases of tests/golden/test020_vecS.{npz,json}: per-variable saturation S (1-D tensor of length N),
+    made by make_golden.py --only-vector-s from the reference."""
+    with open(os.path.join(GOLDEN_DIR, "test020_vecS.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def vector_s_arrays():
+    return np.load(os.path.join(GOLDEN_DIR, "test020_vecS.npz"))
+
+
 _cache = {}
 
 

@@ -9,15 +9,23 @@ differently still passes, and far tighter than the GPU parity tolerance.
 import pytest
 import torch
 
-from golden_util import all_cases, bounds_arrays, bounds_cases, check_noise_checksum, golden
+from golden_util import (all_cases, bounds_arrays, bounds_cases, check_noise_checksum, golden, vector_s_arrays,
+                         vector_s_cases)
 from oracle import ccvm_oracle as oracle
 
 ATOL_STATE = 1e-5
 RTOL_OBJ = 1e-5
 
 
+def _saturation(value):
+    """Scalar S, or the per-variable S of the vector-S fixtures as a float32 tensor."""
+    return torch.tensor(value, dtype=torch.float32) if isinstance(value, list) else value
+
+
 def run_oracle(g, meta):
-    kind, p = meta["kind"], meta["params"]
+    kind, p = meta["kind"], dict(meta["params"])
+    if "S" in p:
+        p["S"] = _saturation(p["S"])
     q, v, f = g.scaled(kind)
     common = dict(bounds=tuple(meta.get("bounds", (0.0, 1.0))), scaled_by=f, optimal_value=g.instance["optimal_sol"],
                   post_processor=meta["post"])
@@ -25,7 +33,8 @@ def run_oracle(g, meta):
     torch.manual_seed(meta["seed"])
     if kind == "dl":
         return oracle.solve_dl(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"],
-                               g=0.05, S=meta.get("dl_S") or 1, pump_rate_flag=meta["pump_rate_flag"], **common)
+                               g=0.05, S=_saturation(meta.get("dl_S")) if meta.get("dl_S") is not None else 1,
+                               pump_rate_flag=meta["pump_rate_flag"], **common)
     if kind == "mf":
         return oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01,
                                pump_rate_flag=meta["pump_rate_flag"], adam=meta["adam"], **common)
@@ -64,6 +73,22 @@ def test_oracle_reproduces_reference_with_other_bounds(case):
     """solution_bounds other than (0, 1): the (u - l), (u + l) maps of every drift / grads function."""
     g, meta, arrays = golden("test020"), bounds_cases()[case], bounds_arrays()
     assert tuple(meta["bounds"]) != (0.0, 1.0) or meta["dl_S"] is not None
+    out = run_oracle(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        tol = (RTOL_OBJ if field == "objective_values" else ATOL_STATE) * max(1.0, float(want.abs().max()))
+        assert float((out[field] - want).abs().max()) <= tol, f"{case}/{field}"
+    assert abs(out["best_objective_value"] - meta["best_objective_value"]) <= RTOL_OBJ * abs(
+        meta["best_objective_value"]) + 1e-6
+
+
+@pytest.mark.parametrize("case", sorted(vector_s_cases()))
+def test_oracle_reproduces_reference_with_per_variable_saturation(case):
+    """S given as a 1-D tensor of length N (dl_solver.py:843-848 and the same lines of the other solvers)."""
+    g, meta, arrays = golden("test020"), vector_s_cases()[case], vector_s_arrays()
     out = run_oracle(g, meta)
     for key in arrays.files:
         if not key.startswith(case + "/"):
