@@ -22,7 +22,7 @@ from ctypes import (
 
 LIB_NAME = "libccvm_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -88,6 +88,7 @@ class MfParams(Structure):
         ("upper", c_double),
         ("pump_rate_flag", c_int32),
         ("reserved", c_int32),
+        ("s_cols", c_void_p),
     ]
 
 
@@ -102,6 +103,7 @@ class LangevinParams(Structure):
         ("upper", c_double),
         ("use_pump", c_int32),
         ("pump_rate_flag", c_int32),
+        ("s_cols", c_void_p),
     ]
 
 
@@ -117,6 +119,7 @@ SIGNATURES = {
     "ccvm_pack": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "ccvm_unpack": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "ccvm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ccvm_workspace_bytes_cols": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_dl_run": (
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -134,6 +137,8 @@ SIGNATURES = {
     ),
     "ccvm_clamp": (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P]),
     "ccvm_change_variables": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
+    "ccvm_clamp_cols": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "ccvm_change_variables_cols": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P]),
     "ccvm_energy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
     "ccvm_feedback": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, c_size_t, _P]

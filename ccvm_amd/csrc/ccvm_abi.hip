@@ -131,6 +131,16 @@ int compute_qsum(const float* Q, int N, int ld, float* area, hipStream_t st, con
     return CCVM_OK;
 }
 
+// Per-variable saturation: the row-scaled copy Qs[k][j] = Q[k][j] / S_k at the end of the workspace.
+const float* scaled_rows(const float* Q, const float* s_cols, int N, int ld, void* ws, size_t base_bytes,
+                         hipStream_t st) {
+    float* qs = reinterpret_cast<float*>(static_cast<char*>(ws) + base_bytes);
+    const size_t total = (size_t)ld * ld;
+    size_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, Q, s_cols, qs, N, ld);
+    return qs;
+}
+
 void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N, bool two, bool next) {
     a.step = i;
     a.seed = nz->seed;
@@ -227,6 +237,12 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
         case 5: return qs;                               // ccvm_feedback
         default: return 0;
     }
+}
+
+size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
+    const size_t ld = (size_t)ccvm_ld(N);
+    const size_t base = ccvm_workspace_bytes(solver, B, N);
+    return (solver == 1 || solver == 2) ? base + ld * ld * sizeof(float) : base;
 }
 
 int ccvm_pack(const float* src, int rows, int cols, int src_ld, float* dst, int dst_rows, int dst_ld,
@@ -349,9 +365,15 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if ((rc = check_adam(fn, adam))) return rc;
     if (!aligned16(Q) || !aligned16(mu) || !aligned16(sigma) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, mu, sigma and workspace must be 16-byte aligned", fn);
-    if (ws_bytes < ccvm_workspace_bytes(1, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
-    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->S > 0) || !(p->j > 0))
+    const float* s_cols = p->s_cols;
+    if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(1, B, N) : ccvm_workspace_bytes(1, B, N)))
+        return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || p->S > 0) || !(p->j > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0, j > 0", fn);
+    if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
+    // per-variable saturation: every 1 / S factor of the scalars is left out (S_eff = 1) and applied per
+    // column -- 1 / S_k of the input map through the row-scaled copy Qs, 1 / S_j in the epilogue
+    const double S_eff = s_cols ? 1.0 : p->S;
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
@@ -369,15 +391,17 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
-        pa.Q = Q; pa.V = V; pa.qsum = qsum; pa.x0 = mu; pa.x1 = sigma; pa.xt = mu_tilde_out; pa.table = table;
+        pa.Q = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        pa.V = V; pa.qsum = qsum; pa.x0 = mu; pa.x1 = sigma; pa.xt = mu_tilde_out; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = replay;
-        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / p->S); pa.in_shift = (float)up;
-        pa.S = (float)p->S;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
+        pa.S = (float)S_eff;
+        pa.s_cols = s_cols;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
-            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, p->S, ul, p->pump_rate_flag, T, step0 + done, k, asc};
+            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
             hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
             pa.step0 = step0 + done;
             pa.nsteps = k;
@@ -398,15 +422,19 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     {
         const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(step0))) / sdt);
         hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], carry, B, N,
-                           ld, k0, (float)p->S, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
+                           ld, k0, (float)S_eff, s_cols, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
         CCVM_CHECK_LAUNCH(fn);
     }
 
     StepArgs a;
     base_args(a, Q, V, B, N, ld);
-    a.in_scale = (float)(ul / p->S);
+    a.in_scale = (float)(ul / S_eff);
     a.in_shift = (float)up;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum))) return rc;
+    if (s_cols) {
+        a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st);
+        a.s_cols = s_cols;
+    }
     a.carry = carry;
     a.st0 = mu;
     a.st1 = sigma;
@@ -423,15 +451,15 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         MfScalars& k = a.s.mf;
         k.a0 = (float)(-(1.0 + j_i) + p_i);
         k.g2 = (float)(p->g * p->g);
-        k.f_q = (float)(-p->feedback_scale * 0.25 * ul / p->S);
-        k.f_v = (float)(-p->feedback_scale * ul / (2.0 * p->S));
+        k.f_q = (float)(-p->feedback_scale * 0.25 * ul / S_eff);
+        k.f_v = (float)(-p->feedback_scale * ul / (2.0 * S_eff));
         k.j_i = (float)j_i;
         k.one_j = (float)(1.0 + j_i);
         k.sqrt_j = (float)std::sqrt(j_i);
         k.inv_sdt = (float)(1.0 / sdt);
         k.dt = (float)p->dt;
         k.k_next = has_next ? (float)(std::sqrt(1.0 / (4.0 * j_at(i + 1))) / sdt) : 0.0f;
-        k.S = (float)p->S;
+        k.S = (float)S_eff;
         k.has_next = has_next;
         if (use_adam) fill_adam(a.ad, adam, i);
         a.a0 = mt[cur];
@@ -460,9 +488,13 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if ((rc = check_adam(fn, adam))) return rc;
     if (!aligned16(Q) || !aligned16(c) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, c and workspace must be 16-byte aligned", fn);
-    if (ws_bytes < ccvm_workspace_bytes(2, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
-    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->S > 0))
+    const float* s_cols = p->s_cols;
+    if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(2, B, N) : ccvm_workspace_bytes(2, B, N)))
+        return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || p->S > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0", fn);
+    if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
+    const double S_eff = s_cols ? 1.0 : p->S;  // see ccvm_mf_run
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
@@ -475,21 +507,25 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     StepArgs a;
     base_args(a, Q, V, B, N, ld);
-    a.in_scale = (float)(ul / (2.0 * p->S));  // langevin_solver.py:133
+    a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
+    if (s_cols) {
+        a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(2, B, N), st);
+        a.s_cols = s_cols;
+    }
     if (want_persist(N)) {
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
-        pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table;
+        pa.Q = a.Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table; pa.s_cols = s_cols;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
-            LvSched sc{p->dt, p->sigma, p->feedback_scale, p->S, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
+            LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
             hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
             pa.step0 = step0 + done;
@@ -508,14 +544,14 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     int cur = 0;
     for (int i = step0; i < step0 + nsteps; ++i) {
         LvScalars& k = a.s.lv;
-        k.g_q = (float)(-ul / (2.0 * p->S));
+        k.g_q = (float)(-ul / (2.0 * S_eff));
         k.g_v = k.g_q;
         const double p_i = p->pump_rate_flag ? p->pump * (double)(i + 1) / (double)T : p->pump;  // pl:279-282
         k.pm = (float)(-1.0 + p_i);
         k.dt = (float)p->dt;
         k.dt_fs = (float)(p->dt * p->feedback_scale);
         k.w = (float)(p->sigma * std::sqrt(p->dt));
-        k.S = (float)p->S;
+        k.S = (float)S_eff;
         k.use_pump = p->use_pump;
         if (use_adam) fill_adam(a.ad, adam, i);
         a.a0 = buf[cur];
@@ -539,6 +575,27 @@ int ccvm_clamp(float* x, int B, int N, int ld, float lo, float hi, void* stream)
     hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream, x, B, N, ld,
                        lo, hi);
     CCVM_CHECK_LAUNCH("ccvm_clamp");
+    return CCVM_OK;
+}
+
+int ccvm_clamp_cols(float* x, int B, int N, int ld, const float* s_cols, void* stream) {
+    int rc;
+    if (!x || !s_cols) return fail(CCVM_E_INVALID, "ccvm_clamp_cols: NULL argument");
+    if ((rc = check_layout("ccvm_clamp_cols", B, N, ld))) return rc;
+    hipLaunchKernelGGL(clamp_cols_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream, x, B, N,
+                       ld, s_cols);
+    CCVM_CHECK_LAUNCH("ccvm_clamp_cols");
+    return CCVM_OK;
+}
+
+int ccvm_change_variables_cols(const float* x, float* y, int B, int N, int ld, const float* s_cols, double lower,
+                               double upper, void* stream) {
+    int rc;
+    if (!x || !y || !s_cols) return fail(CCVM_E_INVALID, "ccvm_change_variables_cols: NULL argument");
+    if ((rc = check_layout("ccvm_change_variables_cols", B, N, ld))) return rc;
+    hipLaunchKernelGGL(change_variables_cols_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, N, ld, s_cols, (float)(upper - lower), (float)(0.5 * (upper + lower)));
+    CCVM_CHECK_LAUNCH("ccvm_change_variables_cols");
     return CCVM_OK;
 }
 

@@ -129,10 +129,11 @@ __device__ __forceinline__ void mf_update(const MfScalars& k, float mu, float sg
     sgn = __builtin_fmaf(k.dt, dsig, sg);
 }
 
-__device__ __forceinline__ float lv_update(const LvScalars& k, float c, float g, float n0) {
+// `S`: the clamp bound of this column (k.S, or the per-variable saturation of the column)
+__device__ __forceinline__ float lv_update(const LvScalars& k, float c, float g, float n0, float S) {
     float x = __builtin_fmaf(k.dt_fs, g, c) + k.w * n0;
     if (k.use_pump) x = __builtin_fmaf(k.dt, (k.pm - c * c) * c, x);
-    return clampf(x, -k.S, k.S);
+    return clampf(x, -S, S);
 }
 #pragma clang fp contract(fast)
 

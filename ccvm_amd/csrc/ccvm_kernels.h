@@ -54,6 +54,9 @@ struct StepArgs {
     const float* w0;    // REPLAY: this step's [N][B] block
     const float* w1;    // REPLAY: DL second stream
     const float* w0n;   // REPLAY (MF): next step's block
+    const float* s_cols; // per-variable saturation S_j (length ld) or NULL: then the scalars carry S.
+                         // With s_cols the scalars are built for S = 1, Q is the row-scaled copy
+                         // Q[k][j] / S_k, and the epilogue applies 1 / S_j and clamps to +-S_j.
     unsigned long long* dbg;  // ablation stamps only
     uint64_t seed;
     int64_t row_offset;
@@ -231,6 +234,9 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     auto gofs = [&](int r) { return (size_t)(row0 + 8 * (r >> 2)) * ld; };  // uniform part
     const float vj = col_ok ? a.V[j] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[j];  // shift * colsum(Q)[j]
+    // per-variable saturation: the column's bound and the 1 / S_j factor of its feedback term
+    const float sat_j = (a.s_cols && col_ok) ? a.s_cols[j] : 1.0f;
+    const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
 
     // Registers R0 + ibase + ii, ii = 0 .. H - 1.  hf: affine-folded GEMM sums; he0/he1: old state;
     // he2/he3: Adam moments; hcar: MF's normals of this step.
@@ -293,21 +299,22 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
-                const float fb = adam(__builtin_fmaf(k.f_q, hf[0][ii], k.f_v * vj));
+                const float bound = a.s_cols ? sat_j : k.S;
+                const float fb = adam(__builtin_fmaf(k.f_q, hf[0][ii], k.f_v * vj) * inv_sat_j);
                 float mun, sgn;
                 mf_update(k, he0[ii], he1[ii], fb, n0, mun, sgn);
                 if (ok) {
                     st_nt(&(a.st0 + gb)[lo], mun);
                     st_nt(&(a.st1 + gb)[lo], sgn);
                     if (k.has_next) {
-                        st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(k.k_next, n0n, mun), -k.S, k.S));
+                        st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(k.k_next, n0n, mun), -bound, bound));
                         if constexpr (FUSED) st_nt(&(a.carry + gb)[lo], n0n);  // next step's normal
                     }
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
-                const float g = adam(__builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj));
-                const float x = lv_update(k, he0[ii], g, n0);
+                const float g = adam(__builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj) * inv_sat_j);
+                const float x = lv_update(k, he0[ii], g, n0, a.s_cols ? sat_j : k.S);
                 if (ok) st_nt(&(a.o0 + gb)[lo], x);
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
@@ -723,6 +730,39 @@ __global__ void clamp_kernel(float* x, int B, int N, int ld, float lo, float hi)
     }
 }
 
+// Per-variable saturation: Qs[k][j] = Q[k][j] / S_k (the input map's 1 / S_k folded into the rows).
+__global__ void scale_rows_kernel(const float* __restrict__ Q, const float* __restrict__ s_cols,
+                                  float* __restrict__ Qs, int N, int ld) {
+    const size_t total = (size_t)ld * ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / ld);
+        Qs[i] = (k < N) ? Q[i] / s_cols[k] : 0.0f;
+    }
+}
+
+// x = clamp(x, -S_j, S_j) / y = 0.5 * x / S_j * (u - l) + 0.5 * (u + l) with a per-variable S.
+__global__ void clamp_cols_kernel(float* x, int B, int N, int ld, const float* __restrict__ s_cols) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        float* p = x + (size_t)r * ld + c;
+        *p = clampf(*p, -s_cols[c], s_cols[c]);
+    }
+}
+
+__global__ void change_variables_cols_kernel(const float* x, float* y, int B, int N, int ld,
+                                             const float* __restrict__ s_cols, float ul, float half_up) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        const size_t idx = (size_t)r * ld + c;
+        y[idx] = 0.5f * x[idx] / s_cols[c] * ul + half_up;
+    }
+}
+
 // y = 0.5 * x / S * (u - l) + 0.5 * (u + l), in the reference's operation order.
 __global__ void change_variables_kernel(const float* x, float* y, int B, int N, int ld,
                                         float S, float ul, float half_up) {
@@ -739,15 +779,16 @@ __global__ void change_variables_kernel(const float* x, float* y, int B, int N, 
 //   mu_tilde_c = clamp(mu + k * W, -S, S)    (reference mf_solver.py:551-554)
 // Also seeds the carry buffer with this step's normals (fused mode).
 __global__ void mf_prepare_kernel(const float* mu, float* out, float* carry, int B, int N, int ld,
-                                  float k, float S, uint64_t seed, int64_t row_offset, int step,
-                                  const float* w0) {
+                                  float k, float S, const float* s_cols, uint64_t seed, int64_t row_offset,
+                                  int step, const float* w0) {
     const size_t total = (size_t)B * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
         const float n0 = w0 ? w0[(size_t)j * B + b] : normal_single(seed, row_offset + b, step, j);
         const size_t idx = (size_t)b * ld + j;
-        out[idx] = clampf(mu[idx] + k * n0, -S, S);
+        const float bound = s_cols ? s_cols[j] : S;
+        out[idx] = clampf(mu[idx] + k * n0, -bound, bound);
         if (!w0) carry[idx] = n0;
     }
 }

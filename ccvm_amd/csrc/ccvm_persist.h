@@ -60,6 +60,7 @@ struct PersistArgs {
     float in_scale, in_shift;
     float k_first;      // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;            // MF: clamp of the measured amplitude
+    const float* s_cols; // per-variable saturation S_j (length ld) or NULL (see StepArgs::s_cols)
     AdamConsts ad;
 };
 
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     for (int k = 0; k < KMAX; ++k) qf[k] = a.Q[(size_t)k * ld + col];
     const float vj = col_ok ? a.V[col] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[col];  // shift * colsum(Q)[j]
+    const float sat_j = (a.s_cols && col_ok) ? a.s_cols[col] : 1.0f;  // per-variable saturation
+    const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
 
     // ---- this lane's elements: batch rows brow[e] at column col -------------------------------
     const int row0 = (blockIdx.x * RSW + wave / NCG) * BR;
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     if constexpr (MODE == MODE_MF) {
         stream_normals(a.step0, 0, wc);  // mf_solver.py:551-554 for the first step of the launch
 #pragma unroll
-        for (int e = 0; e < NE; ++e) mt[e] = ok[e] ? clampf(__builtin_fmaf(a.k_first, wc[e], s0[e]), -a.S, a.S) : 0.0f;
+        for (int e = 0; e < NE; ++e) {
+            const float bound = a.s_cols ? sat_j : a.S;
+            mt[e] = ok[e] ? clampf(__builtin_fmaf(a.k_first, wc[e], s0[e]), -bound, bound) : 0.0f;
+        }
     }
     auto publish = [&](float* buf) {  // this lane's GEMM-input values into an LDS state tile
 #pragma unroll
@@ -288,14 +294,15 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             if (k.has_next) stream_normals(step + 1, it + 1, wn);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                const float fb = adam(__builtin_fmaf(k.f_q, qx[e], k.f_v * vj), e);
+                const float bound = a.s_cols ? sat_j : k.S;
+                const float fb = adam(__builtin_fmaf(k.f_q, qx[e], k.f_v * vj) * inv_sat_j, e);
                 float mun, sgn;
                 mf_update(k, s0[e], s1[e], fb, wc[e], mun, sgn);
                 s0[e] = ok[e] ? mun : s0[e];
                 s1[e] = ok[e] ? sgn : s1[e];
                 // the last step's input is what mu_tilde_out returns: no new measurement after it
                 const bool nxt = ok[e] && k.has_next;
-                mt[e] = nxt ? clampf(__builtin_fmaf(k.k_next, wn[e], s0[e]), -k.S, k.S) : mt[e];
+                mt[e] = nxt ? clampf(__builtin_fmaf(k.k_next, wn[e], s0[e]), -bound, bound) : mt[e];
                 wc[e] = nxt ? wn[e] : wc[e];
             }
         } else {
@@ -304,8 +311,8 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             stream_normals(step, it, n0);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                const float g = adam(__builtin_fmaf(k.g_q, qx[e], k.g_v * vj), e);
-                const float x = lv_update(k, s0[e], g, n0[e]);
+                const float g = adam(__builtin_fmaf(k.g_q, qx[e], k.g_v * vj) * inv_sat_j, e);
+                const float x = lv_update(k, s0[e], g, n0[e], a.s_cols ? sat_j : k.S);
                 s0[e] = ok[e] ? x : s0[e];
             }
         }

@@ -291,6 +291,7 @@ class Trajectories:
         self.n, self.ld, self.device = problem.n, problem.ld, problem.device
         self.rows = rows_of(self.b)
         self.step = 0
+        self.s_cols = None  # per-variable saturation (device array), MF / Langevin only
         lo, hi = float(bounds[0]), float(bounds[1])
         with torch.cuda.device(self.device):
             zeros = lambda: torch.zeros((self.rows, self.ld), dtype=torch.float32, device=self.device)
@@ -306,14 +307,14 @@ class Trajectories:
                 self.state["sigma"][: self.b, : self.n] = 0.5  # mf_solver.py:538-540
                 cp = _lib.MfParams()
                 cp.pump, cp.dt, cp.j = params["pump"], params["dt"], params["j"]
-                cp.feedback_scale, cp.g, cp.S = params["feedback_scale"], params["g"], params["S"]
+                cp.feedback_scale, cp.g = params["feedback_scale"], params["g"]
                 cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
+                self._set_saturation(cp, params["S"])
             else:
                 self.state["c"] = zeros()
                 cp = _lib.LangevinParams()
-                cp.dt, cp.sigma, cp.feedback_scale, cp.S = (
-                    params["dt"], params["sigma"], params["feedback_scale"], params["S"]
-                )
+                cp.dt, cp.sigma, cp.feedback_scale = params["dt"], params["sigma"], params["feedback_scale"]
+                self._set_saturation(cp, params["S"])
                 cp.use_pump = 1 if params.get("use_pump", False) else 0
                 cp.pump = float(params.get("pump", 0.0))
                 cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
@@ -325,9 +326,18 @@ class Trajectories:
                 if float(adam["beta2"]) != 1.0:
                     self.adam_v = zeros()
             self.adam = _adam_struct(adam, self.adam_m, self.adam_v)
-            ws_bytes = self.lib.ccvm_workspace_bytes(self._SOLVER_ID[kind], self.b, self.n)
+            size_of = self.lib.ccvm_workspace_bytes_cols if self.s_cols is not None else self.lib.ccvm_workspace_bytes
+            ws_bytes = size_of(self._SOLVER_ID[kind], self.b, self.n)
             self.ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=self.device)
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
+
+    def _set_saturation(self, cp, S):
+        """Scalar S, or a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs)."""
+        if is_per_variable(S):
+            self.s_cols = saturation_columns(S, self.n, self.device)
+            cp.S, cp.s_cols = 1.0, self.s_cols.data_ptr()
+        else:
+            cp.S, cp.s_cols = float(S), None
 
     # ------------------------------------------------------------------ #
     def advance(self, nsteps):
@@ -359,12 +369,16 @@ class Trajectories:
 
     # ------------------------------------------------------------------ #
     def clamp(self, name, lo, hi):
+        """In-place clamp of a state array; ``hi`` may be a per-variable saturation (bounds -hi_j, +hi_j)."""
         with torch.cuda.device(self.device):
-            _lib.check(
-                self.lib.ccvm_clamp(_ptr(self.state[name]), self.b, self.n, self.ld, float(lo), float(hi),
-                                    _stream_ptr()),
-                "ccvm_clamp",
-            )
+            if is_per_variable(hi):
+                cols = saturation_columns(hi, self.n, self.device)
+                rc = self.lib.ccvm_clamp_cols(_ptr(self.state[name]), self.b, self.n, self.ld, _ptr(cols),
+                                              _stream_ptr())
+            else:
+                rc = self.lib.ccvm_clamp(_ptr(self.state[name]), self.b, self.n, self.ld, float(lo), float(hi),
+                                         _stream_ptr())
+            _lib.check(rc, "ccvm_clamp")
 
     def compact(self, name):
         """Logical (B, N) copy of one state array, on the GPU."""
@@ -388,31 +402,56 @@ def _rows_of_problem(xg, q_matrix, what):
     return int(xg.shape[0]), int(xg.shape[1])
 
 
+def is_per_variable(S):
+    """True for a per-variable saturation: the reference accepts S as a 1-D tensor of length N and
+    repeats it over the batch (dl_solver.py:843-848, mf_solver.py:834-839, ...)."""
+    return torch.is_tensor(S) and S.ndim == 1 and S.numel() > 1
+
+
+def saturation_columns(S, n, dev):
+    """The device array (ld floats, padding 1) the ``*_cols`` entry points and ``s_cols`` fields take."""
+    s = S.detach().to(device="cpu", dtype=torch.float32).reshape(-1)
+    if s.numel() != n:
+        raise ValueError("Tensor S size should be equal to problem size.")
+    if not bool((s > 0).all()):
+        raise ValueError("every entry of the saturation S must be positive")
+    out = torch.ones((ld_of(n),), dtype=torch.float32, device=dev)
+    out[:n] = s.to(dev)
+    return out
+
+
 def change_variables(x, S, lower, upper):
-    """0.5 * x / S * (upper - lower) + 0.5 * (upper + lower) on the GPU."""
+    """0.5 * x / S * (upper - lower) + 0.5 * (upper + lower) on the GPU (S scalar or per variable)."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
     b, n = xg.shape
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
-        _lib.check(
-            lib.ccvm_change_variables(_ptr(xp), _ptr(xp), b, n, xp.shape[1], float(S), float(lower),
-                                      float(upper), _stream_ptr()),
-            "ccvm_change_variables",
-        )
+        if is_per_variable(S):
+            cols = saturation_columns(S, n, dev)
+            rc = lib.ccvm_change_variables_cols(_ptr(xp), _ptr(xp), b, n, xp.shape[1], _ptr(cols), float(lower),
+                                                float(upper), _stream_ptr())
+        else:
+            rc = lib.ccvm_change_variables(_ptr(xp), _ptr(xp), b, n, xp.shape[1], float(S), float(lower),
+                                           float(upper), _stream_ptr())
+        _lib.check(rc, "ccvm_change_variables")
         return unpack(xp, b, n).to(x.device)
 
 
 def clamp(x, lo, hi):
-    """clamp(x, lo, hi) on the GPU (fit_to_constraints)."""
+    """clamp(x, lo, hi) on the GPU (fit_to_constraints); ``hi`` may be a per-variable saturation, then
+    the bounds are -hi_j, +hi_j."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
     b, n = xg.shape
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
-        _lib.check(
-            lib.ccvm_clamp(_ptr(xp), b, n, xp.shape[1], float(lo), float(hi), _stream_ptr()), "ccvm_clamp"
-        )
+        if is_per_variable(hi):
+            cols = saturation_columns(hi, n, dev)
+            rc = lib.ccvm_clamp_cols(_ptr(xp), b, n, xp.shape[1], _ptr(cols), _stream_ptr())
+        else:
+            rc = lib.ccvm_clamp(_ptr(xp), b, n, xp.shape[1], float(lo), float(hi), _stream_ptr())
+        _lib.check(rc, "ccvm_clamp")
         return unpack(xp, b, n).to(x.device)
 
 

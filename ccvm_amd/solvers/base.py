@@ -196,15 +196,20 @@ class CCVMSolver(ABC):
             ) from exc
 
     def _broadcast_saturation(self, S, problem_size):
-        """The reference broadcasts a 1-D tensor S to (B, N) (dl_solver.py:843-848).  The
-        fused kernels take a scalar saturation; per-variable S is rejected loudly."""
+        """The reference repeats a 1-D tensor S of length N over the batch (dl_solver.py:843-848 and the
+        same lines of the other solvers).  The engine keeps it as the per-variable vector it is: the
+        kernels apply S_j per column (``s_cols`` of the C ABI).  A full (B, N) saturation -- one bound per
+        trajectory AND variable, which the reference would also accept -- is rejected loudly."""
         if torch.is_tensor(S):
-            if S.ndim == 1 and S.size(dim=0) != problem_size:
+            if S.ndim == 1 and S.size(dim=0) != problem_size and S.numel() != 1:
                 raise ValueError("Tensor S size should be equal to problem size.")
             if S.numel() == 1:
                 return float(S.item())
+            if S.ndim == 1:
+                return S.detach().to(device="cpu", dtype=torch.float32)
             raise NotImplementedError(
-                "per-variable (tensor) saturation S is not supported by the HIP engine; pass a float"
+                "a (batch, N) saturation tensor is not supported by the HIP engine; pass a float or a 1-D "
+                "tensor of length N"
             )
         return S
 
@@ -335,7 +340,9 @@ class CCVMSolver(ABC):
 
 
 def _reject_tensor_s(S):
-    if torch.is_tensor(S) and S.numel() != 1:
+    """Scalars and per-variable (1-D) saturations pass; a (batch, N) tensor is not supported."""
+    if torch.is_tensor(S) and S.numel() != 1 and S.ndim != 1:
         raise NotImplementedError(
-            "per-variable (tensor) saturation bounds are not supported by the HIP engine"
+            "a (batch, N) saturation tensor is not supported by the HIP engine; pass a float or a 1-D "
+            "tensor of length N"
         )

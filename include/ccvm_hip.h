@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 1
+#define CCVM_ABI_VERSION 2
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -97,6 +97,11 @@ typedef struct ccvm_mf_params {
     double lower, upper;
     int32_t pump_rate_flag;
     int32_t reserved;
+    /* Per-variable saturation (the reference accepts S as a 1-D tensor of length N,
+     * mf_solver.py:834-839): device array of ld floats, S_j > 0 for j < N; NULL selects the
+     * scalar S above (which is ignored otherwise).  Needs the larger workspace of
+     * ccvm_workspace_bytes_cols. */
+    const float* s_cols;
 } ccvm_mf_params;
 
 /* Langevin (use_pump = 0): reference langevin_solver.py:368-435, :437-561, :117-166.
@@ -108,6 +113,8 @@ typedef struct ccvm_langevin_params {
     double lower, upper;
     int32_t use_pump;
     int32_t pump_rate_flag;  /* p_i = pump*(i+1)/T when set, else pump */
+    const float* s_cols;     /* per-variable saturation, as in ccvm_mf_params (langevin_solver.py:630-635,
+                                pumped_langevin_solver.py:519-524); NULL = scalar S */
 } ccvm_langevin_params;
 
 /* ---- library / layout ------------------------------------------------------- */
@@ -128,6 +135,8 @@ int ccvm_unpack(const float* src, int src_ld,
  * buffers, column sums of Q).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run, 2 ccvm_langevin_run,
  * 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);
+/* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
+size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
 
 /* Steps step0 .. step0+nsteps-1 of a T-step DL-CCVM run, in place on c and s.
  * Chunking a run into several calls does not change the result.  The final clamp
@@ -158,6 +167,13 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c,
 /* x = clamp(x, lo, hi) on the logical B x N region (fit_to_constraints,
  * dl_solver.py:237-250). */
 int ccvm_clamp(float* x, int B, int N, int ld, float lo, float hi, void* stream);
+
+/* The two above with a per-variable saturation S_j (s_cols: device array of ld floats):
+ * x = clamp(x, -S_j, S_j) and y = 0.5 * x / S_j * (upper - lower) + 0.5 * (upper + lower)
+ * (the reference repeats a 1-D S to (B, N), dl_solver.py:843-848). */
+int ccvm_clamp_cols(float* x, int B, int N, int ld, const float* s_cols, void* stream);
+int ccvm_change_variables_cols(const float* x, float* y, int B, int N, int ld,
+                               const float* s_cols, double lower, double upper, void* stream);
 
 /* y = 0.5 * x / S * (upper - lower) + 0.5 * (upper + lower)   (change_variables,
  * dl_solver.py:219-235).  y may alias x. */

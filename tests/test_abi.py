@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 1
+    assert hip_lib.ccvm_abi_version() == 2
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
@@ -55,6 +55,10 @@ def test_layout_helpers_and_version(hip_lib):
     assert hip_lib.ccvm_workspace_bytes(4, 1000, 1000) == 2 * state
     assert hip_lib.ccvm_workspace_bytes(5, 1000, 1000) == qs
     assert hip_lib.ccvm_workspace_bytes(9, 1000, 1000) == 0
+    # per-variable saturation: room for the row-scaled copy of Q (MF, Langevin only)
+    assert hip_lib.ccvm_workspace_bytes_cols(1, 1000, 1000) == 3 * state + qs + table + 1024 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes_cols(2, 1000, 1000) == state + qs + table + 1024 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes_cols(0, 1000, 1000) == hip_lib.ccvm_workspace_bytes(0, 1000, 1000)
 
 
 def test_struct_layouts_match_the_header():
@@ -64,8 +68,8 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.Adam) == 4 + 4 + 3 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8
-    assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8
-    assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8
+    assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8          # ... + s_cols
+    assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8 + 8    # ... + s_cols
 
 
 def test_host_side_argument_checks_need_no_gpu(hip_lib):

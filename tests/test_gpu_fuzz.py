@@ -37,12 +37,14 @@ def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "96")), seed=int(os.envir
         bounds = rng.choice([(0.0, 1.0), (0.0, 1.0), (-1.0, 1.0), (-0.5, 2.0), (1.0, 3.0)])  # solution_bounds
         g = rng.choice([None, None, 0.1, 0.002])      # __call__(g=...) of DL / MF
         ramp = rng.random() < 0.7                     # pump_rate_flag
-        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, bounds, g, ramp))
+        vec_s = kind != "dl" and rng.random() < 0.35  # per-variable saturation (1-D tensor S)
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, bounds, g, ramp,
+                    vec_s))
     return out
 
 
-@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp", _cases())
-def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp):
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp,vec_s", _cases())
+def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s):
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
     from oracle import ccvm_oracle as oracle
@@ -51,6 +53,9 @@ def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts
     adam = ADAMS[adam_i]
     q, v, _ = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
+    if vec_s:
+        gen = torch.Generator().manual_seed(n * 131 + b)
+        p["S"] = p["S"] * (0.5 + 1.5 * torch.rand(n, generator=gen))
     seed = 0xABCDEF12345 + 7919 * n + b
     if replay:
         noise = engine.NoiseSpec(mode="replay")
@@ -94,7 +99,7 @@ def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts
         scale = max(1.0, float(ref.abs().max()))
         err = float((got - ref).abs().max())
         assert err <= gate * scale, (f"{kind} N={n} B={b} T={t} adam={adam_i} offset={offset} cuts={cuts} "
-                                     f"replay={replay} bounds={bounds} g={g} ramp={ramp} {name}: {err:.3e}")
+                                     f"replay={replay} bounds={bounds} g={g} ramp={ramp} vec_s={vec_s} {name}: {err:.3e}")
     for name, arr in traj.state.items():  # padding stays zero
         assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
         assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0

@@ -42,9 +42,13 @@ def _run_case(g, meta, device="cpu"):
     from ccvm_amd.solvers.algorithms import AdamParameters
 
     kind = meta["kind"]
-    solver = _solver_for(kind, meta["batch"], device, meta.get("dl_S"))
+    as_s = lambda v: torch.tensor(v, dtype=torch.float32) if isinstance(v, list) else v  # per-variable S
+    solver = _solver_for(kind, meta["batch"], device, as_s(meta.get("dl_S")))
     inst = _instance(g, device, meta.get("bounds", (0.0, 1.0)))
-    solver.parameter_key = {inst.problem_size: dict(meta["params"])}
+    key = dict(meta["params"])
+    if "S" in key:
+        key["S"] = as_s(key["S"])
+    solver.parameter_key = {inst.problem_size: key}
     inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
     kwargs = {}
     if kind in ("dl", "mf", "pl"):
@@ -115,6 +119,33 @@ def test_solver_matches_reference_with_other_bounds(case, kernel_path):
             1.0, float(want.abs().max()))
         err = float((got.cpu() - want).abs().max())
         assert err <= tol, f"{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
+
+
+def _vector_s_case_names():
+    from golden_util import vector_s_cases
+
+    return sorted(vector_s_cases())
+
+
+@pytest.mark.parametrize("case", _vector_s_case_names())
+def test_solver_matches_reference_with_per_variable_saturation(case, kernel_path):
+    """S as a 1-D tensor of length N (dl_solver.py:843-848, mf_solver.py:834-839, langevin_solver.py:630-635,
+    pumped_langevin_solver.py:519-524): per-column bounds and 1 / S_j factors inside the kernels."""
+    from golden_util import vector_s_arrays, vector_s_cases
+
+    g, meta, arrays = golden("test020"), vector_s_cases()[case], vector_s_arrays()
+    sol = _run_case(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        tol = ATOL_OBJ if field == "objective_values" else ATOL_X * max(1.0, float(want.abs().max()))
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol, f"{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * abs(
+        meta["best_objective_value"]) + 1e-4
 
 
 def test_dl_example_anchor():
@@ -484,8 +515,14 @@ def test_unsupported_requests_fail_loudly():
     with pytest.raises(TypeError):  # same exception type as the reference's broken call
         dl(instance=inst, algorithm_parameters=AdamParameters())
     mf = MFSolver(device="cpu", batch_size=8)
-    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(20))}
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(8, 20))}  # one bound per row AND variable
     with pytest.raises(NotImplementedError):
+        mf(instance=inst)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(19))}     # wrong length
+    with pytest.raises(ValueError, match="Tensor S size should be equal to problem size"):
+        mf(instance=inst)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=-torch.ones(20))}    # not positive
+    with pytest.raises(ValueError, match="positive"):
         mf(instance=inst)
     mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"])}
     mf.calculate_grads = lambda *a, **k: 0
