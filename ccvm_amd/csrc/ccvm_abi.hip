@@ -168,10 +168,19 @@ int launch_step(StepArgs a, hipStream_t st, const char* name) {
     const int ks = choose_ks(a.B, a.N);
     set_grid(a, ks);
     const int grid = a.nrb * a.ncb;
-    if (ks == 2)
+    constexpr bool CAN_VS = (MODE == MODE_MF || MODE == MODE_LANGEVIN);
+    if (CAN_VS && a.s_cols) {  // per-variable saturation
+        if constexpr (CAN_VS) {
+            if (ks == 2)
+                hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 2, true>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 1, true>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+        }
+    } else if (ks == 2) {
         hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 2>), dim3(grid), dim3(WG_THREADS), 0, st, a);
-    else
+    } else {
         hipLaunchKernelGGL((step_kernel<MODE, ADAM, 0, 1>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+    }
     CCVM_CHECK_LAUNCH(name);
     return CCVM_OK;
 }

@@ -123,9 +123,12 @@ typedef const __attribute__((address_space(1))) void global_cvoid;
 // the k-steps [8 kh, 8 kh + 8) of each lane-half.  After the loop the two halves swap 8 accumulator
 // registers through LDS, so each wave ends up with the full sum of 8 of the 16 rows and the
 // epilogue work stays balanced.
-template <int MODE, bool ADAM, int ABL = 0, int KS = 1>
+// VS: per-variable saturation (StepArgs::s_cols).  A template parameter, not a run-time test of the
+// pointer: with the run-time form the scalar path of the N = 500 kernels lost 0.4 us per step.
+template <int MODE, bool ADAM, int ABL = 0, int KS = 1, bool VS = false>
 __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     static_assert(KS == 1 || KS == 2, "KS");
+    static_assert(!VS || MODE == MODE_MF || MODE == MODE_LANGEVIN, "per-variable saturation: MF and Langevin steps");
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
     constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
     constexpr int BNT = BN / KS;             // columns per workgroup
@@ -234,9 +237,11 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     auto gofs = [&](int r) { return (size_t)(row0 + 8 * (r >> 2)) * ld; };  // uniform part
     const float vj = col_ok ? a.V[j] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[j];  // shift * colsum(Q)[j]
-    // per-variable saturation: the column's bound and the 1 / S_j factor of its feedback term
-    const float sat_j = (a.s_cols && col_ok) ? a.s_cols[j] : 1.0f;
-    const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
+    // per-variable saturation: the column's bound (its reciprocal, the 1 / S_j factor of the feedback
+    // term, is formed in the epilogue: a division here would put a vmcnt(0) wait for all of these loads
+    // in front of the producers' first DMA)
+    float sat_j = 1.0f;
+    if constexpr (VS) sat_j = col_ok ? a.s_cols[j] : 1.0f;
 
     // Registers R0 + ibase + ii, ii = 0 .. H - 1.  hf: affine-folded GEMM sums; he0/he1: old state;
     // he2/he3: Adam moments; hcar: MF's normals of this step.
@@ -250,6 +255,8 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         // register; the common case (whole row block inside the batch, fused noise) runs it under
         // ONE column mask with no per-element branches, edge blocks and replay mode take the
         // general path.
+        float inv_sat_j = 1.0f;
+        if constexpr (VS) inv_sat_j = 1.0f / sat_j;
         auto element = [&](int ii, bool ok, auto fused_tag) {
             constexpr bool FUSED = decltype(fused_tag)::value;
             const int r = R0 + ibase + ii;
@@ -299,8 +306,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 }
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars& k = a.s.mf;
-                const float bound = a.s_cols ? sat_j : k.S;
-                const float fb = adam(__builtin_fmaf(k.f_q, hf[0][ii], k.f_v * vj) * inv_sat_j);
+                const float bound = VS ? sat_j : k.S;
+                float fq = __builtin_fmaf(k.f_q, hf[0][ii], k.f_v * vj);
+                if constexpr (VS) fq *= inv_sat_j;
+                const float fb = adam(fq);
                 float mun, sgn;
                 mf_update(k, he0[ii], he1[ii], fb, n0, mun, sgn);
                 if (ok) {
@@ -313,8 +322,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 }
             } else if constexpr (MODE == MODE_LANGEVIN) {
                 const LvScalars& k = a.s.lv;
-                const float g = adam(__builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj) * inv_sat_j);
-                const float x = lv_update(k, he0[ii], g, n0, a.s_cols ? sat_j : k.S);
+                float gq = __builtin_fmaf(k.g_q, hf[0][ii], k.g_v * vj);
+                if constexpr (VS) gq *= inv_sat_j;
+                const float g = adam(gq);
+                const float x = lv_update(k, he0[ii], g, n0, VS ? sat_j : k.S);
                 if (ok) st_nt(&(a.o0 + gb)[lo], x);
             } else if constexpr (MODE == MODE_GD) {
                 const PpScalars& k = a.s.pp;
