@@ -473,6 +473,18 @@ def feedback(x, q_matrix, v_vector, in_scale, in_shift, f_q, f_v):
         return unpack(yp, b, n).to(x.device)
 
 
+def saturated_feedback(x, q_matrix, v_vector, S, in_scale, in_shift, f_q, f_v):
+    """The feedback term of a solver whose input map and output each carry one factor 1 / S:
+        (f_q * ((x / S * in_scale + in_shift) @ Q) + f_v * V) / S
+    with the scalars given for S = 1.  S: float, or a per-variable 1-D tensor (then x / S and the final
+    1 / S are applied per column around the device kernel)."""
+    if is_per_variable(S):
+        s = S.detach().to(device=x.device, dtype=torch.float32)
+        return feedback(x / s, q_matrix, v_vector, in_scale, in_shift, f_q, f_v) / s
+    S = float(S)
+    return feedback(x, q_matrix, v_vector, in_scale / S, in_shift, f_q / S, f_v / S)
+
+
 def energy(confs, q_matrix, v_vector, scaled_by=1.0):
     """(1/2 x Q x + V x) * scaled_by for every row of ``confs``."""
     lib = _lib.load()

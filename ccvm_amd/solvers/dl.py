@@ -38,10 +38,10 @@ class DLSolver(CCVMSolver):
     # ---- compatibility hooks (not used by the fused loop) ------------------------- #
     def _calculate_grads_boxqp(self, c, s, lower_limit=0, upper_limit=1, S=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
-        kw = dict(in_scale=ul / S, in_shift=up, f_q=-0.25 * ul / S, f_v=-ul / (2 * S))
+        kw = dict(in_scale=ul, in_shift=up, f_q=-0.25 * ul, f_v=-ul / 2)
         return (
-            engine.feedback(c, self.q_matrix, self.v_vector, **kw),
-            engine.feedback(s, self.q_matrix, self.v_vector, **kw),
+            engine.saturated_feedback(c, self.q_matrix, self.v_vector, S, **kw),
+            engine.saturated_feedback(s, self.q_matrix, self.v_vector, S, **kw),
         )
 
     def _calculate_drift_boxqp(

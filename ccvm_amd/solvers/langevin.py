@@ -31,9 +31,9 @@ class _LangevinFamily(CCVMSolver):
 
     def _calculate_grads_boxqp(self, c, lower_limit=0, upper_limit=1, S=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
-        k = ul / (2 * S)
-        return engine.feedback(
-            c, self.q_matrix, self.v_vector, in_scale=k, in_shift=up / 2, f_q=-k, f_v=-k
+        k = ul / 2
+        return engine.saturated_feedback(
+            c, self.q_matrix, self.v_vector, S, in_scale=k, in_shift=up / 2, f_q=-k, f_v=-k
         )
 
     def _run(self, batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,

@@ -36,9 +36,9 @@ class MFSolver(CCVMSolver):
     # ---- compatibility hooks (not used by the fused loop) ------------------------- #
     def _calculate_grads_boxqp(self, mu_tilde, S, fs, lower_limit=0, upper_limit=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
-        return engine.feedback(
-            mu_tilde, self.q_matrix, self.v_vector,
-            in_scale=ul / S, in_shift=up, f_q=-fs * 0.25 * ul / S, f_v=-fs * ul / (2 * S),
+        return engine.saturated_feedback(
+            mu_tilde, self.q_matrix, self.v_vector, S,
+            in_scale=ul, in_shift=up, f_q=-fs * 0.25 * ul, f_v=-fs * ul / 2,
         )
 
     def _calculate_drift_boxqp(

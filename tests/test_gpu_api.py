@@ -37,6 +37,37 @@ def test_mf_hooks_known_answers():
     assert torch.equal(z, torch.tensor([[1.0, -1.0, 0.25]]))
 
 
+def test_hooks_accept_a_per_variable_saturation():
+    """calculate_grads / change_variables / fit_to_constraints with S as a 1-D tensor, against the
+    oracle's formulas (which the reference goldens pin for tensor S)."""
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver
+    from oracle import ccvm_oracle as oracle
+
+    n, b = 12, 5
+    gen = torch.Generator().manual_seed(1)
+    q = torch.rand(n, n, generator=gen) - 0.5
+    v = torch.rand(n, generator=gen) - 0.5
+    x = torch.rand(b, n, generator=gen) - 0.5
+    S = 0.5 + torch.rand(n, generator=gen)
+    mf = MFSolver(device="cpu", batch_size=b)
+    mf.q_matrix, mf.v_vector = q, v
+    assert torch.allclose(mf.calculate_grads(x, S, 3.0, -0.5, 2.0), oracle.mf_grads(x, q, v, S, 3.0, -0.5, 2.0),
+                          rtol=1e-5, atol=1e-5)
+    lv = LangevinSolver(device="cpu", batch_size=b)
+    lv.q_matrix, lv.v_vector = q, v
+    want = -(torch.einsum("bi,ij->bj", x * 2.5 / (2 * S) + 0.75, q) + v) * 2.5 / (2 * S)   # langevin_solver.py:117-139
+    assert torch.allclose(lv.calculate_grads(x, -0.5, 2.0, S), want, rtol=1e-5, atol=1e-5)
+    dl = DLSolver(device="cpu", batch_size=b)
+    dl.q_matrix, dl.v_vector = q, v
+    gc, gs = dl.calculate_grads(x, -x, 0.0, 1.0, S)
+    # the hook returns the gradient with its sign (dc = +fsd * grads + ...), the oracle's helper the
+    # feedback G of dc = -fsd * G + ...
+    assert torch.allclose(gc, -oracle.dl_feedback(x, q, v, 0.0, 1.0, S), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gs, -oracle.dl_feedback(-x, q, v, 0.0, 1.0, S), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(mf.change_variables(x, -0.5, 2.0, S), 0.5 * x / S * 2.5 + 0.75, rtol=1e-6, atol=1e-6)
+    assert torch.equal(mf.fit_to_constraints(3 * x, -S, S), torch.clamp(3 * x, -S, S))
+
+
 @pytest.mark.parametrize("kind,step_size", [("dl", 7), ("mf", 10), ("pl", 4)])
 def test_evolution_sampling_matches_oracle(tmp_path, kind, step_size):
     """evolution_step_size: samples after steps i % k == 0 and the last one, best row written
