@@ -726,6 +726,37 @@ int ccvm_pp_adam(const float* Q, const float* V, float* x, int B, int N, int ld,
     return CCVM_OK;
 }
 
+int ccvm_pp_asgd(const float* Q, const float* V, float* x, int B, int N, int ld, double lr, double lambd, double lo,
+                 double hi, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_pp_asgd";
+    int rc;
+    if (!Q || !V || !x) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(4, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* xn = static_cast<float*>(ws);
+    float* qs = xn + state;
+    if (hipMemsetAsync(xn, 0, state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
+    CCVM_CHECK_LAUNCH(fn);
+    StepArgs a;
+    base_args(a, qs, V, B, N, ld);
+    a.a0 = x;
+    a.o0 = xn;
+    a.s.pp.step = (float)lr;
+    a.s.pp.eps = (float)(1.0 - lambd * lr);  // first step of torch.optim.ASGD: eta = lr
+    a.s.pp.lo = (float)lo;
+    a.s.pp.hi = (float)hi;
+    if ((rc = launch_step<MODE_ASGDPP, false>(a, st, fn))) return rc;
+    if (hipMemcpyAsync(x, xn, state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+    return CCVM_OK;
+}
+
 int ccvm_philox_normals(uint64_t seed, int64_t row_offset, int step, int B, int N, float* w0, float* w1,
                         void* stream) {
     if (!w0 || B <= 0 || N <= 0 || step < 0) return fail(CCVM_E_INVALID, "ccvm_philox_normals: bad argument");

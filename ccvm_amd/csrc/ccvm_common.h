@@ -23,7 +23,8 @@ enum Mode : int {
     MODE_ENERGY = 3,    // row partials of 1/2 xQx + Vx
     MODE_GD = 4,        // projected gradient step (post-processor)
     MODE_ADAMPP = 5,    // one Adam step from zero moments (post-processor)
-    MODE_AFFINE = 6     // y = f_q * (A(x) @ Q) + f_v * V   (the bare feedback term)
+    MODE_AFFINE = 6,    // y = f_q * (A(x) @ Q) + f_v * V   (the bare feedback term)
+    MODE_ASGDPP = 7     // one torch.optim.ASGD step (post-processor)
 };
 
 // Per-step scalars, computed on the host in fp64 exactly where the reference uses

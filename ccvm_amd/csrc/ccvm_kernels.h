@@ -334,6 +334,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                 const PpScalars& k = a.s.pp;
                 const float g = hf[0][ii] + vj;
                 if (ok) st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(-k.step, g / (fabsf(g) + k.eps), he0[ii]), k.lo, k.hi));
+            } else if constexpr (MODE == MODE_ASGDPP) {
+                const PpScalars& k = a.s.pp;  // eps = 1 - lambd * lr (the decay of the parameter)
+                const float g = hf[0][ii] + vj;
+                if (ok) st_nt(&(a.o0 + gb)[lo], clampf(__builtin_fmaf(-k.step, g, k.eps * he0[ii]), k.lo, k.hi));
             } else if constexpr (MODE == MODE_AFFINE) {
                 const PpScalars& k = a.s.pp;  // step = f_q, eps = f_v
                 if (ok) st_nt(&(a.o0 + gb)[lo], __builtin_fmaf(k.step, hf[0][ii], k.eps * vj));

@@ -25,6 +25,7 @@ _ALIASES = {
     "post_processor.factory": "ccvm_amd.post_processor.factory",
     "post_processor.post_processor": "ccvm_amd.post_processor.post_processor",
     "post_processor.adam": "ccvm_amd.post_processor.adam",
+    "post_processor.asgd": "ccvm_amd.post_processor.asgd",
     "post_processor.grad_descent": "ccvm_amd.post_processor.grad_descent",
 }
 

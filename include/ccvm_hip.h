@@ -212,6 +212,14 @@ int ccvm_pp_adam(const float* Q, const float* V, float* x,
                  int B, int N, int ld, double lr, double eps,
                  double lo, double hi,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* asgd: the first step of torch.optim.ASGD(lr, lambd) on 1/2 xQx + Vx, then clamp
+ *   (post_processor/asgd.py): x <- clamp(x * (1 - lambd * lr) - lr * g, lo, hi), g as for adam.
+ *   (In the reference only the first optimizer step of adam / asgd ever takes effect: the Parameter is
+ *   replaced after every step while the optimizer keeps the original, so num_iter > 1 changes nothing.) */
+int ccvm_pp_asgd(const float* Q, const float* V, float* x,
+                 int B, int N, int ld, double lr, double lambd,
+                 double lo, double hi,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- noise generator, exposed for tests -------------------------------------- */
 /* Fill w0 (and w1 if not NULL) with the standard normals the fused PHILOX mode uses

@@ -113,19 +113,32 @@ def pp_grad_descent(x, q, v, lo=0.0, hi=1.0, num_iter_main=1000, num_iter_pp=Non
     return x
 
 
+def _pp_gradient(x, q, v):
+    """d/dx (1/2 xQx + Vx) = 1/2 (Q + Q') x + V  (autograd of box_qp_model.py:72-74)."""
+    return 0.5 * (torch.einsum("bi,ij -> bj", x, q) + torch.einsum("bj,ij -> bi", x, q)) + v
+
+
 def pp_adam(x, q, v, lo=0.0, hi=1.0, num_iter=1, lr=0.01, eps=1e-8):
-    """post_processor/adam.py:58-66 in closed form.  The reference rebuilds the Parameter
-    after every step, so each torch.optim.Adam step starts from zero moments:
-    m^ = g, v^ = g^2  ->  x <- clamp(x - lr g/(sqrt(g^2) + eps)),  g = d/dx (1/2 xQx + Vx)
-    = 1/2 (Q + Q') x + V  (autograd of box_qp_model.py:72-74)."""
-    x = x.clone()
-    for _ in range(num_iter):
-        g = 0.5 * (torch.einsum("bi,ij -> bj", x, q) + torch.einsum("bj,ij -> bi", x, q)) + v
-        x = torch.clamp(x - lr * g / (g.abs() + eps), lo, hi)
-    return x
+    """post_processor/adam.py:58-66 in closed form.  The reference rebuilds the Parameter after every
+    step while the optimizer keeps the original one (whose grad stays None afterwards): only the FIRST
+    torch.optim.Adam step ever takes effect -- num_iter = 3 equals num_iter = 1 bit for bit (probed).
+    From zero moments: m^ = g, v^ = g^2  ->  x <- clamp(x - lr g/(sqrt(g^2) + eps))."""
+    if num_iter < 1:
+        return x.clone()
+    g = _pp_gradient(x, q, v)
+    return torch.clamp(x - lr * g / (g.abs() + eps), lo, hi)
 
 
-_POST = {"grad-descent": pp_grad_descent, "adam": pp_adam}
+def pp_asgd(x, q, v, lo=0.0, hi=1.0, num_iter=1, lr=0.01, lambd=0.001):
+    """post_processor/asgd.py in closed form: the first step of torch.optim.ASGD(lr, lambd)
+    (eta = lr: param *= 1 - lambd eta; param -= eta grad), then clamp; later iterations are
+    no-ops for the same reason as in pp_adam (probed)."""
+    if num_iter < 1:
+        return x.clone()
+    return torch.clamp(x * (1.0 - lambd * lr) - lr * _pp_gradient(x, q, v), lo, hi)
+
+
+_POST = {"grad-descent": pp_grad_descent, "adam": pp_adam, "asgd": pp_asgd}
 
 
 def _adam_update(grads, m, v, i, hp):

@@ -160,8 +160,42 @@ def vector_s_cases():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
+def asgd_cases():
+    """post_processor="asgd" through every solver, and the post-processors called directly with
+    num_iter = 1 and 3 (only the first optimizer step of adam / asgd ever takes effect)."""
+    from ccvm_simulators.post_processor.adam import PostProcessorAdam
+    from ccvm_simulators.post_processor.asgd import PostProcessorASGD
+    from ccvm_simulators.post_processor.grad_descent import PostProcessorGradDescent
+
+    store, manifest = {}, {"cases": {}}
+    for kind in SOLVERS:
+        name = f"{kind}_T50_asgd"
+        arrays, meta = run_case(kind, INSTANCES["test020"], 50, post="asgd", batch=40)
+        for k, v in arrays.items():
+            store[f"{name}/{k}"] = v
+        manifest["cases"][name] = meta
+        print("asgd", name, meta["best_objective_value"])
+    g = torch.Generator().manual_seed(17)
+    n, b = 13, 9
+    q, v, c = torch.rand(n, n, generator=g) - 0.5, torch.rand(n, generator=g) - 0.5, torch.rand(b, n, generator=g) * 1.2 - 0.1
+    store["direct/q"], store["direct/v"], store["direct/c"] = q.numpy(), v.numpy(), c.numpy()
+    for label, cls in (("adam", PostProcessorAdam), ("asgd", PostProcessorASGD)):
+        for it in (1, 3):
+            store[f"direct/{label}_iter{it}"] = cls().postprocess(c.clone(), q, v, num_iter=it).numpy()
+        store[f"direct/{label}_bounds"] = cls().postprocess(c.clone(), q, v, lower_clamp=0.2, upper_clamp=0.7).numpy()
+    store["direct/grad-descent"] = PostProcessorGradDescent().postprocess(c.clone(), q, v).numpy()
+    store["direct/grad-descent_custom"] = PostProcessorGradDescent().postprocess(
+        c.clone(), q, v, lower_clamp=0.1, upper_clamp=0.9, num_iter_pp=4, step_size=0.05).numpy()
+    np.savez_compressed(os.path.join(OUT, "test020_asgd.npz"), **store)
+    with open(os.path.join(OUT, "test020_asgd.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
+    if "--only-asgd" in sys.argv:
+        asgd_cases()
+        return
     if "--only-vector-s" in sys.argv:
         vector_s_cases()
         return
@@ -218,6 +252,7 @@ def main():
     anchors()
     bounds_cases()
     vector_s_cases()
+    asgd_cases()
 
 
 if __name__ == "__main__":

@@ -61,6 +61,17 @@ def vector_s_arrays():
     return np.load(os.path.join(GOLDEN_DIR, "test020_vecS.npz"))
 
 
+def asgd_cases():
+    """tests/golden/test020_asgd.{npz,json}: post_processor="asgd" through every solver, and under the
+    "direct/" prefix the post-processors called on their own (num_iter 1 and 3, custom bounds)."""
+    with open(os.path.join(GOLDEN_DIR, "test020_asgd.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def asgd_arrays():
+    return np.load(os.path.join(GOLDEN_DIR, "test020_asgd.npz"))
+
+
 _cache = {}
 
 

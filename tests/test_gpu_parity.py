@@ -148,6 +148,51 @@ def test_solver_matches_reference_with_per_variable_saturation(case, kernel_path
         meta["best_objective_value"]) + 1e-4
 
 
+def _asgd_case_names():
+    from golden_util import asgd_cases
+
+    return sorted(asgd_cases())
+
+
+@pytest.mark.parametrize("case", _asgd_case_names())
+def test_solver_matches_reference_with_asgd_post_processor(case, kernel_path):
+    from golden_util import asgd_arrays, asgd_cases
+
+    g, meta, arrays = golden("test020"), asgd_cases()[case], asgd_arrays()
+    sol = _run_case(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        tol = ATOL_OBJ if field == "objective_values" else ATOL_X * max(1.0, float(want.abs().max()))
+        assert float((got.cpu() - want).abs().max()) <= tol, f"{case}/{field}"
+
+
+def test_post_processors_called_directly_match_the_reference():
+    """adam / asgd with num_iter 1 and 3 (identical in the reference: only the first optimizer step takes
+    effect), custom bounds, grad-descent with a custom iteration count and step size."""
+    from ccvm_amd.post_processor.factory import PostProcessorFactory
+    from golden_util import asgd_arrays
+
+    a = asgd_arrays()
+    q, v, c = (torch.from_numpy(a[f"direct/{k}"].copy()) for k in ("q", "v", "c"))
+    for label in ("adam", "asgd"):
+        pp = PostProcessorFactory.create_postprocessor(label)
+        for it in (1, 3):
+            want = torch.from_numpy(a[f"direct/{label}_iter{it}"].copy())
+            assert float((pp.postprocess(c.clone(), q, v, num_iter=it) - want).abs().max()) <= 2e-6
+        want = torch.from_numpy(a[f"direct/{label}_bounds"].copy())
+        assert float((pp.postprocess(c.clone(), q, v, lower_clamp=0.2, upper_clamp=0.7) - want).abs().max()) <= 2e-6
+        assert torch.equal(pp.postprocess(c.clone(), q, v, num_iter=0), c)
+    gd = PostProcessorFactory.create_postprocessor("grad-descent")
+    assert float((gd.postprocess(c.clone(), q, v) - torch.from_numpy(a["direct/grad-descent"].copy())).abs().max()) <= 1e-5
+    want = torch.from_numpy(a["direct/grad-descent_custom"].copy())
+    got = gd.postprocess(c.clone(), q, v, lower_clamp=0.1, upper_clamp=0.9, num_iter_pp=4, step_size=0.05)
+    assert float((got - want).abs().max()) <= 1e-5
+
+
 def test_dl_example_anchor():
     """The reference's DL example exactly as shipped (B=1000, T=1500, seed 1234,
     tuningH020-100-0): best 130.7142, `optimal` fraction 0.987."""
@@ -508,8 +553,9 @@ def test_unsupported_requests_fail_loudly():
 
     g = golden("test020")
     inst = _instance(g)
-    with pytest.raises(NotImplementedError):
-        PostProcessorFactory.create_postprocessor("bfgs")
+    for host_only in ("bfgs", "lbfgs"):
+        with pytest.raises(NotImplementedError):
+            PostProcessorFactory.create_postprocessor(host_only)
     dl = DLSolver(device="cpu", batch_size=8)
     dl.parameter_key = {20: dict(g.cases["dl_T1"]["params"])}
     with pytest.raises(TypeError):  # same exception type as the reference's broken call

@@ -9,8 +9,8 @@ differently still passes, and far tighter than the GPU parity tolerance.
 import pytest
 import torch
 
-from golden_util import (all_cases, bounds_arrays, bounds_cases, check_noise_checksum, golden, vector_s_arrays,
-                         vector_s_cases)
+from golden_util import (all_cases, asgd_arrays, asgd_cases, bounds_arrays, bounds_cases, check_noise_checksum,
+                         golden, vector_s_arrays, vector_s_cases)
 from oracle import ccvm_oracle as oracle
 
 ATOL_STATE = 1e-5
@@ -99,6 +99,36 @@ def test_oracle_reproduces_reference_with_per_variable_saturation(case):
         assert float((out[field] - want).abs().max()) <= tol, f"{case}/{field}"
     assert abs(out["best_objective_value"] - meta["best_objective_value"]) <= RTOL_OBJ * abs(
         meta["best_objective_value"]) + 1e-6
+
+
+@pytest.mark.parametrize("case", sorted(asgd_cases()))
+def test_oracle_reproduces_reference_with_asgd_post_processor(case):
+    g, meta, arrays = golden("test020"), asgd_cases()[case], asgd_arrays()
+    out = run_oracle(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        tol = (RTOL_OBJ if field == "objective_values" else ATOL_STATE) * max(1.0, float(want.abs().max()))
+        assert float((out[field] - want).abs().max()) <= tol, f"{case}/{field}"
+
+
+def test_oracle_post_processors_match_reference_called_directly():
+    """num_iter = 3 equals num_iter = 1 for adam and asgd (only the first optimizer step takes effect in
+    the reference); custom bounds; grad-descent with custom iteration count and step."""
+    a = asgd_arrays()
+    q, v, c = (torch.from_numpy(a[f"direct/{k}"].copy()) for k in ("q", "v", "c"))
+    for label, fn in (("adam", oracle.pp_adam), ("asgd", oracle.pp_asgd)):
+        assert (a[f"direct/{label}_iter1"] == a[f"direct/{label}_iter3"]).all()
+        for it in (1, 3):
+            want = torch.from_numpy(a[f"direct/{label}_iter{it}"].copy())
+            assert float((fn(c, q, v, num_iter=it) - want).abs().max()) <= 1e-7
+        want = torch.from_numpy(a[f"direct/{label}_bounds"].copy())
+        assert float((fn(c, q, v, 0.2, 0.7) - want).abs().max()) <= 1e-7
+    assert float((oracle.pp_grad_descent(c, q, v) - torch.from_numpy(a["direct/grad-descent"].copy())).abs().max()) <= 1e-6
+    want = torch.from_numpy(a["direct/grad-descent_custom"].copy())
+    assert float((oracle.pp_grad_descent(c, q, v, 0.1, 0.9, num_iter_pp=4, step_size=0.05) - want).abs().max()) <= 1e-6
 
 
 def test_oracle_reproduces_baseline_config_1():
