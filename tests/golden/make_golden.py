@@ -60,7 +60,7 @@ ADAMS = {
 
 
 def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0),
-             dl_S=None, s_vector=None):
+             dl_S=None, s_vector=None, g=None):
     """``s_vector``: per-variable saturation (1-D tensor of length N) -- DL takes it in the constructor,
     the other solvers in the parameter key, scaled to the magnitude of their scalar default."""
     if kind == "dl" and s_vector is not None:
@@ -78,6 +78,8 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
         kwargs["pump_rate_flag"] = flag
     if adam:
         kwargs["algorithm_parameters"] = AdamParameters(**ADAMS[adam])
+    if g is not None:
+        kwargs["g"] = g  # __call__(g=...) of DL (default 0.05) and MF (default 0.01)
     torch.manual_seed(seed)
     first_draw = torch.randn(inst.problem_size, batch)  # checksum of the stream's first block
     torch.manual_seed(seed)
@@ -88,7 +90,7 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     meta = {
         "kind": kind, "iterations": iterations, "adam": ADAMS[adam] if adam else None, "post": post,
         "pump_rate_flag": flag, "batch": batch, "seed": seed, "params": params_out, "bounds": list(bounds),
-        "dl_S": dl_S.tolist() if torch.is_tensor(dl_S) else dl_S,
+        "dl_S": dl_S.tolist() if torch.is_tensor(dl_S) else dl_S, "g": g,
         "best_objective_value": sol.best_objective_value,
         "solution_performance": sol.solution_performance,
         "scaled_by": float(inst.scaled_by),
@@ -135,6 +137,15 @@ def bounds_cases():
                 store[f"{name}/{k}"] = v
             manifest["cases"][name] = meta
             print("S", name, meta["best_objective_value"])
+    # the nonlinearity / measurement strength g of __call__ (dl_solver.py:549, mf_solver.py:141-198)
+    for kind, g in (("dl", 0.2), ("dl", 0.005), ("mf", 0.05), ("mf", 0.3)):
+        for adam in (None, "adamC") if kind == "mf" else (None,):
+            name = f"{kind}_T40_g{g}" + (f"_{adam}" if adam else "")
+            arrays, meta = run_case(kind, INSTANCES["test020"], 40, adam=adam, batch=40, g=g)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print("g", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_bounds.npz"), **store)
     with open(os.path.join(OUT, "test020_bounds.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)

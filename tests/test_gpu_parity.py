@@ -55,6 +55,8 @@ def _run_case(g, meta, device="cpu"):
         kwargs["pump_rate_flag"] = meta["pump_rate_flag"]
     if meta["adam"]:
         kwargs["algorithm_parameters"] = AdamParameters(**meta["adam"])
+    if meta.get("g") is not None:
+        kwargs["g"] = meta["g"]
     torch.manual_seed(meta["seed"])
     return solver(instance=inst, post_processor=meta["post"], **kwargs)
 

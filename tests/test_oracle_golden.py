@@ -33,10 +33,12 @@ def run_oracle(g, meta):
     torch.manual_seed(meta["seed"])
     if kind == "dl":
         return oracle.solve_dl(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"],
-                               g=0.05, S=_saturation(meta.get("dl_S")) if meta.get("dl_S") is not None else 1,
+                               g=meta.get("g") or 0.05,
+                               S=_saturation(meta.get("dl_S")) if meta.get("dl_S") is not None else 1,
                                pump_rate_flag=meta["pump_rate_flag"], **common)
     if kind == "mf":
-        return oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01,
+        return oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"],
+                               g=meta.get("g") or 0.01,
                                pump_rate_flag=meta["pump_rate_flag"], adam=meta["adam"], **common)
     if kind == "langevin":
         return oracle.solve_langevin(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"],
@@ -72,7 +74,7 @@ def test_oracle_reproduces_reference(tag, case):
 def test_oracle_reproduces_reference_with_other_bounds(case):
     """solution_bounds other than (0, 1): the (u - l), (u + l) maps of every drift / grads function."""
     g, meta, arrays = golden("test020"), bounds_cases()[case], bounds_arrays()
-    assert tuple(meta["bounds"]) != (0.0, 1.0) or meta["dl_S"] is not None
+    assert tuple(meta["bounds"]) != (0.0, 1.0) or meta["dl_S"] is not None or meta["g"] is not None
     out = run_oracle(g, meta)
     for key in arrays.files:
         if not key.startswith(case + "/"):
