@@ -149,6 +149,9 @@ SIGNATURES = {
     "ccvm_pp_adam": (
         c_int, [_P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, c_size_t, _P]
     ),
+    "ccvm_pp_lbfgs": (
+        c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P, c_size_t, _P]
+    ),
     "ccvm_pp_asgd": (
         c_int, [_P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, c_size_t, _P]
     ),

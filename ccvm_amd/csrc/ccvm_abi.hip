@@ -757,6 +757,38 @@ int ccvm_pp_asgd(const float* Q, const float* V, float* x, int B, int N, int ld,
     return CCVM_OK;
 }
 
+int ccvm_pp_lbfgs(const float* Q, const float* V, float* x, int B, int N, int ld, int iters, double lr, double lo,
+                  double hi, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_pp_lbfgs";
+    int rc;
+    if (!Q || !V || !x || iters < 0) return fail(CCVM_E_INVALID, "%s: bad argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(4, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (iters == 0) return CCVM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t state = (size_t)ccvm_rows(B) * ld;
+    float* grad = static_cast<float*>(ws);
+    float* qs = grad + state;
+    if (hipMemsetAsync(grad, 0, state * sizeof(float), st) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: memset failed", fn);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
+    CCVM_CHECK_LAUNCH(fn);
+    StepArgs a;
+    base_args(a, qs, V, B, N, ld);  // g = x @ 1/2 (Q + Q') + V
+    a.a0 = x;
+    a.o0 = grad;
+    a.s.pp.step = 1.0f;
+    a.s.pp.eps = 1.0f;
+    for (int i = 0; i < iters; ++i) {
+        if ((rc = launch_step<MODE_AFFINE, false>(a, st, fn))) return rc;
+        hipLaunchKernelGGL(lbfgs_row_kernel, dim3(B), dim3(256), 0, st, x, grad, N, ld, (float)lr, (float)lo, (float)hi);
+        CCVM_CHECK_LAUNCH(fn);
+    }
+    return CCVM_OK;
+}
+
 int ccvm_philox_normals(uint64_t seed, int64_t row_offset, int step, int B, int N, float* w0, float* w1,
                         void* stream) {
     if (!w0 || B <= 0 || N <= 0 || step < 0) return fail(CCVM_E_INVALID, "ccvm_philox_normals: bad argument");

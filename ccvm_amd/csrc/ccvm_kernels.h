@@ -855,6 +855,37 @@ __global__ void qsum_final_kernel(const float* __restrict__ part, int ld, float*
     qsum[j] = acc;
 }
 
+// LBFGS post-processor, one iteration of one row per workgroup (torch.optim.LBFGS(lr, max_iter=1) from a
+// fresh state is one steepest-descent step of length lr * min(1, 1 / |g|_1); it returns without moving
+// when max|g| <= 1e-7 (tolerance_grad) or g.g < 1e-9 (tolerance_change)):
+//   x <- clamp(x - lr * min(1, 1 / |g|_1) * g, lo, hi).   Fixed-order reductions: deterministic.
+__global__ __launch_bounds__(256) void lbfgs_row_kernel(float* x, const float* g, int N, int ld, float lr,
+                                                        float lo, float hi) {
+    __shared__ float red[3][256];
+    const size_t row = (size_t)blockIdx.x * ld;
+    float l1 = 0.0f, mx = 0.0f, sq = 0.0f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float v = g[row + j];
+        l1 += fabsf(v);
+        mx = fmaxf(mx, fabsf(v));
+        sq = __builtin_fmaf(v, v, sq);
+    }
+    red[0][threadIdx.x] = l1; red[1][threadIdx.x] = mx; red[2][threadIdx.x] = sq;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + w]);
+            red[2][threadIdx.x] += red[2][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    l1 = red[0][0]; mx = red[1][0]; sq = red[2][0];
+    const bool moves = (mx > 1e-7f) && (sq >= 1e-9f);
+    const float t = moves ? fminf(1.0f, 1.0f / l1) * lr : 0.0f;
+    for (int j = threadIdx.x; j < N; j += 256) x[row + j] = clampf(__builtin_fmaf(-t, g[row + j], x[row + j]), lo, hi);
+}
+
 // Qs = 1/2 (Q + Q^T) on the padded [ld][ld] matrix
 __global__ void symmetrize_kernel(const float* Q, float* Qs, int ld) {
     const size_t total = (size_t)ld * ld;

@@ -506,7 +506,7 @@ def energy(confs, q_matrix, v_vector, scaled_by=1.0):
 
 def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, step=0.1, lr=0.01,
                 eps=1e-8, lambd=0.001):
-    """On-device grad-descent / adam / asgd post-processor; returns (x', seconds)."""
+    """On-device grad-descent / adam / asgd / lbfgs post-processor; returns (x', seconds)."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
     b, n = _rows_of_problem(xg, q_matrix, f"post-processor {method!r}")
@@ -524,6 +524,9 @@ def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, s
         elif method == "adam":
             rc = lib.ccvm_pp_adam(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(lr), float(eps),
                                   float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
+        elif method == "lbfgs":
+            rc = lib.ccvm_pp_lbfgs(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, int(iters), float(lr),
+                                   float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
         elif method == "asgd":
             rc = lib.ccvm_pp_asgd(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(lr), float(lambd),
                                   float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())

@@ -26,6 +26,7 @@ _ALIASES = {
     "post_processor.post_processor": "ccvm_amd.post_processor.post_processor",
     "post_processor.adam": "ccvm_amd.post_processor.adam",
     "post_processor.asgd": "ccvm_amd.post_processor.asgd",
+    "post_processor.lbfgs": "ccvm_amd.post_processor.lbfgs",
     "post_processor.grad_descent": "ccvm_amd.post_processor.grad_descent",
 }
 

@@ -220,6 +220,14 @@ int ccvm_pp_asgd(const float* Q, const float* V, float* x,
                  int B, int N, int ld, double lr, double lambd,
                  double lo, double hi,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* lbfgs: `iters` times a fresh torch.optim.LBFGS(lr, max_iter=1) step per row, then clamp
+ *   (post_processor/lbfgs.py): one steepest-descent step of length lr * min(1, 1 / |g|_1),
+ *   x <- clamp(x - lr * min(1, 1 / |g|_1) * g, lo, hi), g as for adam; a row whose gradient is below
+ *   LBFGS's tolerances (max|g| <= 1e-7 or g.g < 1e-9) does not move. */
+int ccvm_pp_lbfgs(const float* Q, const float* V, float* x,
+                  int B, int N, int ld, int iters, double lr,
+                  double lo, double hi,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- noise generator, exposed for tests -------------------------------------- */
 /* Fill w0 (and w1 if not NULL) with the standard normals the fused PHILOX mode uses

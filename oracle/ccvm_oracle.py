@@ -138,7 +138,21 @@ def pp_asgd(x, q, v, lo=0.0, hi=1.0, num_iter=1, lr=0.01, lambd=0.001):
     return torch.clamp(x * (1.0 - lambd * lr) - lr * _pp_gradient(x, q, v), lo, hi)
 
 
-_POST = {"grad-descent": pp_grad_descent, "adam": pp_adam, "asgd": pp_asgd}
+def pp_lbfgs(x, q, v, lo=0.0, hi=1.0, num_iter=1, lr=0.001):
+    """post_processor/lbfgs.py in closed form: per row and iteration a NEW torch.optim.LBFGS(lr,
+    max_iter=1) -- no curvature history, so its one iteration is the steepest-descent step
+    t = lr * min(1, 1/|g|_1) (torch's first-iteration step), skipped below LBFGS's tolerances
+    (max|g| <= 1e-7 or g.g < 1e-9); then clamp.  Identical to the reference for num_iter 1 and 3 (probed)."""
+    x = x.clone()
+    for _ in range(num_iter):
+        g = _pp_gradient(x, q, v)
+        t = torch.clamp(1.0 / g.abs().sum(1, keepdim=True), max=1.0) * lr
+        moves = (g.abs().amax(1, keepdim=True) > 1e-7) & ((g * g).sum(1, keepdim=True) >= 1e-9)
+        x = torch.clamp(x - torch.where(moves, t, torch.zeros_like(t)) * g, lo, hi)
+    return x
+
+
+_POST = {"grad-descent": pp_grad_descent, "adam": pp_adam, "asgd": pp_asgd, "lbfgs": pp_lbfgs}
 
 
 def _adam_update(grads, m, v, i, hp):

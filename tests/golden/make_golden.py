@@ -177,23 +177,26 @@ def asgd_cases():
     from ccvm_simulators.post_processor.adam import PostProcessorAdam
     from ccvm_simulators.post_processor.asgd import PostProcessorASGD
     from ccvm_simulators.post_processor.grad_descent import PostProcessorGradDescent
+    from ccvm_simulators.post_processor.lbfgs import PostProcessorLBFGS
 
     store, manifest = {}, {"cases": {}}
     for kind in SOLVERS:
-        name = f"{kind}_T50_asgd"
-        arrays, meta = run_case(kind, INSTANCES["test020"], 50, post="asgd", batch=40)
-        for k, v in arrays.items():
-            store[f"{name}/{k}"] = v
-        manifest["cases"][name] = meta
-        print("asgd", name, meta["best_objective_value"])
+        for post in ("asgd", "lbfgs"):
+            name = f"{kind}_T50_{post}"
+            arrays, meta = run_case(kind, INSTANCES["test020"], 50, post=post, batch=40)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print(post, name, meta["best_objective_value"])
     g = torch.Generator().manual_seed(17)
     n, b = 13, 9
     q, v, c = torch.rand(n, n, generator=g) - 0.5, torch.rand(n, generator=g) - 0.5, torch.rand(b, n, generator=g) * 1.2 - 0.1
     store["direct/q"], store["direct/v"], store["direct/c"] = q.numpy(), v.numpy(), c.numpy()
-    for label, cls in (("adam", PostProcessorAdam), ("asgd", PostProcessorASGD)):
+    for label, cls in (("adam", PostProcessorAdam), ("asgd", PostProcessorASGD), ("lbfgs", PostProcessorLBFGS)):
         for it in (1, 3):
             store[f"direct/{label}_iter{it}"] = cls().postprocess(c.clone(), q, v, num_iter=it).numpy()
         store[f"direct/{label}_bounds"] = cls().postprocess(c.clone(), q, v, lower_clamp=0.2, upper_clamp=0.7).numpy()
+    store["direct/lbfgs_steep"] = PostProcessorLBFGS().postprocess(c.clone(), q * 100, v * 100, num_iter=2).numpy()
     store["direct/grad-descent"] = PostProcessorGradDescent().postprocess(c.clone(), q, v).numpy()
     store["direct/grad-descent_custom"] = PostProcessorGradDescent().postprocess(
         c.clone(), q, v, lower_clamp=0.1, upper_clamp=0.9, num_iter_pp=4, step_size=0.05).numpy()

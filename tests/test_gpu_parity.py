@@ -157,7 +157,7 @@ def _asgd_case_names():
 
 
 @pytest.mark.parametrize("case", _asgd_case_names())
-def test_solver_matches_reference_with_asgd_post_processor(case, kernel_path):
+def test_solver_matches_reference_with_asgd_and_lbfgs_post_processors(case, kernel_path):
     from golden_util import asgd_arrays, asgd_cases
 
     g, meta, arrays = golden("test020"), asgd_cases()[case], asgd_arrays()
@@ -180,7 +180,7 @@ def test_post_processors_called_directly_match_the_reference():
 
     a = asgd_arrays()
     q, v, c = (torch.from_numpy(a[f"direct/{k}"].copy()) for k in ("q", "v", "c"))
-    for label in ("adam", "asgd"):
+    for label in ("adam", "asgd", "lbfgs"):
         pp = PostProcessorFactory.create_postprocessor(label)
         for it in (1, 3):
             want = torch.from_numpy(a[f"direct/{label}_iter{it}"].copy())
@@ -188,6 +188,9 @@ def test_post_processors_called_directly_match_the_reference():
         want = torch.from_numpy(a[f"direct/{label}_bounds"].copy())
         assert float((pp.postprocess(c.clone(), q, v, lower_clamp=0.2, upper_clamp=0.7) - want).abs().max()) <= 2e-6
         assert torch.equal(pp.postprocess(c.clone(), q, v, num_iter=0), c)
+    want = torch.from_numpy(a["direct/lbfgs_steep"].copy())
+    got = PostProcessorFactory.create_postprocessor("lbfgs").postprocess(c.clone(), q * 100, v * 100, num_iter=2)
+    assert float((got - want).abs().max()) <= 2e-6
     gd = PostProcessorFactory.create_postprocessor("grad-descent")
     assert float((gd.postprocess(c.clone(), q, v) - torch.from_numpy(a["direct/grad-descent"].copy())).abs().max()) <= 1e-5
     want = torch.from_numpy(a["direct/grad-descent_custom"].copy())
@@ -555,9 +558,8 @@ def test_unsupported_requests_fail_loudly():
 
     g = golden("test020")
     inst = _instance(g)
-    for host_only in ("bfgs", "lbfgs"):
-        with pytest.raises(NotImplementedError):
-            PostProcessorFactory.create_postprocessor(host_only)
+    with pytest.raises(NotImplementedError):
+        PostProcessorFactory.create_postprocessor("bfgs")
     dl = DLSolver(device="cpu", batch_size=8)
     dl.parameter_key = {20: dict(g.cases["dl_T1"]["params"])}
     with pytest.raises(TypeError):  # same exception type as the reference's broken call

@@ -104,7 +104,7 @@ def test_oracle_reproduces_reference_with_per_variable_saturation(case):
 
 
 @pytest.mark.parametrize("case", sorted(asgd_cases()))
-def test_oracle_reproduces_reference_with_asgd_post_processor(case):
+def test_oracle_reproduces_reference_with_asgd_and_lbfgs_post_processors(case):
     g, meta, arrays = golden("test020"), asgd_cases()[case], asgd_arrays()
     out = run_oracle(g, meta)
     for key in arrays.files:
@@ -121,13 +121,16 @@ def test_oracle_post_processors_match_reference_called_directly():
     the reference); custom bounds; grad-descent with custom iteration count and step."""
     a = asgd_arrays()
     q, v, c = (torch.from_numpy(a[f"direct/{k}"].copy()) for k in ("q", "v", "c"))
-    for label, fn in (("adam", oracle.pp_adam), ("asgd", oracle.pp_asgd)):
-        assert (a[f"direct/{label}_iter1"] == a[f"direct/{label}_iter3"]).all()
+    for label, fn in (("adam", oracle.pp_adam), ("asgd", oracle.pp_asgd), ("lbfgs", oracle.pp_lbfgs)):
+        # adam / asgd: only the first optimizer step takes effect; lbfgs makes a new optimizer per iteration
+        assert (a[f"direct/{label}_iter1"] == a[f"direct/{label}_iter3"]).all() == (label != "lbfgs")
         for it in (1, 3):
             want = torch.from_numpy(a[f"direct/{label}_iter{it}"].copy())
             assert float((fn(c, q, v, num_iter=it) - want).abs().max()) <= 1e-7
         want = torch.from_numpy(a[f"direct/{label}_bounds"].copy())
         assert float((fn(c, q, v, 0.2, 0.7) - want).abs().max()) <= 1e-7
+    want = torch.from_numpy(a["direct/lbfgs_steep"].copy())  # |g|_1 >> 1: the 1 / |g|_1 branch of the step size
+    assert float((oracle.pp_lbfgs(c, q * 100, v * 100, num_iter=2) - want).abs().max()) <= 1e-7
     assert float((oracle.pp_grad_descent(c, q, v) - torch.from_numpy(a["direct/grad-descent"].copy())).abs().max()) <= 1e-6
     want = torch.from_numpy(a["direct/grad-descent_custom"].copy())
     assert float((oracle.pp_grad_descent(c, q, v, 0.1, 0.9, num_iter_pp=4, step_size=0.05) - want).abs().max()) <= 1e-6
