@@ -109,6 +109,7 @@ class DLSolver(CCVMSolver):
         S = self._broadcast_saturation(self.S, problem_size)
         lo, hi = self.solution_bounds
 
+        self._select_algorithm(algorithm_parameters)  # validates the type before anything touches the GPU
         start = self._timer_start("dl", problem_size)
         samples_taken, evolution_file = self._begin_sampling(
             instance, batch_size, problem_size, iterations, evolution_step_size, evolution_file

@@ -112,6 +112,7 @@ class LangevinSolver(_LangevinFamily):
         )
         S = self._broadcast_saturation(S, problem_size)
 
+        self._select_algorithm(algorithm_parameters)  # validates the type before anything touches the GPU
         start = self._timer_start("langevin", problem_size, algorithm_parameters)
         samples_taken, evolution_file = self._begin_sampling(
             instance, batch_size, problem_size, iterations, evolution_step_size, evolution_file
@@ -186,6 +187,7 @@ class PumpedLangevinSolver(_LangevinFamily):
         )
         S = self._broadcast_saturation(S, problem_size)
 
+        self._select_algorithm(algorithm_parameters)  # validates the type before anything touches the GPU
         start = self._timer_start("langevin", problem_size, algorithm_parameters)
         samples_taken, evolution_file = self._begin_sampling(
             instance, batch_size, problem_size, iterations, evolution_step_size, evolution_file

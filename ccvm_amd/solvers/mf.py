@@ -124,6 +124,7 @@ class MFSolver(CCVMSolver):
         S = self._broadcast_saturation(S, problem_size)
         lo, hi = self.solution_bounds
 
+        self._select_algorithm(algorithm_parameters)  # validates the type before anything touches the GPU
         start = self._timer_start("mf", problem_size, algorithm_parameters)
         samples_taken, evolution_file = self._begin_sampling(
             instance, batch_size, problem_size, iterations, evolution_step_size, evolution_file

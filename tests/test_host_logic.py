@@ -201,3 +201,19 @@ def test_post_processor_factory_names():
         PostProcessorFactory.create_postprocessor("newton")
     with pytest.raises(TypeError, match="parameter c must be a tensor"):
         PostProcessorAdam().postprocess([1.0], torch.eye(1), torch.ones(1))
+
+
+def test_wrong_algorithm_parameters_type_is_rejected_before_the_engine_is_touched():
+    """`algorithm_parameters` of an unsupported type -> ValueError("Solver option type ... is not
+    supported.") as in the reference (dl_solver.py:924-927, mf_solver.py, langevin_solver.py) -- raised
+    by the host-side validation, so it is the same with or without a GPU."""
+    g = golden("test020")
+    from ccvm_amd.problem_classes.boxqp import ProblemInstance
+
+    keys = {"dl": "dl_T1", "mf": "mf_T1", "langevin": "langevin_T1", "pl": "pl_T1"}
+    for kind, cls in solvers().items():
+        inst = ProblemInstance.from_arrays(g.q(), g.v())
+        solver = cls(device="cpu", batch_size=4)
+        solver.parameter_key = {20: dict(g.cases[keys[kind]]["params"])}
+        with pytest.raises(ValueError, match="Solver option type <class 'str'> is not supported."):
+            solver(instance=inst, algorithm_parameters="adam")
