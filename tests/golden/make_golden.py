@@ -205,8 +205,47 @@ def asgd_cases():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
+def larger_n_cases():
+    """The reference on a problem larger than its shipped files (N = 96, dense synthetic, written to a
+    temporary .in file the reference parses itself): pins the oracle beyond N = 20 -- other einsum
+    blocking, several K chunks / column groups of the engine's small-N kernel."""
+    import tempfile
+
+    n = 96
+    g = torch.Generator().manual_seed(96)
+    a = torch.randn(n, n, generator=g) * 5
+    q_file = ((a + a.T) / 2 ** 0.5).double().numpy()   # maximisation form, as stored in .in files
+    v_file = (torch.randn(n, generator=g) * 17).double().numpy()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "synthetic096-100-96.in")
+        with open(path, "w") as fh:
+            fh.write("\t".join([str(n), "1.0", "1.0", "True", "0.0", "0.0", "96", "0"]) + "\n")
+            fh.write("\t".join(repr(float(x)) for x in v_file) + "\n")
+            for row in q_file:
+                fh.write("\t".join(repr(float(x)) for x in row) + "\n")
+        inst = ProblemInstance(instance_type="test", file_path=path, device="cpu")
+        store = {"q_matrix": inst.q_matrix.numpy().copy(), "v_vector": inst.v_vector.numpy().copy()}
+        manifest = {"cases": {}, "instance": {"problem_size": n, "optimal_sol": inst.optimal_sol,
+                                              "best_sol": inst.best_sol, "name": inst.name}}
+        rel = os.path.relpath(path, REFERENCE)
+        for kind in SOLVERS:
+            for adam in (None, "adamA") if kind != "dl" else (None,):
+                name = f"{kind}_T25" + (f"_{adam}" if adam else "")
+                arrays, meta = run_case(kind, rel, 25, adam=adam, batch=24)
+                for k, v in arrays.items():
+                    store[f"{name}/{k}"] = v
+                manifest["cases"][name] = meta
+                print("N=96", name, meta["best_objective_value"])
+    np.savez_compressed(os.path.join(OUT, "synthetic096.npz"), **store)
+    with open(os.path.join(OUT, "synthetic096.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
+    if "--only-larger-n" in sys.argv:
+        larger_n_cases()
+        return
     if "--only-asgd" in sys.argv:
         asgd_cases()
         return
@@ -267,6 +306,7 @@ def main():
     bounds_cases()
     vector_s_cases()
     asgd_cases()
+    larger_n_cases()
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TAGS = ("test020", "tuningH020")
+TAGS = ("test020", "tuningH020", "synthetic096")  # synthetic096: the reference on an N = 96 dense instance
 
 
 class Golden:
