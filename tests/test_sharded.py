@@ -60,7 +60,9 @@ def _worker(rank, world, port, batch, queue):
         solver, inst = _make(batch)
         torch.manual_seed(100 + rank)  # ranks disagree on purpose: rank 0's key must win
         sol = solve_sharded(solver, inst, gather_variables=True, local_solve=_oracle_local_solve)
-        queue.put((rank, sol.objective_values.clone(), sol.variables["problem_variables"].clone(),
+        # numpy copies: pickled by value (a torch tensor would travel as a shared-memory handle the
+        # parent may try to open after this process has gone)
+        queue.put((rank, sol.objective_values.numpy().copy(), sol.variables["problem_variables"].numpy().copy(),
                    sol.best_objective_value, sol.solution_performance, sol.batch_size, sol.shard,
                    solver.noise_seed))
     finally:
@@ -94,8 +96,8 @@ def test_sharded_solve_equals_unsharded(world, batch):
     for rank, obj, xs, best, perf, b, shard, _ in results:
         assert b == batch and shard["world"] == world and shard["rank"] == rank
         sizes.append(shard["rows"][1] - shard["rows"][0])
-        assert torch.equal(obj, whole.objective_values)          # exact: same global rows, same noise
-        assert torch.equal(xs, whole.variables["problem_variables"])
+        assert torch.equal(torch.from_numpy(obj), whole.objective_values)   # exact: same global rows, same noise
+        assert torch.equal(torch.from_numpy(xs), whole.variables["problem_variables"])
         assert best == whole.best_objective_value and perf == whole.solution_performance
     assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1
 
