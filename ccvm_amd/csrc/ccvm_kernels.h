@@ -103,6 +103,16 @@ __device__ __forceinline__ unsigned long long stamp_delta(unsigned long long a, 
 
 // Sixteenths of a step's noise units made in the prologue by the consumer / by the producer wave
 // (the remainder is spread over the main loop).  Tuned with tools/ablate.hip.
+// Wave priorities (s_setprio) of the producer / consumer waves, for tools/ablate.hip.  Both 0: while the
+// producers still made noise inside the main loop a raised producer priority paid; with the noise in the
+// prologue ANY producer priority above the consumers' costs ~1 us per step at N = 1000 (35.4 vs 34.5),
+// and a raised consumer priority changes nothing.
+#ifndef CCVM_CONSUMER_PRIO
+#define CCVM_CONSUMER_PRIO 0
+#endif
+#ifndef CCVM_PRODUCER_PRIO
+#define CCVM_PRODUCER_PRIO 0
+#endif
 #ifndef CCVM_NOISE_PROLOGUE_C
 #define CCVM_NOISE_PROLOGUE_C 8
 #endif
@@ -360,9 +370,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
 
     if (producer) {
         // =========================== producer waves ====================================
-        // Producers issue few instructions but each must get out promptly; at equal priority the
-        // SIMD arbiter favours the older (consumer) wave, which always has an MFMA pending.
-        __builtin_amdgcn_s_setprio(3);
+        if (CCVM_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(CCVM_PRODUCER_PRIO);
         // DMA pieces (1 KiB = one wave instruction) of a tile: 4 per A tile (8 rows x 128 B) then
         // 16 / KS of Q (1024 / (4 BNT) rows x 4 BNT B), dealt round-robin to the NPW producer waves.
         // LDS destination = piece base + lane * 16 (hardware); the A tile's swizzle (chunk c of row
@@ -527,6 +535,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     };
 
     FragsT f0, f1;
+    if (CCVM_CONSUMER_PRIO) __builtin_amdgcn_s_setprio(CCVM_CONSUMER_PRIO);
     if (gen_noise) {  // this thread's share of the noise, under the first tiles' flight time
 #pragma unroll
         for (int u = 0; u < NPRO_C; ++u) make_noise(u);
