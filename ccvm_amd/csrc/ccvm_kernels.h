@@ -114,10 +114,10 @@ __device__ __forceinline__ unsigned long long stamp_delta(unsigned long long a, 
 #define CCVM_PRODUCER_PRIO 0
 #endif
 #ifndef CCVM_NOISE_PROLOGUE_C
-#define CCVM_NOISE_PROLOGUE_C 8
+#define CCVM_NOISE_PROLOGUE_C 12
 #endif
 #ifndef CCVM_NOISE_PROLOGUE_P
-#define CCVM_NOISE_PROLOGUE_P 8
+#define CCVM_NOISE_PROLOGUE_P 4
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -202,8 +202,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // idle anyway: units [0, NPRO_C) by the consumer, [NPRO_C, NPRO_C + NPRO_P) by the producer
     // after it has issued the first NSTAGE tiles, the rest (if any) one per main-loop iteration.
     constexpr int NUNIT = ((MODE == MODE_DL) ? 16 : 8) / KS;  // noise work units per lane and step
-    constexpr int NPRO_C = NUNIT * CCVM_NOISE_PROLOGUE_C / 16;
-    constexpr int NPRO_P = NUNIT * CCVM_NOISE_PROLOGUE_P / 16;
+    // split tuned on the same box (tools/ablate.hip, bench.py): 12/4 for the 32 x 128 tiles (N = 1000:
+    // -0.3 us against 8/8), an even split for the short 32 x 64 split-K kernels
+    constexpr int NPRO_C = NUNIT * (KS == 1 ? CCVM_NOISE_PROLOGUE_C : 8) / 16;
+    constexpr int NPRO_P = NUNIT * (KS == 1 ? CCVM_NOISE_PROLOGUE_P : 8) / 16;
     static_assert(NPRO_C + NPRO_P <= NUNIT, "noise split");
     auto make_noise = [&](int u) {
         if constexpr (NOISY && !(ABL & 64)) {
