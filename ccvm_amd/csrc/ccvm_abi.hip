@@ -112,7 +112,10 @@ void set_grid(StepArgs& a, int ks) {
             if (per % xc || a.ncb % xc) continue;
             const int xr = per / xc;
             if (xr > a.nrb || a.nrb % xr || (a.nrb / xr) * (a.ncb / xc) != 8) continue;
-            const long cost = 2L * xr + (4L / ks) * xc;
+            long cost = 2L * xr + (4L / ks) * xc;
+            if (const char* f = std::getenv("CCVM_AMD_XCD_XC")) {  // tuning: force the rectangle's width
+                if (std::atoi(f) == xc) cost = 0;
+            }
             if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
         }
     }
