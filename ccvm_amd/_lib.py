@@ -21,7 +21,8 @@ from ctypes import (
 )
 
 LIB_NAME = "libccvm_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
+LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 ABI_VERSION = 2
 
 NOISE_PHILOX = 0

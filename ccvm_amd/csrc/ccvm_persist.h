@@ -214,7 +214,46 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         float af[16 * NCH / KC];
 #pragma unroll
         for (int c = 0; c < 16 * NCH / KC; ++c) af[c] = xb[c * KC];
-        __builtin_amdgcn_sched_barrier(0);  // all reads in flight before the first MFMA (one latency, not NCH)
+        __builtin_amdgcn_sched_barrier(0);  // all reads in flight before anything else (one latency, not NCH)
+        // ---- this step's normals -- DL: (W_c, W_s) per element; MF: the NEXT step's; Langevin: this step's.
+        // One-wave row sets make them HERE, while the A reads are in flight (they do not depend on them:
+        // DL N=20 0.53 -> 0.46 us/step, N=64 0.63 -> 0.56); with two or four waves side by side the same
+        // order was 3-12 % slower (same-box A/B), so those make them after the contraction.
+        constexpr bool NOISE_FIRST = (NCG == 1);
+        float nz0[NE], nz1[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.0f;
+        auto make_step_noise = [&]() {
+            if constexpr (MODE == MODE_DL) {
+                if (a.replay) {
+    #pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const size_t w = ((size_t)it * N + col) * a.B + brow[e];
+                        nz0[e] = ok[e] ? a.w0[w] : 0.0f;
+                        nz1[e] = ok[e] ? a.w1[w] : 0.0f;
+                    }
+                } else {
+                    if constexpr (CCVM_PERSIST_ABL & 2) {
+    #pragma unroll
+                        for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.25f;
+                    } else if constexpr (NE == 2) {  // two generator calls in lockstep
+                        NormalPair pa, pb;
+                        normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
+                        nz0[0] = pa.n0; nz1[0] = pa.n1; nz0[1] = pb.n0; nz1[1] = pb.n1;
+                    } else {
+                        const NormalPair p = normal_pair(a.seed, a.row_offset + brow[0], step, col);
+                        nz0[0] = p.n0;
+                        nz1[0] = p.n1;
+                    }
+                }
+            } else if constexpr (MODE == MODE_MF) {
+                if (reinterpret_cast<const MfScalars*>(trow)->has_next) stream_normals(step + 1, it + 1, nz0);
+            } else {
+                stream_normals(step, it, nz0);
+            }
+        };
+        if constexpr (NOISE_FIRST) make_step_noise();
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(CCVM_PERSIST_ABL & 1)) {
             mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, 16 * NCH>{});
         } else {
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
+        if constexpr (!NOISE_FIRST) make_step_noise();
         float qx[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -249,49 +289,24 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         // ---- update ------------------------------------------------------------------------------
         // The elements of a lane are independent dependency chains and this wave is usually alone on
         // its SIMD (a dependent VALU instruction issues every ~8 cycles, an independent one every 4):
-        // noise for all elements first, then all updates, branch-free, so the scheduler interleaves them.
+        // all updates together, branch-free, so the scheduler interleaves them.
         if constexpr (MODE == MODE_DL) {
             const DlScalars k = *reinterpret_cast<const DlScalars*>(trow);
-            float n0[NE], n1[NE];
-            if (a.replay) {
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const size_t w = ((size_t)it * N + col) * a.B + brow[e];
-                    n0[e] = ok[e] ? a.w0[w] : 0.0f;
-                    n1[e] = ok[e] ? a.w1[w] : 0.0f;
-                }
-            } else {
-                if constexpr (CCVM_PERSIST_ABL & 2) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) n0[e] = n1[e] = 0.25f;
-                } else if constexpr (NE == 2) {  // two generator calls in lockstep
-                    NormalPair pa, pb;
-                    normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
-                    n0[0] = pa.n0; n1[0] = pa.n1; n0[1] = pb.n0; n1[1] = pb.n1;
-                } else {
-                    const NormalPair p = normal_pair(a.seed, a.row_offset + brow[0], step, col);
-                    n0[0] = p.n0;
-                    n1[0] = p.n1;
-                }
-            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 float cn, sn;
                 if constexpr (CCVM_PERSIST_ABL & 4) {
-                    cn = s0[e] + qx[2 * e] * n0[e];
-                    sn = s1[e] + qx[2 * e + 1] * n1[e];
+                    cn = s0[e] + qx[2 * e] * nz0[e];
+                    sn = s1[e] + qx[2 * e + 1] * nz1[e];
                 } else {
-                    dl_update(k, s0[e], s1[e], qx[2 * e], qx[2 * e + 1], vj, n0[e], n1[e], cn, sn);
+                    dl_update(k, s0[e], s1[e], qx[2 * e], qx[2 * e + 1], vj, nz0[e], nz1[e], cn, sn);
                 }
                 s0[e] = ok[e] ? cn : s0[e];
                 s1[e] = ok[e] ? sn : s1[e];
             }
         } else if constexpr (MODE == MODE_MF) {
             const MfScalars k = *reinterpret_cast<const MfScalars*>(trow);
-            float wn[NE];
-#pragma unroll
-            for (int e = 0; e < NE; ++e) wn[e] = 0.0f;
-            if (k.has_next) stream_normals(step + 1, it + 1, wn);
+            const float* wn = nz0;  // the next step's normals
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const float bound = a.s_cols ? sat_j : k.S;
@@ -307,8 +322,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             }
         } else {
             const LvScalars k = *reinterpret_cast<const LvScalars*>(trow);
-            float n0[NE];
-            stream_normals(step, it, n0);
+            const float* n0 = nz0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const float g = adam(__builtin_fmaf(k.g_q, qx[e], k.g_v * vj) * inv_sat_j, e);
