@@ -259,7 +259,11 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // he2/he3: Adam moments; hcar: MF's normals of this step.
     // The new state is written once and next read by the following launch (mostly from other CUs):
     // non-temporal stores shorten the drain of the tail (-0.5 us per step at the headline shape).
+#ifdef CCVM_ABL_NO_STORES  // tools/ablate.hip: the epilogue's arithmetic without its stores
+    auto st_nt = [](float* p, float x) { if (x == 123.456f) __builtin_nontemporal_store(x, p); };
+#else
     auto st_nt = [](float* p, float x) { __builtin_nontemporal_store(x, p); };
+#endif
     auto run_epilogue = [&](const float (&hf)[NA][H], const float (&he0)[H], const float (&he1)[H],
                             const float (&he2)[H], const float (&he3)[H], const float (&hcar)[H], int ibase) {
         // every operand is already in registers, so each result is stored as soon as it is
