@@ -114,11 +114,18 @@ def cpu_baseline(kind, n, b, total_steps, budget_s=12.0):
         done += 5
     dt = time.time() - t0
     steps = done - 2
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {
         "value": b * steps / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"{steps} steps of the same workload (N={n}, batch={b}) with the torch-CPU oracle "
                   f"(bit-identical to the reference's CPU path), {dt / steps * 1e3:.1f} ms/step, "
-                  f"{torch.get_num_threads()} torch threads",
+                  f"{torch.get_num_threads()} torch threads on {model} ({len(os.sched_getaffinity(0))} cores visible), "
+                  f"torch {torch.__version__}",
     }
 
 
