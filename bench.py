@@ -1,19 +1,30 @@
-"""Headline benchmark: SDE row-steps/s of the DL-CCVM inner loop on MI355X.
+"""Headline benchmark: SDE row-steps/s of the CCVM inner loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload W] [--post adam]
 
-A "step" is one fused Euler-Maruyama update of every batch row.  Workload (BASELINE.json
-`metric`): DL-CCVM, N = 1000 synthetic dense BoxQP, batch 1000 PER GPU (weak scaling: the
-8-GPU run is BASELINE config 4, batch 8000 sharded 1000/GPU), fp32, fused Philox noise.
-Ranks are independent (batch rows never interact); the only collective is one RCCL
-all-gather of the final objective values, outside the timed region like the reference's
-own timer (dl_solver.py:851/933 brackets the loop only).
+A "step" is one fused Euler-Maruyama update of every batch row.  Default workload (BASELINE.json
+`metric`): DL-CCVM, N = 1000 synthetic dense BoxQP, batch 1000 PER GPU (weak scaling: the 8-GPU run
+is BASELINE config 4, batch 8000 sharded 1000/GPU), fp32, fused counter-based noise.
+`--workload pl_n2000_b512 --post adam` is BASELINE config 5 (pumped Langevin N = 2000, 512 rows per
+GPU, on-device Adam post-processor after the loop).
 
-Prints ONE JSON line on rank 0.
+Ranks are independent (batch rows never interact); the only collective is one all-gather of the
+final objective values (RCCL), outside the timed region like the reference's own timer
+(dl_solver.py:851/933 brackets the loop only).
+
+Launching: `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a
+launcher: it starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set)
+before anything touches the GPU, waits for them and exits with the worst return code.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the environment is already
+there and the process is a rank.  CCVM_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box): every rank uses
+cuda:0 and the collectives run over gloo on host copies.
+
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,106 +37,151 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
 PEAK_HBM_GBS = 8000.0
 
-
-def measured_traffic(workload):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_bench_pmc.json: separate FETCH_SIZE and WRITE_SIZE runs of this same command;
-    gfx950 correction: FETCH_SIZE counts half of a wide coalesced read, so it is doubled).
-    None when no profile of this workload is committed."""
-    import glob
-
-    if workload != "dl_n1000_b1000":
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.json")))
-    if not files:
-        return None
-    with open(files[-1]) as fh:
-        c = json.load(fh)["counters"]
-    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-        return None
-    kib = 2.0 * c["FETCH_SIZE"]["mean_per_dispatch"] + c["WRITE_SIZE"]["mean_per_dispatch"]
-    return kib * 1024.0
-
-
-def measured_mfma_busy(workload):
-    """Fraction of the kernel's cycles in which the matrix pipes were busy, from the committed SQ
-    counter pass (profiles/r*_bench_pmc.json): SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs,
-    SQ_BUSY_CYCLES over the 32 shader engines (its per-engine value is the kernel's length in cycles)."""
-    import glob
-
-    if workload != "dl_n1000_b1000":
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.json")))
-    if not files:
-        return None
-    with open(files[-1]) as fh:
-        c = json.load(fh)["counters"]
-    if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "SQ_BUSY_CYCLES" not in c:
-        return None
-    return (c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 1024.0) / (c["SQ_BUSY_CYCLES"]["mean_per_dispatch"] / 32.0)
-
 WORKLOADS = {
-    # name: (solver kind, N, batch per GPU, flops per row-step)
+    # name: (solver kind, N, batch per GPU)
     "dl_n1000_b1000": ("dl", 1000, 1000),
     "dl_n100_b1000": ("dl", 100, 1000),
     "mf_n500_b1000": ("mf", 500, 1000),
     "langevin_n500_b1000": ("langevin", 500, 1000),
     "pl_n2000_b512": ("pl", 2000, 512),
 }
+SOLVER_ID = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
+SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example scripts' S (workloads.py)
+
+
+# --------------------------------------------------------------------------- #
+# launcher (no GPU call may happen in this process before the ranks are started)
+# --------------------------------------------------------------------------- #
+def launch_ranks(n, argv):
+    import socket
+
+    share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
+    visible = torch.cuda.device_count()  # counts devices without creating a HIP context
+    if visible < n and not share:
+        raise SystemExit(f"bench.py --gpus {n}: only {visible} GPU(s) visible "
+                         "(CCVM_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU over gloo)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    worst, deadline = 0, time.time() + float(os.environ.get("CCVM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the rank this launcher started
+            p.wait()
+            rc = 124
+        worst = max(worst, abs(rc))
+    return worst
+
+
+# --------------------------------------------------------------------------- #
+def profiled_counters(workload):
+    """Counters of the dominant kernel from the COMMITTED rocprofv3 --pmc passes of this same
+    command (profiles/r*_<workload>_pmc.json, written by tools/pmc_summary.py).  They are NOT
+    measured by this run -- PMC collection needs separate profiler passes -- and are reported in a
+    sub-object that says so.  gfx950 correction: FETCH_SIZE counts half of a wide coalesced read, so
+    HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM)."""
+    import glob
+
+    stem = "bench" if workload == "dl_n1000_b1000" else workload
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{stem}_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        doc = json.load(fh)
+    c = doc["counters"]
+    out = {"source": os.path.relpath(files[-1], ROOT), "measured_by_this_run": False,
+           "kernel": doc.get("kernel"), "command": doc.get("command")}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["traffic_bytes_per_launch"] = 1024.0 * (2.0 * c["FETCH_SIZE"]["mean_per_dispatch"]
+                                                    + c["WRITE_SIZE"]["mean_per_dispatch"])
+        out["dispatches"] = c["FETCH_SIZE"]["dispatches"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        # MFMA_BUSY is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (its
+        # per-engine value is the kernel's length in cycles)
+        out["mfma_busy_frac"] = (c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 1024.0) / \
+                                (c["SQ_BUSY_CYCLES"]["mean_per_dispatch"] / 32.0)
+    return out
+
+
+def workload_params(kind):
+    from ccvm_amd.workloads import EXAMPLE_PARAMS
+
+    p = dict(EXAMPLE_PARAMS[kind])
+    if kind == "dl":
+        p["g"] = 0.05
+    elif kind == "mf":
+        p["g"] = 0.01
+    else:
+        p["use_pump"] = kind == "pl"
+    return p
 
 
 def make_trajectories(kind, n, b, total_steps, rank, seed=1):
     from ccvm_amd import engine
-    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from ccvm_amd.workloads import scaled_qv
 
     q, v, _ = scaled_qv(n, kind)
     prob = engine.DeviceProblem(q, v)
-    p = dict(EXAMPLE_PARAMS[kind])
-    noise = engine.NoiseSpec(mode="philox", seed=seed, row_offset=rank * b)
-    if kind == "dl":
-        p["g"] = 0.05
-        return engine.Trajectories(prob, b, "dl", total_steps, p, (0.0, 1.0), noise), q, v
-    if kind == "mf":
-        p["g"] = 0.01
-        return engine.Trajectories(prob, b, "mf", total_steps, p, (0.0, 1.0), noise), q, v
-    p["use_pump"] = kind == "pl"
-    return engine.Trajectories(prob, b, "langevin", total_steps, p, (0.0, 1.0), noise), q, v
+    noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=rank * b)
+    ekind = {"dl": "dl", "mf": "mf"}.get(kind, "langevin")
+    return engine.Trajectories(prob, b, ekind, total_steps, workload_params(kind), (0.0, 1.0), noise), q, v
 
 
-def cpu_baseline(kind, n, b, total_steps, budget_s=12.0):
-    """The oracle (torch CPU restatement of the reference loop, bit-identical to it on this
-    torch build) timed on the host cores on a bounded sample of the same workload."""
-    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            return next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
+    except (OSError, StopIteration):
+        return "unknown CPU"
+
+
+def cpu_baseline(kind, n, b, total_steps, budget_s=12.0, threads=None):
+    """The oracle (torch CPU restatement of the reference loop, bit-identical to it on this torch
+    build) timed on the host cores on a bounded sample of the same workload.  Threads: a 1-GPU box
+    exposes a 16-core CPU share of the host; profiles/r02_cpu_thread_sweep.md holds the 1..64-thread
+    sweep behind the default (more threads than the share only oversubscribe)."""
+    from ccvm_amd.workloads import scaled_qv
     from oracle import ccvm_oracle as oracle
 
-    assert kind == "dl"
-    # a 1-GPU box exposes a 16-core CPU share; more torch threads than that only oversubscribe
-    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    visible = len(os.sched_getaffinity(0))
+    torch.set_num_threads(max(1, threads or min(16, visible)))
     q, v, _ = scaled_qv(n, kind)
-    p = EXAMPLE_PARAMS[kind]
+    p = workload_params(kind)
     torch.manual_seed(1)
-    c = torch.zeros((b, n)); s = torch.zeros((b, n))
-    run = lambda step0, k: oracle.dl_loop(q, v, b, total_steps, p["pump"], p["dt"], p["noise_ratio"],
-                                          p["feedback_scale"], 0.05, (0.0, 1.0), True, None, step0, k, c, s)
+    bounds = (0.0, 1.0)
+    if kind == "dl":
+        c = torch.zeros((b, n)); s = torch.zeros((b, n))
+        run = lambda step0, k: oracle.dl_loop(q, v, b, total_steps, p["pump"], p["dt"], p["noise_ratio"],
+                                              p["feedback_scale"], p["g"], bounds, True, None, step0, k, c, s)
+    else:
+        # the other loops run whole trajectories: time short runs of the same per-step work
+        def run(step0, k):
+            if kind == "mf":
+                oracle.mf_loop(q, v, b, k, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], p["g"], bounds)
+            elif kind == "langevin":
+                oracle.langevin_loop(q, v, b, k, p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
+            else:
+                oracle.pl_loop(q, v, b, k, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
     run(0, 2)  # warm-up (first-call overheads)
     done, t0 = 2, time.time()
-    while time.time() - t0 < budget_s and done + 5 <= total_steps:
+    while time.time() - t0 < budget_s and done + 5 <= max(total_steps, 12):
         run(done, 5)
         done += 5
     dt = time.time() - t0
     steps = done - 2
-    model = "unknown CPU"
-    try:
-        with open("/proc/cpuinfo") as fh:
-            model = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
-    except (OSError, StopIteration):
-        pass
     return {
         "value": b * steps / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"{steps} steps of the same workload (N={n}, batch={b}) with the torch-CPU oracle "
                   f"(bit-identical to the reference's CPU path), {dt / steps * 1e3:.1f} ms/step, "
-                  f"{torch.get_num_threads()} torch threads on {model} ({len(os.sched_getaffinity(0))} cores visible), "
-                  f"torch {torch.__version__}",
+                  f"{torch.get_num_threads()} torch threads on {cpu_model()} ({visible} cores visible to this "
+                  f"process), torch {torch.__version__}",
     }
 
 
@@ -161,6 +217,16 @@ def tts99_leg():
     }
 
 
+def describe_launch(kind, b, n):
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.load().ccvm_describe_launch(SOLVER_ID[kind], b, n, 0, 0, buf, 256), "ccvm_describe_launch")
+    return buf.value.decode()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,19 +238,26 @@ def main():
                          "burst from idle measures the ramp, 42 us/step, not the 36 us/step a real 1500-15000 "
                          "step solve runs at)")
     ap.add_argument("--workload", default="dl_n1000_b1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--post", default=None, choices=["adam", "grad-descent"],
+                    help="run this on-device post-processor on the final variables (after the timed loop, like "
+                         "the reference's pp_time) before they are scored: BASELINE config 5 = "
+                         "--workload pl_n2000_b512 --post adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="torch threads of the cpu_baseline leg")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # this process never touches the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
 
-    # CCVM_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box): every rank uses cuda:0 and the collectives
-    # run over gloo on host copies; the real multi-GPU run is one rank per GPU over RCCL ("nccl").
     share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
@@ -217,6 +290,7 @@ def main():
     traj.advance(args.warmup)
     torch.cuda.synchronize(dev)
     barrier()
+    # HIP events on the stream the engine launches on (torch's current stream: engine._stream_ptr)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -226,41 +300,45 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg per step launch on the launch stream
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # stream time of the timed region / steps
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # the step right after the loop + the one collective: gather objective values (RCCL)
-    from ccvm_amd import engine
+    # the steps right after the loop (device-side finalize: clamp, change of variables, optional
+    # post-processor, energy) + the one collective: all-gather of the objective values (RCCL)
     from ccvm_amd.workloads import scaled_qv
 
+    _, _, f = scaled_qv(n, kind)
+    pp_seconds = 0.0
     if kind == "dl":
         traj.clamp("c", -1.0, 1.0)
-        x = engine.change_variables(traj.compact("c"), 1.0, 0.0, 1.0)
-    elif kind == "mf":
-        x = engine.change_variables(traj.compact("mu_tilde"), 20.0, 0.0, 1.0)
-    else:
-        x = engine.change_variables(traj.compact("c"), 0.5, 0.0, 1.0)
-    _, _, f = scaled_qv(n, kind)
-    obj = engine.energy(x, q, v, float(f))
+    name = "mu_tilde" if kind == "mf" else "c"
+    obj, pp_seconds = traj.score(name, SATURATION[kind], float(f), post_processor=args.post)
     finite = bool(torch.isfinite(obj).all().item())
+    ranks_seen = 1
     if world > 1:
         obj = obj.to(comm_dev)
         gathered = [torch.empty_like(obj) for _ in range(world)]
         dist.all_gather(gathered, obj)
         obj = torch.cat(gathered)
+        ranks_seen = dist.get_world_size()
     best = float((-obj).max().item())
 
     if rank == 0:
         na = 2 if kind == "dl" else 1
-        flops_per_launch = 2.0 * na * n * n * b
-        bytes_per_launch = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        launch = describe_launch(kind, b, n)
+        steps_per_launch = min(args.steps, 4096) if "persist_kernel" in launch else 1
+        flops_per_step = 2.0 * na * n * n * b
+        bytes_per_step = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
+        achieved = flops_per_step / (gpu_ms_per_step * 1e-3) / 1e12
+        metric = "SDE row-steps/s (Euler-Maruyama steps/s x batch)"
+        if args.workload == "dl_n1000_b1000":
+            metric += ", DL-CCVM N=1000 batch=1000 per GPU"
         out = {
-            "metric": "SDE row-steps/s (Euler-Maruyama steps/s x batch), DL-CCVM N=1000 batch=1000 per GPU",
+            "metric": metric,
             "value": args.steps * b * world / elapsed,
             "unit": "row-steps/s",
             "n_gpus": world,
@@ -273,33 +351,47 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "spinup_ms": args.spinup_ms,
+            "n_ranks_seen": ranks_seen,
             "config": {
                 "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
                             f"batch {b} per GPU x {world} GPU, fp32 state, fused Threefry noise, "
-                            f"schedule of a {total}-step run",
+                            f"schedule of a {total}-step run"
+                            + (f", {args.post} post-processor on device after the loop" if args.post else ""),
                 "global_batch": b * world,
-                "parallelism": f"batch-sharded x{world}, no data-path collective",
+                "parallelism": f"batch-sharded x{world}, no data-path collective; one all-gather of "
+                               f"{b * world} objective values after the loop "
+                               f"({'gloo rehearsal on one GPU' if share else 'RCCL' if world > 1 else 'single rank'})",
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
-                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
-                "algorithmic_bytes": bytes_per_launch, "algorithmic_flops": flops_per_launch,
-                "mfma_busy_frac": measured_mfma_busy(args.workload),
-                "kernel": "ccvm::step_kernel<MODE_DL>" if kind == "dl" else "ccvm::step_kernel",
-                "avg_launch_us": kernel_ms * 1e3,
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None,  # HBM bytes need separate rocprofv3 --pmc passes: see "profiled"
+                "algorithmic_bytes": bytes_per_step * steps_per_launch,
+                "algorithmic_flops": flops_per_step * steps_per_launch,
+                "kernel": launch,
+                "steps_per_launch": steps_per_launch,
+                "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch,
+                "avg_step_us": gpu_ms_per_step * 1e3,
+                "timing": "HIP events on the launch stream around the timed region / launches in it",
                 "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
                              "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip)",
-                "hbm_algorithmic_GBps": bytes_per_launch / (kernel_ms * 1e-3) / 1e9,
-                "hbm_frac": bytes_per_launch / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
+                "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
-            "check": {"objective_values_finite": finite, "best_objective_value": best},
+            "check": {"objective_values_finite": finite, "best_objective_value": best,
+                      "post_processor": args.post, "pp_seconds": pp_seconds},
         }
+        prof = profiled_counters(args.workload)
+        if prof is not None:
+            out["roofline"]["profiled"] = prof
+            out["roofline"]["traffic"] = prof.get("traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = (f"{prof['source']}: separate rocprofv3 --pmc passes of this command "
+                                                 f"({prof.get('dispatches')} dispatches), NOT measured by this run")
         if world == 1 and args.workload == "dl_n1000_b1000":
             out["tts99"] = tts99_leg()
-        if world == 1 and kind == "dl" and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, n, b, total)
-        print(json.dumps(out))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, n, b, total, threads=args.cpu_threads)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

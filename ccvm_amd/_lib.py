@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -108,6 +108,31 @@ class LangevinParams(Structure):
     ]
 
 
+class FinalizeParams(Structure):
+    _fields_ = [
+        ("S", c_double),
+        ("s_cols", c_void_p),
+        ("s_full", c_void_p),
+        ("lower", c_double),
+        ("upper", c_double),
+        ("clamp_lo", c_double),
+        ("clamp_hi", c_double),
+        ("scaled_by", c_double),
+        ("optimal_value", c_double),
+        ("clamp", c_int32),
+        ("change_variables", c_int32),
+    ]
+
+
+class SolutionStats(Structure):
+    _fields_ = [
+        ("best_objective_value", c_float),
+        ("within", c_int32 * 7),
+        ("rows", c_int32),
+        ("nonfinite", c_int32),
+    ]
+
+
 _P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 # name -> (restype, argtypes); the single source of truth checked against the header
@@ -121,6 +146,7 @@ SIGNATURES = {
     "ccvm_unpack": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "ccvm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_workspace_bytes_cols": (c_size_t, [c_int, c_int, c_int]),
+    "ccvm_describe_launch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_size_t]),
     "ccvm_dl_run": (
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -140,7 +166,13 @@ SIGNATURES = {
     "ccvm_change_variables": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     "ccvm_clamp_cols": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "ccvm_change_variables_cols": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P]),
+    "ccvm_clamp_full": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "ccvm_change_variables_full": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_double, c_double, _P]),
     "ccvm_energy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
+    "ccvm_objective_stats": (c_int, [_P, c_int, c_double, _P, _P]),
+    "ccvm_finalize": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_int, POINTER(FinalizeParams), _P, _P, _P, c_size_t, _P]
+    ),
     "ccvm_feedback": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, c_size_t, _P]
     ),

@@ -81,9 +81,67 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
     s.add_assign = ad->add_assign;
 }
 
-void set_grid(StepArgs& a, int ks);
+// Tuning knobs from the environment (tests / profiling only), read ONCE per ABI call: the per-step
+// launch loop never touches environ (getenv is a linear scan, and not safe against a concurrent
+// setenv from another host thread).
+//   CCVM_AMD_KERNEL=tile      force the per-step tile kernel where the persistent kernel would apply
+//   CCVM_AMD_KS=1|2           force the tile shape (32 x 128 / 32 x 64 split-K)
+//   CCVM_AMD_XCD=0            linear block -> tile map instead of the XCD rectangles
+//   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
+//   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
+struct Tuning {
+    bool force_tile = false;
+    int ks = 0;          // 0: choose by grid size
+    bool xcd = true;
+    int xcd_xc = 0;      // 0: choose by L2 footprint
+    int persist_ru = 0;  // 0: choose by batch size
+};
 
-void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld) {
+Tuning read_tuning() {
+    Tuning t;
+    if (const char* e = std::getenv("CCVM_AMD_KERNEL")) t.force_tile = !std::strcmp(e, "tile");
+    if (const char* e = std::getenv("CCVM_AMD_KS"))
+        if (e[0] == '1' || e[0] == '2') t.ks = e[0] - '0';
+    if (const char* e = std::getenv("CCVM_AMD_XCD")) t.xcd = e[0] != '0';
+    if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
+        if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
+    return t;
+}
+
+// Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
+// a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).
+int choose_ks(int B, int N, const Tuning& tun) {
+    if (tun.ks) return tun.ks;
+    const int tiles = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return tiles <= 128 ? 2 : 1;
+}
+
+// Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
+// (nrb/xr) * (ncb/xc) = 8, minimising the L2 footprint  xr * (bytes of an A row block) + xc * (bytes
+// of a Q column panel).
+void set_grid(StepArgs& a, const Tuning& tun) {
+    const int ks = a.ks;
+    a.nrb = (a.B + BM - 1) / BM;
+    a.ncb = (a.N + BN / ks - 1) / (BN / ks);
+    a.xr = a.xc = 0;
+    const int total = a.nrb * a.ncb;
+    if (total % 8 == 0 && tun.xcd) {
+        const int per = total / 8;
+        long best = -1;
+        for (int xc = 1; xc <= a.ncb; ++xc) {
+            if (per % xc || a.ncb % xc) continue;
+            const int xr = per / xc;
+            if (xr > a.nrb || a.nrb % xr || (a.nrb / xr) * (a.ncb / xc) != 8) continue;
+            long cost = 2L * xr + (4L / ks) * xc;
+            if (tun.xcd_xc == xc) cost = 0;  // tuning: force the rectangle's width
+            if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
+        }
+    }
+}
+
+// Everything of a launch that does not change from step to step: operands, tile shape and grid.
+void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun) {
     std::memset(&a, 0, sizeof(a));
     a.Q = Q;
     a.V = V;
@@ -93,32 +151,8 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
     a.qsum = V;  // any valid array while in_shift == 0
-    set_grid(a, 1);
-}
-
-// Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
-// (nrb/xr) * (ncb/xc) = 8, minimising the L2 footprint  xr * (bytes of an A row block) + xc * (bytes
-// of a Q column panel).  CCVM_AMD_XCD=0 disables the rectangles (linear fallback).
-void set_grid(StepArgs& a, int ks) {
-    a.nrb = (a.B + BM - 1) / BM;
-    a.ncb = (a.N + BN / ks - 1) / (BN / ks);
-    a.xr = a.xc = 0;
-    const int total = a.nrb * a.ncb;
-    const char* e = std::getenv("CCVM_AMD_XCD");
-    if (total % 8 == 0 && !(e && e[0] == '0')) {
-        const int per = total / 8;
-        long best = -1;
-        for (int xc = 1; xc <= a.ncb; ++xc) {
-            if (per % xc || a.ncb % xc) continue;
-            const int xr = per / xc;
-            if (xr > a.nrb || a.nrb % xr || (a.nrb / xr) * (a.ncb / xc) != 8) continue;
-            long cost = 2L * xr + (4L / ks) * xc;
-            if (const char* f = std::getenv("CCVM_AMD_XCD_XC")) {  // tuning: force the rectangle's width
-                if (std::atoi(f) == xc) cost = 0;
-            }
-            if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
-        }
-    }
+    a.ks = choose_ks(B, N, tun);
+    set_grid(a, tun);
 }
 
 // Column sums of Q into `area` ((QSUM_SLICES + 1) * ld floats); returns the qsum pointer.
@@ -157,19 +191,9 @@ void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N
     }
 }
 
-// Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
-// a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).  CCVM_AMD_KS=1|2 forces one.
-int choose_ks(int B, int N) {
-    const char* e = std::getenv("CCVM_AMD_KS");
-    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
-    const int tiles = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
-    return tiles <= 128 ? 2 : 1;
-}
-
 template <int MODE, bool ADAM>
-int launch_step(StepArgs a, hipStream_t st, const char* name) {
-    const int ks = choose_ks(a.B, a.N);
-    set_grid(a, ks);
+int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
+    const int ks = a.ks;
     const int grid = a.nrb * a.ncb;
     constexpr bool CAN_VS = (MODE == MODE_MF || MODE == MODE_LANGEVIN);
     if (CAN_VS && a.s_cols) {  // per-variable saturation
@@ -192,12 +216,9 @@ int launch_step(StepArgs a, hipStream_t st, const char* name) {
 constexpr int TABLE_STEPS = 4096;  // steps per persistent launch (schedule table rows in the workspace)
 size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float); }
 
-// CCVM_AMD_KERNEL=tile|persist forces a path (tests / profiling); default: persistent when it applies.
-bool want_persist(int N) {
-    if (N > PERSIST_MAX_N) return false;
-    const char* e = std::getenv("CCVM_AMD_KERNEL");  // read per call so a test can flip it
-    return !(e && !std::strcmp(e, "tile"));
-}
+// The persistent row-owner kernel applies up to PERSIST_MAX_N columns (CCVM_AMD_KERNEL=tile forces
+// the per-step kernel; read once per ABI call so a test can flip it between calls).
+bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
 template <int MODE, bool ADAM>
 int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
@@ -257,6 +278,31 @@ size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
     return (solver == 1 || solver == 2) ? base + ld * ld * sizeof(float) : base;
 }
 
+int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0 || solver < 0 || solver > 2 || B <= 0 || N <= 0)
+        return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
+    const Tuning tun = read_tuning();
+    const bool ad = adam && solver != 0;
+    if (want_persist(N, tun)) {
+        const int nch = std::min((N + 15) / 16, 16);
+        const int cw = nch == 1 ? 16 : nch == 2 ? 32 : 64;
+        const int ncg = nch <= 4 ? 1 : nch <= 8 ? 2 : 4;
+        const int br4 = (solver == 0 ? 2 : 4) * (64 / cw);
+        int ru = ((B + br4 - 1) / br4) * ncg >= 768 ? 4 : 2;
+        if (tun.persist_ru) ru = tun.persist_ru;
+        const int per = br4 * ru / 4 * (4 / ncg);
+        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d> grid %d x 256 threads, up to %d steps per launch",
+                      solver, ad ? "true" : "false", cw, ncg, nch, ru, (B + per - 1) / per, TABLE_STEPS);
+    } else {
+        StepArgs a;
+        base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun);
+        std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
+                      solver, ad ? "true" : "false", a.ks, (per_variable_s && solver != 0) ? "true" : "false",
+                      a.nrb * a.ncb, WG_THREADS, a.xr, a.xc);
+    }
+    return CCVM_OK;
+}
+
 int ccvm_pack(const float* src, int rows, int cols, int src_ld, float* dst, int dst_rows, int dst_ld,
               void* stream) {
     if (!src || !dst || rows < 0 || cols < 0 || src_ld < cols || dst_rows < rows || dst_ld < cols)
@@ -284,6 +330,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 int nsteps, int T, const ccvm_dl_params* p, const ccvm_noise* nz, void* ws, size_t ws_bytes,
                 void* stream) {
     const char* fn = "ccvm_dl_run";
+    const Tuning tun = read_tuning();
     if (!Q || !V || !c || !s || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -307,11 +354,11 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
     if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
-    if (nsteps > 0 && want_persist(N)) {
+    if (nsteps > 0 && want_persist(N, tun)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
@@ -319,6 +366,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.x1 = s; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        pa.ru_override = tun.persist_ru;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
@@ -369,6 +417,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
                 int ld, int step0, int nsteps, int T, const ccvm_mf_params* p, const ccvm_adam* adam,
                 const ccvm_noise* nz, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_mf_run";
+    const Tuning tun = read_tuning();
     if (!Q || !V || !mu || !sigma || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -396,7 +445,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     auto j_at = [&](int i) { return p->j * std::exp(-(double)(i + 1) / (double)T * 3.0); };  // :550
     const bool replay = nz->mode == CCVM_NOISE_REPLAY;
 
-    if (want_persist(N)) {
+    if (want_persist(N, tun)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         const float* qsum;
         if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum))) return rc;
@@ -408,6 +457,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = replay;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
         pa.S = (float)S_eff;
+        pa.ru_override = tun.persist_ru;
         pa.s_cols = s_cols;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
@@ -439,7 +489,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     }
 
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / S_eff);
     a.in_shift = (float)up;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum))) return rc;
@@ -492,6 +542,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
                       int T, const ccvm_langevin_params* p, const ccvm_adam* adam, const ccvm_noise* nz,
                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_langevin_run";
+    const Tuning tun = read_tuning();
     if (!Q || !V || !c || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -518,7 +569,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
@@ -526,13 +577,14 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(2, B, N), st);
         a.s_cols = s_cols;
     }
-    if (want_persist(N)) {
+    if (want_persist(N, tun)) {
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = a.Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table; pa.s_cols = s_cols;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        pa.ru_override = tun.persist_ru;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
@@ -611,6 +663,27 @@ int ccvm_change_variables_cols(const float* x, float* y, int B, int N, int ld, c
     return CCVM_OK;
 }
 
+int ccvm_clamp_full(float* x, int B, int N, int ld, const float* lo, const float* hi, void* stream) {
+    int rc;
+    if (!x || !lo || !hi) return fail(CCVM_E_INVALID, "ccvm_clamp_full: NULL argument");
+    if ((rc = check_layout("ccvm_clamp_full", B, N, ld))) return rc;
+    hipLaunchKernelGGL(clamp_full_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream, x, B, N,
+                       ld, lo, hi);
+    CCVM_CHECK_LAUNCH("ccvm_clamp_full");
+    return CCVM_OK;
+}
+
+int ccvm_change_variables_full(const float* x, float* y, int B, int N, int ld, const float* s_full, double lower,
+                               double upper, void* stream) {
+    int rc;
+    if (!x || !y || !s_full) return fail(CCVM_E_INVALID, "ccvm_change_variables_full: NULL argument");
+    if ((rc = check_layout("ccvm_change_variables_full", B, N, ld))) return rc;
+    hipLaunchKernelGGL(change_variables_full_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, N, ld, s_full, (float)(upper - lower), (float)(0.5 * (upper + lower)));
+    CCVM_CHECK_LAUNCH("ccvm_change_variables_full");
+    return CCVM_OK;
+}
+
 int ccvm_change_variables(const float* x, float* y, int B, int N, int ld, double S, double lower, double upper,
                           void* stream) {
     int rc;
@@ -626,6 +699,7 @@ int ccvm_change_variables(const float* x, float* y, int B, int N, int ld, double
 int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, int ld, double scaled_by,
                 float* obj, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_energy";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x || !obj) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -634,7 +708,7 @@ int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, in
     if (ws_bytes < ccvm_workspace_bytes(3, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     hipStream_t st = (hipStream_t)stream;
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.a0 = x;
     a.o0 = static_cast<float*>(ws);
     if ((rc = launch_step<MODE_ENERGY, false>(a, st, fn))) return rc;
@@ -644,9 +718,57 @@ int ccvm_energy(const float* Q, const float* V, const float* x, int B, int N, in
     return CCVM_OK;
 }
 
+int ccvm_objective_stats(const float* obj, int B, double optimal_value, ccvm_solution_stats* stats, void* stream) {
+    static_assert(sizeof(ccvm_solution_stats) == sizeof(ObjectiveStats), "ccvm_solution_stats layout");
+    if (!obj || !stats || B <= 0) return fail(CCVM_E_INVALID, "ccvm_objective_stats: bad argument");
+    hipLaunchKernelGGL(objective_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, obj, B,
+                       (float)optimal_value, reinterpret_cast<ObjectiveStats*>(stats));
+    CCVM_CHECK_LAUNCH("ccvm_objective_stats");
+    return CCVM_OK;
+}
+
+int ccvm_finalize(const float* Q, const float* V, float* state, float* x, int B, int N, int ld,
+                  const ccvm_finalize_params* p, float* obj, ccvm_solution_stats* stats, void* ws, size_t ws_bytes,
+                  void* stream) {
+    const char* fn = "ccvm_finalize";
+    const Tuning tun = read_tuning();
+    int rc;
+    if (!Q || !V || !state || !x || !p || !obj) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    if ((rc = check_layout(fn, B, N, ld))) return rc;
+    if (!aligned16(Q) || !aligned16(state) || !aligned16(x) || !aligned16(ws))
+        return fail(CCVM_E_LAYOUT, "%s: Q, state, x and workspace must be 16-byte aligned", fn);
+    if (ws_bytes < ccvm_workspace_bytes(3, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (p->change_variables && !(p->s_cols || p->s_full || p->S > 0))
+        return fail(CCVM_E_INVALID, "%s: S must be positive", fn);
+    if (p->s_cols && p->s_full) return fail(CCVM_E_INVALID, "%s: s_cols and s_full are exclusive", fn);
+    if (p->clamp && !p->s_cols && !p->s_full && !(p->clamp_hi >= p->clamp_lo))
+        return fail(CCVM_E_INVALID, "%s: clamp bounds out of order", fn);
+    hipStream_t st = (hipStream_t)stream;
+    // 1. clamp (in place) + change of variables: state -> x
+    if (p->clamp || p->change_variables || x != state) {
+        hipLaunchKernelGGL(finalize_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, state, x, B, N, ld,
+                           p->clamp, (float)p->clamp_lo, (float)p->clamp_hi, p->change_variables, (float)p->S,
+                           p->s_cols, p->s_full, (float)(p->upper - p->lower), (float)(0.5 * (p->upper + p->lower)));
+        CCVM_CHECK_LAUNCH(fn);
+    }
+    // 2. x @ Q with the row-dot epilogue (column-strip partials), 3. fixed-order strip sum * scaled_by
+    StepArgs a;
+    base_args(a, Q, V, B, N, ld, tun);
+    a.a0 = x;
+    a.o0 = static_cast<float*>(ws);
+    if ((rc = launch_step<MODE_ENERGY, false>(a, st, fn))) return rc;
+    hipLaunchKernelGGL(energy_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, st,
+                       static_cast<const float*>(ws), (N + 31) / 32, a.nrb * BM, B, (float)p->scaled_by, obj);
+    CCVM_CHECK_LAUNCH(fn);
+    // 4. best objective value + the seven gap counters
+    if (stats) return ccvm_objective_stats(obj, B, p->optimal_value, stats, stream);
+    return CCVM_OK;
+}
+
 int ccvm_feedback(const float* Q, const float* V, const float* x, float* y, int B, int N, int ld, double in_scale,
                   double in_shift, double f_q, double f_v, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_feedback";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x || !y || x == y) return fail(CCVM_E_INVALID, "%s: NULL or aliased argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -654,7 +776,7 @@ int ccvm_feedback(const float* Q, const float* V, const float* x, float* y, int 
         return fail(CCVM_E_LAYOUT, "%s: Q, x, y and workspace must be 16-byte aligned", fn);
     if (ws_bytes < ccvm_workspace_bytes(5, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)in_scale;
     a.in_shift = (float)in_shift;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws), (hipStream_t)stream, &a.qsum))) return rc;
@@ -668,6 +790,7 @@ int ccvm_feedback(const float* Q, const float* V, const float* x, float* y, int 
 int ccvm_pp_grad_descent(const float* Q, const float* V, float* x, int B, int N, int ld, int iters, double step,
                          double lo, double hi, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_pp_grad_descent";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x || iters < 0) return fail(CCVM_E_INVALID, "%s: bad argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -681,7 +804,7 @@ int ccvm_pp_grad_descent(const float* Q, const float* V, float* x, int B, int N,
     if (hipMemsetAsync(ws, 0, state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
     StepArgs a;
-    base_args(a, Q, V, B, N, ld);
+    base_args(a, Q, V, B, N, ld, tun);
     a.s.pp.step = (float)step;
     a.s.pp.lo = (float)lo;
     a.s.pp.hi = (float)hi;
@@ -701,6 +824,7 @@ int ccvm_pp_grad_descent(const float* Q, const float* V, float* x, int B, int N,
 int ccvm_pp_adam(const float* Q, const float* V, float* x, int B, int N, int ld, double lr, double eps, double lo,
                  double hi, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_pp_adam";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -716,7 +840,7 @@ int ccvm_pp_adam(const float* Q, const float* V, float* x, int B, int N, int ld,
     hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
     CCVM_CHECK_LAUNCH(fn);
     StepArgs a;
-    base_args(a, qs, V, B, N, ld);
+    base_args(a, qs, V, B, N, ld, tun);
     a.a0 = x;
     a.o0 = xn;
     a.s.pp.step = (float)lr;
@@ -732,6 +856,7 @@ int ccvm_pp_adam(const float* Q, const float* V, float* x, int B, int N, int ld,
 int ccvm_pp_asgd(const float* Q, const float* V, float* x, int B, int N, int ld, double lr, double lambd, double lo,
                  double hi, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_pp_asgd";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -747,7 +872,7 @@ int ccvm_pp_asgd(const float* Q, const float* V, float* x, int B, int N, int ld,
     hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
     CCVM_CHECK_LAUNCH(fn);
     StepArgs a;
-    base_args(a, qs, V, B, N, ld);
+    base_args(a, qs, V, B, N, ld, tun);
     a.a0 = x;
     a.o0 = xn;
     a.s.pp.step = (float)lr;
@@ -763,6 +888,7 @@ int ccvm_pp_asgd(const float* Q, const float* V, float* x, int B, int N, int ld,
 int ccvm_pp_lbfgs(const float* Q, const float* V, float* x, int B, int N, int ld, int iters, double lr, double lo,
                   double hi, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_pp_lbfgs";
+    const Tuning tun = read_tuning();
     int rc;
     if (!Q || !V || !x || iters < 0) return fail(CCVM_E_INVALID, "%s: bad argument", fn);
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -779,7 +905,7 @@ int ccvm_pp_lbfgs(const float* Q, const float* V, float* x, int B, int N, int ld
     hipLaunchKernelGGL(symmetrize_kernel, dim3(ew_grid((size_t)ld * ld)), dim3(256), 0, st, Q, qs, ld);
     CCVM_CHECK_LAUNCH(fn);
     StepArgs a;
-    base_args(a, qs, V, B, N, ld);  // g = x @ 1/2 (Q + Q') + V
+    base_args(a, qs, V, B, N, ld, tun);  // g = x @ 1/2 (Q + Q') + V
     a.a0 = x;
     a.o0 = grad;
     a.s.pp.step = 1.0f;

@@ -130,6 +130,13 @@ __device__ __forceinline__ void mf_update(const MfScalars& k, float mu, float sg
     sgn = __builtin_fmaf(k.dt, dsig, sg);
 }
 
+// change_variables (dl_solver.py:219-235): 0.5 * y / S * (u - l) + 0.5 * (u + l), one rounding per
+// operation in the reference's order (torch evaluates it as four elementwise fp32 ops); half_up is
+// 0.5 * (u + l) rounded once on the host.
+__device__ __forceinline__ float change_var(float y, float S, float ul, float half_up) {
+    return 0.5f * y / S * ul + half_up;
+}
+
 // `S`: the clamp bound of this column (k.S, or the per-variable saturation of the column)
 __device__ __forceinline__ float lv_update(const LvScalars& k, float c, float g, float n0, float S) {
     float x = __builtin_fmaf(k.dt_fs, g, c) + k.w * n0;

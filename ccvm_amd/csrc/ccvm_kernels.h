@@ -65,6 +65,7 @@ struct StepArgs {
     int B, N, ld;
     int nrb, ncb;       // row blocks, column blocks
     int xr, xc;         // tiles of one XCD form an xr x xc rectangle (0: linear fallback)
+    int ks;             // host only: the tile shape this launch plan uses (template parameter KS)
     float in_scale, in_shift;  // GEMM input = x * in_scale + in_shift
     union {
         DlScalars dl;
@@ -789,7 +790,32 @@ __global__ void change_variables_cols_kernel(const float* x, float* y, int B, in
          i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
         const size_t idx = (size_t)r * ld + c;
-        y[idx] = 0.5f * x[idx] / s_cols[c] * ul + half_up;
+        y[idx] = change_var(x[idx], s_cols[c], ul, half_up);
+    }
+}
+
+// The two above with one bound / saturation per trajectory AND variable (pitched [rows][ld] arrays):
+// the reference passes any non-1-D tensor S straight through to the elementwise ops
+// (dl_solver.py:843-848), and its clamp takes tensor bounds (torch.clamp(c, lower, upper)).
+__global__ void clamp_full_kernel(float* x, int B, int N, int ld, const float* __restrict__ lo,
+                                  const float* __restrict__ hi) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        const size_t idx = (size_t)r * ld + c;
+        x[idx] = clampf(x[idx], lo[idx], hi[idx]);
+    }
+}
+
+__global__ void change_variables_full_kernel(const float* x, float* y, int B, int N, int ld,
+                                             const float* __restrict__ s_full, float ul, float half_up) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        const size_t idx = (size_t)r * ld + c;
+        y[idx] = change_var(x[idx], s_full[idx], ul, half_up);
     }
 }
 
@@ -801,7 +827,7 @@ __global__ void change_variables_kernel(const float* x, float* y, int B, int N, 
          i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
         const size_t idx = (size_t)r * ld + c;
-        y[idx] = 0.5f * x[idx] / S * ul + half_up;
+        y[idx] = change_var(x[idx], S, ul, half_up);
     }
 }
 
@@ -848,6 +874,78 @@ __global__ void energy_reduce_kernel(const float* partial, int nstrips, int rows
     float e = 0.0f;
     for (int s = 0; s < nstrips; ++s) e += partial[(size_t)s * rows_pad + b];
     obj[b] = e * scaled_by;
+}
+
+// Finalize, step 1 (one pass over the state): optional fit_to_constraints clamp IN PLACE on the state
+// (dl_solver.py:567: scalar bounds, or -S .. S with a per-variable / per-element saturation) and the change of
+// variables x = 0.5 * y / S * (u - l) + 0.5 * (u + l) (dl_solver.py:219-235, same operation order as
+// change_variables_kernel) into `x`, which may alias the state.  do_cv == 0 copies (x != state) or
+// leaves the state as the variables.
+__global__ void finalize_prepare_kernel(float* state, float* x, int B, int N, int ld, int do_clamp, float clo,
+                                        float chi, int do_cv, float S, const float* __restrict__ s_cols,
+                                        const float* __restrict__ s_full, float ul, float half_up) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        const size_t idx = (size_t)r * ld + c;
+        float y = state[idx];
+        const float sat = s_full ? s_full[idx] : s_cols ? s_cols[c] : S;
+        if (do_clamp) {
+            y = (s_cols || s_full) ? clampf(y, -sat, sat) : clampf(y, clo, chi);
+            state[idx] = y;
+        }
+        if (do_cv) y = change_var(y, sat, ul, half_up);
+        if (do_cv || x != state) x[idx] = y;
+    }
+}
+
+// Success statistics of a batch (solution.py:65-146), one workgroup, fixed-order reductions:
+//   found_b = -obj_b;  best = max_b found_b;  gap_b = (optimal - found_b) * 100 / |found_b|   (fp32, as
+//   torch evaluates it for a float32 tensor and Python-float scalars);  within[k] = #{b : gap_b <= thr_k},
+//   thr = 0.1, 1, 2, 3, 4, 5, 10 (percent).  NaN objective values count in no threshold and make
+//   `best` NaN, like torch.max.
+struct ObjectiveStats {
+    float best_objective_value;
+    int within[7];
+    int rows;
+    int nonfinite;  // rows whose objective value is NaN or infinite (a diverged run)
+};
+__global__ __launch_bounds__(1024) void objective_stats_kernel(const float* __restrict__ obj, int B, float optimal,
+                                                                ObjectiveStats* out) {
+    __shared__ float s_best[1024];
+    __shared__ int s_cnt[9][1024];
+    const float thr[7] = {0.1f, 1.0f, 2.0f, 3.0f, 4.0f, 5.0f, 10.0f};
+    float best = -INFINITY;
+    int cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // 7 thresholds, NaN seen, non-finite rows
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const float found = -obj[b];
+        const float gap = (optimal - found) * 100.0f / fabsf(found);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cnt[k] += (gap <= thr[k]) ? 1 : 0;
+        if (found != found) cnt[7] = 1;
+        else best = fmaxf(best, found);
+        if (!(fabsf(found) <= 3.402823466e38f)) cnt[8] += 1;
+    }
+    s_best[threadIdx.x] = best;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_cnt[k][threadIdx.x] = cnt[k];
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_best[threadIdx.x] = fmaxf(s_best[threadIdx.x], s_best[threadIdx.x + w]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_cnt[k][threadIdx.x] += s_cnt[k][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out->best_objective_value = s_cnt[7][0] ? __builtin_nanf("") : s_best[0];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) out->within[k] = s_cnt[k][0];
+        out->rows = B;
+        out->nonfinite = s_cnt[8][0];
+    }
 }
 
 // Column sums of Q in two deterministic passes: part[s][j] over row slice s, then a fixed-order

@@ -8,9 +8,14 @@
 // and tools/filler.hip), Philox needs two quarter-rate 32x32->64 multiplies per round, and
 // Threefry is add / rotate / xor only ("Noise").
 //
-//   counter = (column, global_row_lo),  key = (seed_lo ^ step, seed_hi ^ global_row_hi)
+//   counter = (column, global_row_lo),  key = (K_lo, K_hi ^ global_row_hi),
+//   K = step_key(seed, step) = splitmix64 finaliser of  seed + 0x9E3779B97F4A7C15 * (step + 1)
 //
-// so a trajectory's noise depends only on its GLOBAL row index, the column and the step --
+// (the step is mixed into the 64-bit key by a bijective hash, NOT xor-ed into the seed: with
+// seed ^ step the runs (seed s, step i) and (seed s ^ d, step i ^ d) consumed the same normals, so
+// repetitions with consecutive small seeds reused each other's noise blocks).  The hash runs on the
+// scalar ALU (seed and step are wave-uniform): no VALU cost.
+// A trajectory's noise depends only on its GLOBAL row index, the column and the step --
 // never on the tiling, the grid or how the batch is sharded over GPUs.  The two output words
 // give one Box-Muller pair (n0, n1):
 //   DL (two Wiener streams per element):  normal_pair(row)  -> (W_c, W_s) of element (row, col);
@@ -49,6 +54,16 @@ __device__ __forceinline__ void threefry2x32_13(uint32_t c0, uint32_t c1, uint32
     o1 = x1;
 }
 
+// Per-step 64-bit Threefry key: the SplitMix64 output function (Steele, Lea, Flood 2014; Vigna's
+// splitmix64.c constants) applied to seed + golden * (step + 1).  step_key(0, 0) = 0xE220A8397B1DCDAF,
+// the first output of splitmix64 seeded with 0 (known answer in tests/test_noise.py).
+__host__ __device__ __forceinline__ uint64_t step_key(uint64_t seed, int step) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(static_cast<uint32_t>(step)) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 // 24-bit uniform strictly inside (0, 1): ((x >> 8) + 0.5) * 2^-24.
 __device__ __forceinline__ float u01(uint32_t x) {
     return (static_cast<float>(x >> 8) + 0.5f) * 5.9604644775390625e-8f;
@@ -56,9 +71,10 @@ __device__ __forceinline__ float u01(uint32_t x) {
 
 __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, int step, int col) {
     uint32_t x0, x1;
+    const uint64_t key = step_key(seed, step);  // wave-uniform: scalar ALU
     threefry2x32_13(static_cast<uint32_t>(col), static_cast<uint32_t>(grow),
-                    static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step),
-                    static_cast<uint32_t>(seed >> 32) ^ static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
+                    static_cast<uint32_t>(key),
+                    static_cast<uint32_t>(key >> 32) ^ static_cast<uint32_t>(static_cast<uint64_t>(grow) >> 32),
                     x0, x1);
     // Box-Muller: r = sqrt(-2 ln u1) with the raw v_log_f32 (log2) / v_sqrt_f32 (u1 >= 2^-25: no
     // denormal fix-ups needed; every VALU op here costs matrix-pipe time); v_sin/v_cos take
@@ -77,8 +93,9 @@ __device__ __forceinline__ NormalPair normal_pair(uint64_t seed, int64_t grow, i
 // to two normal_pair calls.
 __device__ __forceinline__ void normal_pair_x2(uint64_t seed, int64_t grow_a, int64_t grow_b, int step, int col,
                                                NormalPair& pa, NormalPair& pb) {
-    const uint32_t k0 = static_cast<uint32_t>(seed) ^ static_cast<uint32_t>(step);
-    const uint32_t hi = static_cast<uint32_t>(seed >> 32);
+    const uint64_t key = step_key(seed, step);  // wave-uniform: scalar ALU
+    const uint32_t k0 = static_cast<uint32_t>(key);
+    const uint32_t hi = static_cast<uint32_t>(key >> 32);
     const uint32_t k1a = hi ^ static_cast<uint32_t>(static_cast<uint64_t>(grow_a) >> 32);
     const uint32_t k1b = hi ^ static_cast<uint32_t>(static_cast<uint64_t>(grow_b) >> 32);
     const uint32_t ksa[3] = {k0, k1a, 0x1BD11BDAu ^ k0 ^ k1a};

@@ -61,6 +61,7 @@ struct PersistArgs {
     float k_first;      // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;            // MF: clamp of the measured amplitude
     const float* s_cols; // per-variable saturation S_j (length ld) or NULL (see StepArgs::s_cols)
+    int ru_override;     // host only: 2 / 4 forces the rows in use per group (tuning), 0 = by batch size
     AdamConsts ad;
 };
 

@@ -18,16 +18,13 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 
 // Shape by N (columns a wave covers x waves side by side) and rows in use per 4-row group: 4 when
 // that still gives (nearly) every one of the 1024 SIMDs a wave, else 2 (shorter per-step chain per
-// wave, twice the waves).  CCVM_AMD_PERSIST_RU=2|4 overrides (tuning).
+// wave, twice the waves).  PersistArgs::ru_override (CCVM_AMD_PERSIST_RU=2|4, read by the ABI) forces one.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
     constexpr int RG = 64 / CW;
     const int br4 = ((MODE == MODE_DL) ? 2 : 4) * RG;  // batch rows per workgroup at RU = 4
     int ru = ((a.B + br4 - 1) / br4) * NCG >= 768 ? 4 : 2;
-    if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU")) {
-        if (e[0] == '2') ru = 2;
-        if (e[0] == '4') ru = 4;
-    }
+    if (a.ru_override == 2 || a.ru_override == 4) ru = a.ru_override;
     const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
     if (ru == 4) {
         const int per = br4 * (4 / NCG);

@@ -52,7 +52,6 @@ def warmup():
     dev = gpu_device()
     if dev.index in _warm:
         return
-    _warm.add(dev.index)
     lib = _lib.load()
     with torch.cuda.device(dev):
         x = torch.zeros((64, 128), dtype=torch.float32, device=dev)
@@ -66,6 +65,7 @@ def warmup():
                                  ("langevin", lv, adam)):
             Trajectories(prob, 1, kind, 1, params, (0.0, 1.0), NoiseSpec(mode="philox", seed=1), adam=ad).advance(1)
         torch.cuda.synchronize(dev)
+    _warm.add(dev.index)  # only after it succeeded: a failed warm-up is retried by the next call
 
 
 _primed = set()
@@ -85,7 +85,6 @@ def prime(kind, n, batch, adam=None):
     key = (dev.index, kind, int(n), int(batch), bool(adam), use_v)
     if key in _primed:
         return
-    _primed.add(key)
     with torch.cuda.device(dev):
         prob = DeviceProblem(torch.zeros((n, n)), torch.zeros(n))
         params = {
@@ -99,6 +98,7 @@ def prime(kind, n, batch, adam=None):
         for name in traj.state:  # the runtime's host staging buffers for results of this size
             traj.compact(name).cpu()
         torch.cuda.synchronize(dev)
+    _primed.add(key)  # only after it succeeded
 
 
 def _stream_ptr():
@@ -147,8 +147,10 @@ def unpack(src, rows, cols):
 class NoiseSpec:
     """How the Wiener increments of a run are produced.
 
-    mode "philox": counter-based generator (Threefry2x32-20) fused into the step kernel; ``seed`` keys
-        it and ``row_offset`` is the global index of local row 0 (batch sharding).
+    mode "fused" (alias "philox", historical): counter-based generator (Threefry2x32-13 keyed by a
+        SplitMix64 hash of (seed, step), then Box-Muller) fused into the step kernel; ``row_offset`` is
+        the global index of local row 0 (batch sharding).  Any two seeds -- consecutive small integers
+        included -- give unrelated streams.
     mode "replay": standard normals are drawn on the host from ``generator`` (None =
         torch's global CPU generator, i.e. exactly what the reference consumes after
         ``torch.manual_seed``) in the reference's order -- per step one (N, B) block
@@ -160,6 +162,10 @@ class NoiseSpec:
     seed: int = 0
     row_offset: int = 0
     generator: Optional[torch.Generator] = None
+    #: replay mode under batch sharding: every rank draws the (N, global_batch) block of the UNSHARDED
+    #: run from an identically seeded generator and keeps columns [row_offset, row_offset + B), so the
+    #: union of the shards is the unsharded run.  None: the block is (N, B) (unsharded).
+    global_batch: Optional[int] = None
 
     def __post_init__(self):
         if self.mode == "fused":  # clearer name for the in-kernel generator ("philox" is historical)
@@ -173,12 +179,18 @@ def draw_seed():
     return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
 
 
-def default_noise(mode=None, row_offset=0, seed=None):
+def effective_noise_mode(mode=None):
+    """The solver's ``noise_mode`` or, when that is None, $CCVM_AMD_NOISE (default: the fused generator)."""
+    mode = mode or os.environ.get("CCVM_AMD_NOISE", "philox")
+    return "philox" if mode == "fused" else mode
+
+
+def default_noise(mode=None, row_offset=0, seed=None, global_batch=None):
     """Noise spec for a solver call.  PHILOX seeds default to a draw from torch's global CPU
     generator so ``torch.manual_seed`` makes runs reproducible in both modes."""
-    mode = mode or os.environ.get("CCVM_AMD_NOISE", "philox")
+    mode = effective_noise_mode(mode)
     if mode == "replay":
-        return NoiseSpec(mode="replay", row_offset=row_offset)
+        return NoiseSpec(mode="replay", row_offset=row_offset, global_batch=global_batch)
     return NoiseSpec(mode=mode, seed=draw_seed() if seed is None else int(seed), row_offset=row_offset)
 
 
@@ -203,9 +215,15 @@ class _NoiseFeeder:
             return nz
         nz.mode = _lib.NOISE_REPLAY
         host = torch.empty((nsteps, self.streams, self.n, self.b), dtype=torch.float32)
+        gb, lo = self.spec.global_batch, int(self.spec.row_offset)
+        if gb is not None and not (0 <= lo and lo + self.b <= gb):
+            raise ValueError(f"replay noise: rows [{lo}, {lo + self.b}) outside the global batch of {gb}")
         for t in range(nsteps):
             for k in range(self.streams):
-                torch.randn((self.n, self.b), generator=self.spec.generator, out=host[t, k])
+                if gb is None:
+                    torch.randn((self.n, self.b), generator=self.spec.generator, out=host[t, k])
+                else:  # this shard's columns of the unsharded run's block
+                    host[t, k] = torch.randn((self.n, gb), generator=self.spec.generator)[:, lo:lo + self.b]
         dev = host.to(self.device)
         w0 = dev[:, 0].contiguous()
         w1 = dev[:, 1].contiguous() if self.streams == 2 else None
@@ -240,7 +258,10 @@ def device_problem(q_matrix, v_vector):
     call stages Q for the loop, again for the energy evaluation and again for a post-processor
     (3 x 16 MB at N = 2000), and benchmark loops solve one instance many times.  Identity is the
     Python object (weak reference) plus torch's in-place version counter, so a new tensor that
-    happens to reuse the address, or an in-place edit, is never served a stale copy."""
+    happens to reuse the address, or an in-place edit, is never served a stale copy.  (Edits that
+    bypass the version counter -- ``q.data.mul_()``, ``set_`` -- are not seen: re-create the tensor.)
+    A cached entry served to another stream is recorded on it (``record_stream``), so the caching
+    allocator cannot hand its memory out again while kernels of that stream still read it."""
     import weakref
 
     dev = gpu_device()
@@ -248,7 +269,10 @@ def device_problem(q_matrix, v_vector):
         wq, wv, qver, vver, index, prob, ready = entry
         if wq() is q_matrix and wv() is v_vector and qver == q_matrix._version and vver == v_vector._version \
                 and index == dev.index:
-            torch.cuda.current_stream(dev).wait_event(ready)  # staged on another stream, perhaps
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ready)  # staged on another stream, perhaps
+            prob.q.record_stream(cur)
+            prob.v.record_stream(cur)
             return prob
     prob = DeviceProblem(q_matrix, v_vector)
     ready = torch.cuda.Event()
@@ -371,9 +395,14 @@ class Trajectories:
 
     # ------------------------------------------------------------------ #
     def clamp(self, name, lo, hi):
-        """In-place clamp of a state array; ``hi`` may be a per-variable saturation (bounds -hi_j, +hi_j)."""
+        """In-place clamp of a state array; ``hi`` may be a per-variable (1-D) or per-element (batch, N)
+        saturation (bounds -hi, +hi)."""
         with torch.cuda.device(self.device):
-            if is_per_variable(hi):
+            if is_per_element(hi):
+                sat = saturation_full(hi, self.b, self.n, self.device)
+                rc = self.lib.ccvm_clamp_full(_ptr(self.state[name]), self.b, self.n, self.ld, _ptr(-sat), _ptr(sat),
+                                              _stream_ptr())
+            elif is_per_variable(hi):
                 cols = saturation_columns(hi, self.n, self.device)
                 rc = self.lib.ccvm_clamp_cols(_ptr(self.state[name]), self.b, self.n, self.ld, _ptr(cols),
                                               _stream_ptr())
@@ -386,6 +415,25 @@ class Trajectories:
         """Logical (B, N) copy of one state array, on the GPU."""
         with torch.cuda.device(self.device):
             return unpack(self.state[name], self.b, self.n)
+
+    def view(self, name):
+        """The logical (B, N) region of one pitched state array as a strided GPU view (no copy)."""
+        return self.state[name][: self.b, : self.n]
+
+    def score(self, name, S, scaled_by, lower=0.0, upper=1.0, optimal_value=1.0, clamp=None,
+              post_processor=None, rescale_after_pp=False):
+        """Everything between the loop and the Solution without leaving the device (ccvm_finalize):
+        optional clamp of state ``name`` in place, change of variables with saturation ``S``, optional
+        on-device post-processor, energy of every row and the success statistics.  Returns a ``Scored``.
+
+        ``rescale_after_pp``: the DL solver applies the change of variables again AFTER a
+        post-processor (dl_solver.py:936-958: the reported variables are the post-processed ones, the
+        scored configuration is change_variables of them)."""
+        with torch.cuda.device(self.device):
+            x = torch.zeros_like(self.state[name])
+            return finalize_pitched(self.p, self.state[name], x, self.b, self.n, S, lower, upper, scaled_by,
+                                    optimal_value, clamp=clamp, post_processor=post_processor,
+                                    rescale_after_pp=rescale_after_pp)
 
 
 # --------------------------------------------------------------------------- #
@@ -410,6 +458,27 @@ def is_per_variable(S):
     return torch.is_tensor(S) and S.ndim == 1 and S.numel() > 1
 
 
+def is_per_element(S):
+    """True for a saturation / bound with one value per trajectory AND variable: any 2-D tensor (the
+    reference passes a non-1-D tensor S straight through to the elementwise ops, dl_solver.py:843-848)."""
+    return torch.is_tensor(S) and S.ndim == 2 and S.numel() > 1
+
+
+def _full_pitched(t, b, n, dev):
+    """A bound broadcast to (b, n) in the pitched device layout."""
+    full = torch.as_tensor(t, dtype=torch.float32).detach().to(dev).expand(b, n).contiguous()
+    return pack(full, rows_of(b), ld_of(n))
+
+
+def saturation_full(S, b, n, dev):
+    """The pitched device array the ``*_full`` entry points and ``s_full`` take (positive entries)."""
+    if tuple(torch.broadcast_shapes(tuple(S.shape), (b, n))) != (b, n):
+        raise ValueError(f"a 2-D saturation must broadcast to (batch, N) = ({b}, {n}); got {tuple(S.shape)}")
+    if not bool((S > 0).all()):
+        raise ValueError("every entry of the saturation S must be positive")
+    return _full_pitched(S, b, n, dev)
+
+
 def saturation_columns(S, n, dev):
     """The device array (ld floats, padding 1) the ``*_cols`` entry points and ``s_cols`` fields take."""
     s = S.detach().to(device="cpu", dtype=torch.float32).reshape(-1)
@@ -429,7 +498,11 @@ def change_variables(x, S, lower, upper):
     b, n = xg.shape
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
-        if is_per_variable(S):
+        if is_per_element(S):
+            rc = lib.ccvm_change_variables_full(_ptr(xp), _ptr(xp), b, n, xp.shape[1],
+                                                _ptr(saturation_full(S, b, n, dev)), float(lower), float(upper),
+                                                _stream_ptr())
+        elif is_per_variable(S):
             cols = saturation_columns(S, n, dev)
             rc = lib.ccvm_change_variables_cols(_ptr(xp), _ptr(xp), b, n, xp.shape[1], _ptr(cols), float(lower),
                                                 float(upper), _stream_ptr())
@@ -441,14 +514,19 @@ def change_variables(x, S, lower, upper):
 
 
 def clamp(x, lo, hi):
-    """clamp(x, lo, hi) on the GPU (fit_to_constraints); ``hi`` may be a per-variable saturation, then
-    the bounds are -hi_j, +hi_j."""
+    """clamp(x, lo, hi) on the GPU (fit_to_constraints, torch.clamp semantics).  Scalar bounds; or a
+    per-variable saturation ``hi`` (1-D: the bounds are -hi_j, +hi_j); or tensor bounds with one value per
+    element (anything else that broadcasts to x's shape, as torch.clamp accepts)."""
     lib = _lib.load()
     xg, dev = _to_gpu(x)
     b, n = xg.shape
+    scalar = lambda t: not torch.is_tensor(t) or t.numel() == 1
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
-        if is_per_variable(hi):
+        if not is_per_variable(hi) and not (scalar(lo) and scalar(hi)):
+            rc = lib.ccvm_clamp_full(_ptr(xp), b, n, xp.shape[1], _ptr(_full_pitched(lo, b, n, dev)),
+                                     _ptr(_full_pitched(hi, b, n, dev)), _stream_ptr())
+        elif is_per_variable(hi):
             cols = saturation_columns(hi, n, dev)
             rc = lib.ccvm_clamp_cols(_ptr(xp), b, n, xp.shape[1], _ptr(cols), _stream_ptr())
         else:
@@ -506,37 +584,156 @@ def energy(confs, q_matrix, v_vector, scaled_by=1.0):
         return obj.to(confs.device)
 
 
-def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=10, step=0.1, lr=0.01,
-                eps=1e-8, lambd=0.001):
-    """On-device grad-descent / adam / asgd / lbfgs post-processor; returns (x', seconds)."""
+@dataclass
+class Scored:
+    """Result of the device-side finalize: ``variables`` is a strided (B, N) GPU view of the pitched
+    array of reported problem variables, ``objective_values`` B floats on the GPU, ``stats`` the
+    40-byte ccvm_solution_stats record still on the GPU (``read_stats`` fetches it)."""
+
+    variables: torch.Tensor
+    objective_values: torch.Tensor
+    stats: torch.Tensor
+    pp_seconds: float = 0.0
+
+    def __iter__(self):  # (objective values, post-processing seconds)
+        return iter((self.objective_values, self.pp_seconds))
+
+
+# post-processor defaults of the reference (adam.py:58-66, asgd.py, lbfgs.py, grad_descent.py:58-64)
+PP_DEFAULTS = {
+    "adam": dict(lr=0.01, eps=1e-8),
+    "asgd": dict(lr=0.01, lambd=0.001),
+    "lbfgs": dict(iters=1, lr=0.001),
+    "grad-descent": dict(iters=10, step=0.1),
+}
+
+
+def read_stats(stats):
+    """(best_objective_value, [7 counters], rows, nonfinite) from a device ccvm_solution_stats record."""
+    raw = stats.cpu()  # 40 bytes: the only synchronising copy of the finalize
+    rec = _lib.SolutionStats.from_buffer_copy(bytes(raw.numpy().tobytes()))
+    return float(rec.best_objective_value), [int(c) for c in rec.within], int(rec.rows), int(rec.nonfinite)
+
+
+def objective_stats(objective_values, optimal_value):
+    """ccvm_objective_stats of B objective values that are (or are put) on the GPU; returns the device record."""
     lib = _lib.load()
+    dev = gpu_device()
+    obj = objective_values.detach().to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        stats = torch.zeros((ctypes.sizeof(_lib.SolutionStats),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ccvm_objective_stats(_ptr(obj), int(obj.numel()), float(optimal_value), _ptr(stats),
+                                            _stream_ptr()), "ccvm_objective_stats")
+    return stats
+
+
+def _saturation_args(S, b, n, dev):
+    """(scalar S, device s_cols or None, device s_full or None) of a saturation given as a float, a
+    per-variable 1-D tensor or a per-element 2-D tensor."""
+    if is_per_element(S):
+        return 1.0, None, saturation_full(S, b, n, dev)
+    if is_per_variable(S):
+        return 1.0, saturation_columns(S, n, dev), None
+    return float(S.item() if torch.is_tensor(S) else S), None, None
+
+
+def postprocess_pitched(method, prob, xp, b, n, lower=0.0, upper=1.0, **kw):
+    """On-device post-processor in place on the pitched array ``xp``; returns the seconds it took
+    (device-synchronised on both sides, like the reference's pp_time brackets the call)."""
+    lib = _lib.load()
+    dev = prob.device
+    if method not in PP_DEFAULTS:
+        raise ValueError(f"post-processor {method!r} is not implemented by the HIP engine")
+    o = dict(PP_DEFAULTS[method], **{k: v for k, v in kw.items() if v is not None})
+    ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_POSTPROCESS, b, n)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    head = (_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld)
+    tail = (float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    if method == "grad-descent":
+        rc = lib.ccvm_pp_grad_descent(*head, int(o["iters"]), float(o["step"]), *tail)
+    elif method == "adam":
+        rc = lib.ccvm_pp_adam(*head, float(o["lr"]), float(o["eps"]), *tail)
+    elif method == "lbfgs":
+        rc = lib.ccvm_pp_lbfgs(*head, int(o["iters"]), float(o["lr"]), *tail)
+    else:
+        rc = lib.ccvm_pp_asgd(*head, float(o["lr"]), float(o["lambd"]), *tail)
+    _lib.check(rc, f"ccvm_pp_{method}")
+    torch.cuda.synchronize(dev)
+    return time.time() - t0
+
+
+def finalize_pitched(prob, state, x, b, n, S, lower, upper, scaled_by, optimal_value, clamp=None,
+                     post_processor=None, rescale_after_pp=False, pp_options=None):
+    """ccvm_finalize on pitched GPU arrays (``state`` in, ``x`` out; both [rows_pad][ld]).
+
+    Without a post-processor this is ONE ABI call: clamp (optional, in place) -> change of variables ->
+    energy -> statistics.  With one: change of variables (ccvm_change_variables), the post-processor in
+    place on ``x``, then ccvm_finalize on ``x`` (with the second change of variables of the DL quirk when
+    ``rescale_after_pp``; the reported variables stay the post-processed ones)."""
+    lib = _lib.load()
+    dev = prob.device
+    with torch.cuda.device(dev):
+        s_scalar, s_cols, s_full = _saturation_args(S, b, n, dev)
+        obj = torch.empty((b,), dtype=torch.float32, device=dev)
+        stats = torch.zeros((ctypes.sizeof(_lib.SolutionStats),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((max(lib.ccvm_workspace_bytes(_lib.WS_ENERGY, b, n), 16),), dtype=torch.uint8, device=dev)
+        fp = _lib.FinalizeParams()
+        fp.S, fp.s_cols = s_scalar, (s_cols.data_ptr() if s_cols is not None else None)
+        fp.s_full = s_full.data_ptr() if s_full is not None else None
+        fp.lower, fp.upper = float(lower), float(upper)
+        fp.scaled_by, fp.optimal_value = float(scaled_by), float(optimal_value)
+        fp.clamp, fp.clamp_lo, fp.clamp_hi = 0, 0.0, 0.0
+        if clamp is not None:
+            fp.clamp, fp.clamp_lo, fp.clamp_hi = 1, float(clamp[0]), float(clamp[1])
+        pp_seconds = 0.0
+        reported, scored_in, scored_out = x, state, x
+        fp.change_variables = 1
+        if post_processor:
+            if clamp is not None:
+                if s_full is not None:
+                    rc = lib.ccvm_clamp_full(_ptr(state), b, n, prob.ld, _ptr(-s_full), _ptr(s_full), _stream_ptr())
+                elif s_cols is not None:
+                    rc = lib.ccvm_clamp_cols(_ptr(state), b, n, prob.ld, _ptr(s_cols), _stream_ptr())
+                else:
+                    rc = lib.ccvm_clamp(_ptr(state), b, n, prob.ld, fp.clamp_lo, fp.clamp_hi, _stream_ptr())
+                _lib.check(rc, "ccvm_clamp")
+                fp.clamp = 0
+            if s_full is not None:
+                rc = lib.ccvm_change_variables_full(_ptr(state), _ptr(x), b, n, prob.ld, _ptr(s_full), fp.lower,
+                                                    fp.upper, _stream_ptr())
+            elif s_cols is None:
+                rc = lib.ccvm_change_variables(_ptr(state), _ptr(x), b, n, prob.ld, s_scalar, fp.lower, fp.upper,
+                                               _stream_ptr())
+            else:
+                rc = lib.ccvm_change_variables_cols(_ptr(state), _ptr(x), b, n, prob.ld, _ptr(s_cols), fp.lower,
+                                                    fp.upper, _stream_ptr())
+            _lib.check(rc, "ccvm_change_variables")
+            pp_seconds = postprocess_pitched(post_processor, prob, x, b, n, **(pp_options or {}))
+            scored_in = x
+            if rescale_after_pp:
+                scored_out = torch.zeros_like(x)  # configuration scored; `x` stays the reported variables
+            else:
+                fp.change_variables = 0
+        _lib.check(
+            lib.ccvm_finalize(_ptr(prob.q), _ptr(prob.v), _ptr(scored_in), _ptr(scored_out), b, n, prob.ld,
+                              ctypes.byref(fp), _ptr(obj), _ptr(stats), _ptr(ws), ws.numel(), _stream_ptr()),
+            "ccvm_finalize",
+        )
+        return Scored(reported[:b, :n], obj, stats, pp_seconds)
+
+
+def postprocess(method, x, q_matrix, v_vector, lower=0.0, upper=1.0, iters=None, step=None, lr=None,
+                eps=None, lambd=None):
+    """On-device grad-descent / adam / asgd / lbfgs post-processor; returns (x', seconds)."""
     xg, dev = _to_gpu(x)
     b, n = _rows_of_problem(xg, q_matrix, f"post-processor {method!r}")
     with torch.cuda.device(dev):
         prob = device_problem(q_matrix, v_vector)
         xp = pack(xg, rows_of(b), prob.ld)
-        ws_bytes = lib.ccvm_workspace_bytes(_lib.WS_POSTPROCESS, b, n)
-        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize(dev)
-        t0 = time.time()
-        if method == "grad-descent":
-            rc = lib.ccvm_pp_grad_descent(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, int(iters),
-                                          float(step), float(lower), float(upper), _ptr(ws), ws.numel(),
-                                          _stream_ptr())
-        elif method == "adam":
-            rc = lib.ccvm_pp_adam(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(lr), float(eps),
-                                  float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
-        elif method == "lbfgs":
-            rc = lib.ccvm_pp_lbfgs(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, int(iters), float(lr),
-                                   float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
-        elif method == "asgd":
-            rc = lib.ccvm_pp_asgd(_ptr(prob.q), _ptr(prob.v), _ptr(xp), b, n, prob.ld, float(lr), float(lambd),
-                                  float(lower), float(upper), _ptr(ws), ws.numel(), _stream_ptr())
-        else:
-            raise ValueError(f"post-processor {method!r} is not implemented by the HIP engine")
-        _lib.check(rc, f"ccvm_pp_{method}")
-        torch.cuda.synchronize(dev)
-        seconds = time.time() - t0
+        seconds = postprocess_pitched(method, prob, xp, b, n, lower, upper, iters=iters, step=step, lr=lr,
+                                      eps=eps, lambd=lambd)
         return unpack(xp, b, n).to(x.device), seconds
 
 

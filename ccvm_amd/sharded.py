@@ -3,9 +3,18 @@
 Trajectories never interact, so a batch of B rows is split into contiguous row ranges,
 one per rank (one process per GPU, ``torch.distributed``; backend "nccl" is RCCL over
 xGMI).  Nothing is exchanged during the T steps.  Each rank runs its rows with the SAME
-Philox key and its own ``row_offset``, so the union of the shards is bit-identical to the
-unsharded run.  The only collective is one all-gather of the per-row objective values
-(B floats in total) after the loop; the reference has no counterpart (it is single-process).
+noise key and its own ``row_offset``, so the union of the shards is bit-identical to the
+unsharded run -- in the fused mode because the generator is keyed on the global row, in replay
+mode because every rank draws the unsharded run's (N, B) block from an identically seeded torch
+generator and keeps its own columns (the ranks must share the seed: ``torch.manual_seed`` with
+the same value everywhere, as for any torch.distributed program).  The only collective is one
+all-gather of the per-row objective values (B floats in total) after the loop -- from the device
+copy ccvm_finalize left on the GPU when the backend is RCCL -- and the global success
+statistics are counted on the device from the gathered vector; the reference has no counterpart
+(it is single-process).
+
+Evolution sampling under sharding: every rank writes the best row OF ITS SHARD to its own file,
+``<evolution_file>.rank<r>`` (rank r; the name is returned in ``Solution.evolution_file``).
 """
 import copy
 import time
@@ -66,20 +75,40 @@ def solve_sharded(solver, instance, group=None, gather_variables=False, local_so
     backend = dist.get_backend(group)
     comm_device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
+    from . import engine
+
     local = copy.copy(solver)  # shallow: shares parameter_key, rebinds the per-rank fields
     local.batch_size = hi - lo
     local.row_offset = solver.row_offset + lo
-    if solver.noise_seed is None and (solver.noise_mode or "philox") in ("philox", "fused"):
-        from . import engine
-
+    mode = engine.effective_noise_mode(solver.noise_mode)
+    if mode == "replay":
+        if solver.row_offset != 0:
+            raise ValueError("replay noise under sharding needs row_offset 0 on the unsharded solver")
+        local.replay_global_batch = batch  # draw the unsharded block, keep columns [lo, hi)
+    elif solver.noise_seed is None:
         local.noise_seed = broadcast_seed(engine.draw_seed() if rank == 0 else 0, group, comm_device)
+    if call_kwargs.get("evolution_step_size"):
+        base = call_kwargs.get("evolution_file") or f"./{instance.name}_evolution.txt"
+        call_kwargs = dict(call_kwargs, evolution_file=f"{base}.rank{rank}")
 
     t0 = time.time()
     sol = (local_solve or (lambda s, inst, **kw: s(instance=inst, **kw)))(local, instance, **call_kwargs)
     wall = torch.tensor([time.time() - t0, sol.pp_time * (hi - lo)], dtype=torch.float64, device=comm_device)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX, group=group)
 
-    obj = _all_gather_rows(sol.objective_values.to(comm_device), counts, group)
+    # gather from where the values already are: the device copy of ccvm_finalize under RCCL
+    local_obj = sol.objective_values
+    dev_obj = getattr(sol, "device_objective_values", None)
+    if backend == "nccl" and dev_obj is not None:
+        local_obj = dev_obj
+    obj = _all_gather_rows(local_obj.to(comm_device), counts, group)
+    stats = {}
+    if obj.is_cuda and sol.optimal_value is not None:
+        # global success statistics on the device (ccvm_objective_stats), 40 bytes to the host
+        from .solution import fractions_from_counts
+
+        best, within, rows, _ = engine.read_stats(engine.objective_stats(obj, sol.optimal_value))
+        stats = {"best_objective_value": best, "solution_performance": fractions_from_counts(within, rows)}
     variables = dict(sol.variables)
     if gather_variables:
         variables = {
@@ -100,7 +129,10 @@ def solve_sharded(solver, instance, group=None, gather_variables=False, local_so
         solution_vector=sol.solution_vector,
         variables=variables,
         device=sol.device,
+        solution_performance=stats.get("solution_performance"),
+        best_objective_value=stats.get("best_objective_value"),
     )
+    out.device_objective_values = obj if obj.is_cuda else None
     out.evolution_file = sol.evolution_file
     out.shard = {"rank": rank, "world": world, "rows": (lo, hi)}
     return out

@@ -37,6 +37,12 @@ def success_fractions(objective_values, optimal_value):
     }
 
 
+def fractions_from_counts(within, rows):
+    """``solution_performance`` from the device counters of ccvm_objective_stats: round(count / rows, 4)
+    per threshold, keys in the reference's order."""
+    return {key: round(int(cnt) / int(rows), 4) for (key, _), cnt in zip(GAP_THRESHOLDS, within)}
+
+
 def r99(p_success):
     """Runs needed for 99 % success probability: max(1, ln(0.01)/ln(1-p))."""
     if p_success <= 0.0:
@@ -75,8 +81,12 @@ class Solution:
             and self.objective_values.device.type != target.type
         ):
             self.objective_values = self.objective_values.to(self.device)
-        self.best_objective_value = torch.max(-self.objective_values).item()
-        self.get_solution_stats()
+        # The solvers pass both, computed on the device by ccvm_finalize (ccvm_objective_stats: the same
+        # fp32 arithmetic as below); anyone else constructing a Solution gets them computed here.
+        if self.best_objective_value is None:
+            self.best_objective_value = torch.max(-self.objective_values).item()
+        if self.solution_performance is None:
+            self.get_solution_stats()
 
     def get_solution_stats(self):
         """(Re)compute ``solution_performance`` from ``objective_values``."""

@@ -21,7 +21,7 @@ import torch
 
 from .. import engine
 from ..post_processor.factory import PostProcessorFactory
-from ..solution import Solution
+from ..solution import Solution, fractions_from_counts
 from .algorithms import AdamParameters
 
 
@@ -84,6 +84,9 @@ class CCVMSolver(ABC):
         self.row_offset = 0
         #: PHILOX key; None draws one from torch's global CPU generator per call
         self.noise_seed = None
+        #: replay noise under batch sharding: size of the unsharded batch (solve_sharded sets it)
+        self.replay_global_batch = None
+        self._traj = None  # device state of the call in flight (set by _new_trajectories)
 
     # ------------------------------------------------------------------ #
     @property
@@ -148,12 +151,13 @@ class CCVMSolver(ABC):
             )
 
     def _change_variables_boxqp(self, problem_variables, lower_limit=0, upper_limit=1, S=1):
-        _reject_tensor_s(S)
         return engine.change_variables(problem_variables, S, lower_limit, upper_limit)
 
-    def _fit_to_constraints_boxqp(self, c, lower_clamp, upper_clamp):
-        _reject_tensor_s(lower_clamp)
-        _reject_tensor_s(upper_clamp)
+    def _fit_to_constraints_boxqp(self, c=None, lower_clamp=None, upper_clamp=None, **kwargs):
+        # the reference names the first argument after the solver's state (mf_solver.py:252: mu_tilde);
+        # its own tests call it by keyword
+        if c is None and len(kwargs) == 1:
+            (c,) = kwargs.values()
         return engine.clamp(c, lower_clamp, upper_clamp)
 
     @abstractmethod
@@ -184,6 +188,7 @@ class CCVMSolver(ABC):
         self.q_matrix = instance.q_matrix
         self.v_vector = instance.v_vector
         self.solution_bounds = instance.solution_bounds
+        self._traj = None
         return instance.problem_size
 
     def _lookup(self, problem_size, *names):
@@ -195,11 +200,17 @@ class CCVMSolver(ABC):
                 f"The parameter '{exc.args[0]}' for the given instance size is not defined."
             ) from exc
 
+    #: whether a (batch, N) saturation tensor is supported: the DL solver only uses S after the loop
+    #: (final clamp + change of variables: elementwise kernels); in the other solvers S sits inside
+    #: the loop's GEMM input map
+    _FULL_SATURATION = False
+
     def _broadcast_saturation(self, S, problem_size):
         """The reference repeats a 1-D tensor S of length N over the batch (dl_solver.py:843-848 and the
         same lines of the other solvers).  The engine keeps it as the per-variable vector it is: the
-        kernels apply S_j per column (``s_cols`` of the C ABI).  A full (B, N) saturation -- one bound per
-        trajectory AND variable, which the reference would also accept -- is rejected loudly."""
+        kernels apply S_j per column (``s_cols`` of the C ABI).  Any other tensor is passed straight through
+        by the reference, i.e. a 2-D S is one saturation per trajectory AND variable: supported where the
+        saturation only acts after the loop (DL: ``s_full``), rejected loudly elsewhere."""
         if torch.is_tensor(S):
             if S.ndim == 1 and S.size(dim=0) != problem_size and S.numel() != 1:
                 raise ValueError("Tensor S size should be equal to problem size.")
@@ -207,19 +218,68 @@ class CCVMSolver(ABC):
                 return float(S.item())
             if S.ndim == 1:
                 return S.detach().to(device="cpu", dtype=torch.float32)
+            if S.ndim == 2 and self._FULL_SATURATION:
+                return S.detach().to(dtype=torch.float32)
             raise NotImplementedError(
-                "a (batch, N) saturation tensor is not supported by the HIP engine; pass a float or a 1-D "
-                "tensor of length N"
+                "a (batch, N) saturation tensor is not supported by this solver on the HIP engine; pass a "
+                "float or a 1-D tensor of length N"
             )
         return S
 
     def _new_trajectories(self, kind, batch_size, iterations, params, adam=None):
         self._require_fused_hooks()
         problem = engine.device_problem(self.q_matrix, self.v_vector)
-        noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset, seed=self.noise_seed)
-        return engine.Trajectories(
+        noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset, seed=self.noise_seed,
+                                     global_batch=self.replay_global_batch)
+        traj = engine.Trajectories(
             problem, batch_size, kind, iterations, params, self.solution_bounds, noise, adam=adam
         )
+        self._traj = traj  # the device-side finalize of __call__ scores the state where it lies
+        return traj
+
+    def _to_caller(self, traj, name):
+        """State array ``name`` for the caller: a strided view of the pitched device array for
+        device="cuda" (no copy), one device-to-host copy of the logical (B, N) region for "cpu"."""
+        view = traj.view(name)
+        return view if self.device == "cuda" else view.to("cpu")
+
+    # ---- the steps right after the loop -------------------------------------------------------- #
+    def _device_finalize_ok(self, instance, post_processor):
+        """True when clamp / change of variables / post-processor / energy / statistics can run as the
+        fused device-side finalize (ccvm_finalize): the hooks and ``compute_energy`` are the built-ins
+        and the post-processor is an on-device one.  Otherwise the hook-calling path runs (same kernels,
+        one hop per hook)."""
+        from ..problem_classes.boxqp.problem_instance import ProblemInstance
+
+        hooks = (
+            getattr(self.change_variables, "__func__", None) is type(self)._change_variables_boxqp
+            and getattr(self.fit_to_constraints, "__func__", None) is type(self)._fit_to_constraints_boxqp
+        )
+        energy = (
+            isinstance(instance, ProblemInstance)
+            and type(instance).compute_energy is ProblemInstance.compute_energy
+            and "compute_energy" not in vars(instance)
+            and instance.q_matrix is self.q_matrix
+            and instance.v_vector is self.v_vector
+        )
+        pp = not post_processor or (isinstance(post_processor, str) and post_processor.lower() in engine.PP_DEFAULTS)
+        return bool(getattr(self, "_traj", None) is not None and hooks and energy and pp
+                    and instance.optimal_sol is not None)
+
+    def _score_on_device(self, instance, name, S, lower, upper, post_processor, batch_size,
+                         rescale_after_pp=False):
+        """ccvm_finalize on state ``name`` of the last trajectories: returns (variables scored or
+        post-processed, objective values, pp_time per row, device statistics)."""
+        traj = self._traj
+        scored = traj.score(
+            name, S, float(instance.scaled_by), lower, upper, optimal_value=float(instance.optimal_sol),
+            post_processor=post_processor.lower() if post_processor else None, rescale_after_pp=rescale_after_pp,
+        )
+        best, within, rows, _ = engine.read_stats(scored.stats)
+        stats = {"best_objective_value": best, "solution_performance": fractions_from_counts(within, rows),
+                 "device_objective_values": scored.objective_values}
+        to = (lambda t: t) if self.device == "cuda" else (lambda t: t.to("cpu"))
+        return to(scored.variables), to(scored.objective_values), scored.pp_seconds / batch_size, stats
 
     def _advance_with_samples(self, traj, iterations, evolution_step_size, samples_taken):
         """Run the whole trajectory; copy the sampled state arrays to the host buffers
@@ -227,14 +287,24 @@ class CCVMSolver(ABC):
         if not evolution_step_size:
             traj.advance(iterations)
             return
+        # samples are collected in a device-side buffer (depth, B, N) per sampled array -- a strided
+        # device copy per sample point, no synchronisation -- and moved to the host buffers the
+        # reference exposes (B, N, depth) in ONE copy after the loop
+        points = sample_points(iterations, evolution_step_size)
+        first = samples_taken
+        ring = {
+            name: torch.zeros((len(points), traj.b, traj.n), dtype=torch.float32, device=traj.device)
+            for name in self._SAMPLED
+        }
         done = 0
-        for i in sample_points(iterations, evolution_step_size):
+        for k, i in enumerate(points):
             traj.advance(i + 1 - done)
             done = i + 1
             for name in self._SAMPLED:
-                getattr(self, f"{name}_sample")[:, :, samples_taken] = traj.compact(name).cpu()
-            samples_taken += 1
+                ring[name][k].copy_(traj.view(name))
         traj.advance(iterations - done)
+        for name in self._SAMPLED:
+            getattr(self, f"{name}_sample")[:, :, first:first + len(points)] = ring[name].permute(1, 2, 0).cpu()
 
     def _begin_sampling(self, instance, batch_size, problem_size, iterations, evolution_step_size,
                         evolution_file):
@@ -299,9 +369,10 @@ class CCVMSolver(ABC):
         return out, pp.pp_time / batch_size
 
     def _solution(self, instance, batch_size, iterations, objval, solve_time, pp_time, variables,
-                  evolution_step_size, evolution_file):
+                  evolution_step_size, evolution_file, stats=None):
         if evolution_step_size:
             self._write_evolution(evolution_file, objval)
+        stats = stats or {}
         solution = Solution(
             problem_size=instance.problem_size,
             batch_size=batch_size,
@@ -316,7 +387,12 @@ class CCVMSolver(ABC):
             solution_vector=instance.solution_vector,
             variables=variables,
             device=self.device,
+            solution_performance=stats.get("solution_performance"),
+            best_objective_value=stats.get("best_objective_value"),
         )
+        #: the objective values where ccvm_finalize left them (GPU): solve_sharded gathers from here
+        solution.device_objective_values = stats.get("device_objective_values")
+        self._traj = None  # release the device state of this call
         if evolution_step_size:
             solution.evolution_file = evolution_file
         return solution
@@ -337,12 +413,3 @@ class CCVMSolver(ABC):
         reference forgets."""
         self._sync()
         return (time.time() - start) / batch_size
-
-
-def _reject_tensor_s(S):
-    """Scalars and per-variable (1-D) saturations pass; a (batch, N) tensor is not supported."""
-    if torch.is_tensor(S) and S.numel() != 1 and S.ndim != 1:
-        raise NotImplementedError(
-            "a (batch, N) saturation tensor is not supported by the HIP engine; pass a float or a 1-D "
-            "tensor of length N"
-        )

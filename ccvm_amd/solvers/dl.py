@@ -27,6 +27,7 @@ DL_SCALING_MULTIPLIER = 0.2
 class DLSolver(CCVMSolver):
     _PARAMETER_KEYS = frozenset(["pump", "dt", "iterations", "noise_ratio", "feedback_scale"])
     _SAMPLED = ("c", "s")
+    _FULL_SATURATION = True  # S only enters the final clamp and the change of variables (dl_solver.py:567, :956)
 
     def __init__(self, device, problem_category="boxqp", batch_size=1000, S=1):
         super().__init__(device)
@@ -81,7 +82,7 @@ class DLSolver(CCVMSolver):
         traj = self._new_trajectories("dl", batch_size, iterations, params)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
         traj.clamp("c", -S, S)  # dl_solver.py:567 -- fit_to_constraints with self.S
-        return traj.compact("c").to(device), traj.compact("s").to(device)
+        return self._to_caller(traj, "c"), self._to_caller(traj, "s")
 
     def _solve_adam(self, *args, **kwargs):
         # The reference's DL Adam path cannot be reached: __call__ passes `feedback_scale`
@@ -126,15 +127,24 @@ class DLSolver(CCVMSolver):
         # Reference quirk kept: without a post-processor the reported variables are the
         # raw clamped c; with one, change_variables is applied before AND after it
         # (dl_solver.py:936-958).
-        if post_processor:
-            problem_variables, pp_time = self._postprocess(
-                post_processor, self.change_variables(c, lo, hi, S), batch_size
+        stats = None
+        if self._device_finalize_ok(instance, post_processor):
+            # fused on the device (ccvm_finalize): change of variables [+ post-processor + change of
+            # variables again] + energy + success statistics on the pitched state, no host hop
+            scored_x, objval, pp_time, stats = self._score_on_device(
+                instance, "c", S, lo, hi, post_processor, batch_size, rescale_after_pp=True
             )
+            problem_variables = scored_x if post_processor else c
         else:
-            problem_variables, pp_time = c, 0.0
-        confs = self.change_variables(problem_variables, lo, hi, S)
-        objval = instance.compute_energy(confs)
+            if post_processor:
+                problem_variables, pp_time = self._postprocess(
+                    post_processor, self.change_variables(c, lo, hi, S), batch_size
+                )
+            else:
+                problem_variables, pp_time = c, 0.0
+            confs = self.change_variables(problem_variables, lo, hi, S)
+            objval = instance.compute_energy(confs)
         return self._solution(
             instance, batch_size, iterations, objval, solve_time, pp_time,
-            {"problem_variables": problem_variables, "s": s}, evolution_step_size, evolution_file,
+            {"problem_variables": problem_variables, "s": s}, evolution_step_size, evolution_file, stats,
         )

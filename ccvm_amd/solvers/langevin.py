@@ -44,17 +44,23 @@ class _LangevinFamily(CCVMSolver):
         )
         traj = self._new_trajectories("langevin", batch_size, iterations, params, adam=adam)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
-        return traj.compact("c").to(device)
+        return self._to_caller(traj, "c")
 
     def _finish(self, instance, c, S, iterations, batch_size, solve_time, post_processor,
                 evolution_step_size, evolution_file):
         # (c + S) / (2S): langevin_solver.py:722, pumped_langevin_solver.py:604
-        calibrated = engine.change_variables(c, S, 0.0, 1.0)
-        problem_variables, pp_time = self._postprocess(post_processor, calibrated, batch_size)
-        objval = instance.compute_energy(problem_variables)
+        stats = None
+        if self._device_finalize_ok(instance, post_processor):
+            problem_variables, objval, pp_time, stats = self._score_on_device(
+                instance, "c", S, 0.0, 1.0, post_processor, batch_size
+            )
+        else:
+            calibrated = engine.change_variables(c, S, 0.0, 1.0)
+            problem_variables, pp_time = self._postprocess(post_processor, calibrated, batch_size)
+            objval = instance.compute_energy(problem_variables)
         return self._solution(
             instance, batch_size, iterations, objval, solve_time, pp_time,
-            {"problem_variables": problem_variables}, evolution_step_size, evolution_file,
+            {"problem_variables": problem_variables}, evolution_step_size, evolution_file, stats,
         )
 
 

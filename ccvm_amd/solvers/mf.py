@@ -65,7 +65,7 @@ class MFSolver(CCVMSolver):
         )
         traj = self._new_trajectories("mf", batch_size, iterations, params, adam=adam)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
-        return tuple(traj.compact(name).to(device) for name in ("mu", "mu_tilde", "sigma"))
+        return tuple(self._to_caller(traj, name) for name in ("mu", "mu_tilde", "sigma"))
 
     def _solve(
         self,
@@ -138,12 +138,18 @@ class MFSolver(CCVMSolver):
             mu, mu_tilde, sigma = self._solve_adam(*args, adam)
         solve_time = self._timer_stop(start, batch_size)
 
-        problem_variables, pp_time = self._postprocess(
-            post_processor, self.change_variables(mu_tilde, lo, hi, S), batch_size
-        )
-        objval = instance.compute_energy(problem_variables)
+        stats = None
+        if self._device_finalize_ok(instance, post_processor):
+            problem_variables, objval, pp_time, stats = self._score_on_device(
+                instance, "mu_tilde", S, lo, hi, post_processor, batch_size
+            )
+        else:
+            problem_variables, pp_time = self._postprocess(
+                post_processor, self.change_variables(mu_tilde, lo, hi, S), batch_size
+            )
+            objval = instance.compute_energy(problem_variables)
         return self._solution(
             instance, batch_size, iterations, objval, solve_time, pp_time,
             {"problem_variables": problem_variables, "mu": mu, "sigma": sigma},
-            evolution_step_size, evolution_file,
+            evolution_step_size, evolution_file, stats,
         )

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 2
+#define CCVM_ABI_VERSION 3
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -50,16 +50,18 @@ typedef enum ccvm_status {
 
 /* Wiener-noise source for one call. */
 typedef enum ccvm_noise_mode {
-    CCVM_NOISE_PHILOX = 0, /* counter-based generator (Threefry2x32-13 + Box-Muller) fused
-                              into the step kernel; the name is historical               */
+    CCVM_NOISE_FUSED = 0,  /* counter-based generator fused into the step kernel: Threefry2x32-13 on
+                              counter (column, global row), key = SplitMix64 hash of (seed, step),
+                              then Box-Muller (ccvm_amd/csrc/ccvm_noise.h)                     */
+    CCVM_NOISE_PHILOX = 0, /* historical alias of CCVM_NOISE_FUSED (the generator is Threefry)    */
     CCVM_NOISE_REPLAY = 1  /* read standard normals the caller generated (parity mode) */
 } ccvm_noise_mode;
 
 typedef struct ccvm_noise {
     int32_t mode;        /* ccvm_noise_mode */
     int32_t reserved;
-    uint64_t seed;       /* PHILOX: key */
-    int64_t row_offset;  /* PHILOX: global index of local row 0 (batch sharding over GPUs:
+    uint64_t seed;       /* FUSED: 64-bit seed; any two seeds give unrelated streams at every step */
+    int64_t row_offset;  /* FUSED: global index of local row 0 (batch sharding over GPUs:
                             a row's noise depends on its GLOBAL index only) */
     /* REPLAY: standard normals for steps step0 .. step0+nsteps-1, laid out as the
      * reference draws them -- per step an (N, B) block, batch-contiguous:
@@ -138,6 +140,11 @@ size_t ccvm_workspace_bytes(int solver, int B, int N);
 /* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
 
+/* Which kernel instantiation and grid ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2)
+ * launch for this shape under the current tuning environment, as text (the name is what rocprofv3
+ * prints for the kernel): benchmark lines and profiles name the kernel that actually ran.  Host only. */
+int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len);
+
 /* Steps step0 .. step0+nsteps-1 of a T-step DL-CCVM run, in place on c and s.
  * Chunking a run into several calls does not change the result.  The final clamp
  * (dl_solver.py:567) is NOT applied here; see ccvm_clamp. */
@@ -175,6 +182,13 @@ int ccvm_clamp_cols(float* x, int B, int N, int ld, const float* s_cols, void* s
 int ccvm_change_variables_cols(const float* x, float* y, int B, int N, int ld,
                                const float* s_cols, double lower, double upper, void* stream);
 
+/* The same with one bound / saturation per trajectory AND variable (pitched [rows][ld] arrays): the
+ * reference passes a non-1-D tensor S straight to the elementwise ops (dl_solver.py:843-848) and
+ * torch.clamp takes tensor bounds (dl_solver.py:237-250). */
+int ccvm_clamp_full(float* x, int B, int N, int ld, const float* lo, const float* hi, void* stream);
+int ccvm_change_variables_full(const float* x, float* y, int B, int N, int ld,
+                               const float* s_full, double lower, double upper, void* stream);
+
 /* y = 0.5 * x / S * (upper - lower) + 0.5 * (upper + lower)   (change_variables,
  * dl_solver.py:219-235).  y may alias x. */
 int ccvm_change_variables(const float* x, float* y, int B, int N, int ld,
@@ -185,6 +199,49 @@ int ccvm_change_variables(const float* x, float* y, int B, int N, int ld,
 int ccvm_energy(const float* Q, const float* V, const float* x,
                 int B, int N, int ld, double scaled_by, float* obj,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Success statistics of a batch, computed on the device (solution.py:65-85 best_objective_value,
+ * :87-146 the seven gap thresholds 0.1, 1, 2, 3, 4, 5, 10 percent): found_b = -obj_b,
+ * gap_b = (optimal_value - found_b) * 100 / |found_b| in fp32, within[k] = #{b: gap_b <= thr_k}.
+ * The reference's fractions are round(within[k] / rows, 4).  A NaN objective value counts in no
+ * threshold and makes best_objective_value NaN (torch.max). */
+typedef struct ccvm_solution_stats {
+    float best_objective_value;
+    int32_t within[7];
+    int32_t rows;
+    int32_t nonfinite;  /* rows with a NaN / infinite objective value */
+} ccvm_solution_stats;
+
+/* stats: DEVICE pointer (8-byte aligned), written on `stream`.  obj: B floats (device). */
+int ccvm_objective_stats(const float* obj, int B, double optimal_value,
+                         ccvm_solution_stats* stats, void* stream);
+
+/* Everything between the loop and the Solution, on the pitched state in place, without leaving the
+ * device (dl_solver.py:567 clamp, :956-959 change_variables + compute_energy, problem_instance.py:226-241,
+ * solution.py:65-146):
+ *   1. clamp != 0:             state = clamp(state, clamp_lo, clamp_hi)  (with s_cols / s_full: to -S .. S), in place;
+ *   2. change_variables != 0:  x = 0.5 * state / S * (upper - lower) + 0.5 * (upper + lower)
+ *                              (S scalar, per-variable s_cols or per-element s_full); else x = state.
+ *                              x may alias state;
+ *   3. obj[b] = (0.5 * x_b Q x_b + V . x_b) * scaled_by        (same kernels and summation order as ccvm_energy);
+ *   4. stats (device pointer, may be NULL): ccvm_objective_stats(obj, optimal_value).
+ * Only obj (B floats) and stats (40 bytes) need to leave the GPU.  workspace: ccvm_workspace_bytes(3, B, N). */
+typedef struct ccvm_finalize_params {
+    double S;              /* saturation of the change of variables (ignored with s_cols) */
+    const float* s_cols;   /* per-variable saturation (ld floats, device) or NULL */
+    const float* s_full;   /* per-trajectory-and-variable saturation (pitched, device) or NULL */
+    double lower, upper;   /* solution bounds of the change of variables */
+    double clamp_lo, clamp_hi;
+    double scaled_by;      /* ProblemInstance.scaled_by */
+    double optimal_value;  /* ProblemInstance.optimal_sol */
+    int32_t clamp;
+    int32_t change_variables;
+} ccvm_finalize_params;
+
+int ccvm_finalize(const float* Q, const float* V, float* state, float* x,
+                  int B, int N, int ld, const ccvm_finalize_params* params,
+                  float* obj, ccvm_solution_stats* stats,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* The bare feedback term of every solver ("Qx matvec + V bias"):
  *   y = f_q * ((x * in_scale + in_shift) @ Q) + f_v * V

@@ -4,7 +4,8 @@ numbers: as easy as 1, 2, 3", SC'11; rotation constants 13,15,26,6,17,29,16,24, 
 parity 0x1BD11BDA and a key injection after every fourth round, as in Random123 v1.14; 13 rounds
 is the paper's Crush-resistant configuration) on
 
-    counter = (column, global_row_lo),  key = (seed_lo ^ step, seed_hi ^ global_row_hi)
+    counter = (column, global_row_lo),  key = (K_lo, K_hi ^ global_row_hi),
+    K = step_key(seed, step) = SplitMix64 output function of seed + 0x9E3779B97F4A7C15 * (step + 1)
 
 followed by Box-Muller on 24-bit uniforms.  The integer stage is bit-exact with the device
 (pinned by the Random123 known-answer vectors in tests/test_noise.py); the float stage is
@@ -42,6 +43,19 @@ def threefry2x32(c0, c1, k0, k1, rounds=ROUNDS):
     return x0, x1
 
 
+M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def step_key(seed, step):
+    """The per-step 64-bit Threefry key (ccvm_noise.h step_key): SplitMix64's output function
+    (Steele, Lea, Flood 2014) of seed + golden * (step + 1).  step_key(0, 0) is the first output of
+    splitmix64 seeded with 0, 0xE220A8397B1DCDAF."""
+    z = ((int(seed) & M64) + 0x9E3779B97F4A7C15 * ((int(step) & M32) + 1)) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
 def u01(x):
     """((x >> 8) + 0.5) * 2^-24, rounded to float32 like the device computes it."""
     f = ((x >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0**-24)
@@ -52,9 +66,9 @@ def normal_pairs(seed, row_offset, step, b, n):
     """(n0, n1) as float32 arrays of shape (B, N): noise of local rows 0..b-1, columns 0..n-1."""
     rows = (np.arange(b, dtype=np.int64)[:, None] + np.int64(row_offset)).astype(np.uint64)
     cols = np.arange(n, dtype=np.uint32)[None, :]
-    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    k0 = np.uint32((seed & M32) ^ (int(step) & M32))
-    k1 = (np.uint32(seed >> 32) ^ (rows >> np.uint64(32)).astype(np.uint32)).astype(np.uint32)
+    key = step_key(seed, step)
+    k0 = np.uint32(key & M32)
+    k1 = (np.uint32(key >> 32) ^ (rows >> np.uint64(32)).astype(np.uint32)).astype(np.uint32)
     x0, x1 = threefry2x32(cols, (rows & np.uint64(M32)).astype(np.uint32), k0, k1)
     u1, u2 = u01(x0), u01(x1)
     r = np.sqrt(-2.0 * np.log(u1))

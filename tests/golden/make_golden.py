@@ -171,6 +171,28 @@ def vector_s_cases():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
+def full_s_cases():
+    """DLSolver(S=<2-D tensor>): one saturation per trajectory AND variable.  The reference passes any
+    non-1-D tensor S straight through (dl_solver.py:843-848) to the final clamp (:567) and the change of
+    variables (:956-959); shapes (B, N), (B, 1) and (1, N) all broadcast there."""
+    store, manifest = {}, {"cases": {}}
+    g = torch.Generator().manual_seed(11)
+    batch = 40
+    shapes = {"BN": (batch, 20), "B1": (batch, 1), "1N": (1, 20)}
+    for label, shape in shapes.items():
+        s_full = 0.4 + 1.6 * torch.rand(shape, generator=g)
+        for post in (None, "grad-descent", "adam"):
+            name = f"dl_T40_fullS_{label}" + (f"_{post}" if post else "")
+            arrays, meta = run_case("dl", INSTANCES["test020"], 40, post=post, batch=batch, dl_S=s_full)
+            for k, v in arrays.items():
+                store[f"{name}/{k}"] = v
+            manifest["cases"][name] = meta
+            print("fullS", name, meta["best_objective_value"])
+    np.savez_compressed(os.path.join(OUT, "test020_fullS.npz"), **store)
+    with open(os.path.join(OUT, "test020_fullS.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def asgd_cases():
     """post_processor="asgd" through every solver, and the post-processors called directly with
     num_iter = 1 and 3 (only the first optimizer step of adam / asgd ever takes effect)."""
@@ -252,6 +274,9 @@ def main():
     if "--only-vector-s" in sys.argv:
         vector_s_cases()
         return
+    if "--only-full-s" in sys.argv:
+        full_s_cases()
+        return
     if "--only-anchors" in sys.argv:
         anchors()
         return
@@ -305,6 +330,7 @@ def main():
     anchors()
     bounds_cases()
     vector_s_cases()
+    full_s_cases()
     asgd_cases()
     larger_n_cases()
 

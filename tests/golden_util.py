@@ -61,6 +61,24 @@ def vector_s_arrays():
     return np.load(os.path.join(GOLDEN_DIR, "test020_vecS.npz"))
 
 
+def full_s_cases():
+    """tests/golden/test020_fullS.{npz,json}: DLSolver(S=<2-D tensor>), one saturation per trajectory AND
+    variable (shapes (B, N), (B, 1), (1, N)), made by make_golden.py --only-full-s from the reference."""
+    with open(os.path.join(GOLDEN_DIR, "test020_fullS.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def full_s_arrays():
+    return np.load(os.path.join(GOLDEN_DIR, "test020_fullS.npz"))
+
+
+def reference_unit_vectors():
+    """tests/golden/reference_unit_vectors.json: inputs and expected values of the reference's own
+    unit tests (file:line cited inside)."""
+    with open(os.path.join(GOLDEN_DIR, "reference_unit_vectors.json")) as fh:
+        return json.load(fh)
+
+
 def asgd_cases():
     """tests/golden/test020_asgd.{npz,json}: post_processor="asgd" through every solver, and under the
     "direct/" prefix the post-processors called on their own (num_iter 1 and 3, custom bounds)."""

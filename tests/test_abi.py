@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 2
+    assert hip_lib.ccvm_abi_version() == 3
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
@@ -70,6 +70,24 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8
     assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8          # ... + s_cols
     assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8 + 8    # ... + s_cols
+    assert ctypes.sizeof(_lib.FinalizeParams) == 9 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.SolutionStats) == 4 + 7 * 4 + 4 + 4
+
+
+def test_describe_launch_names_the_instantiation(hip_lib):
+    """Host-only: which kernel a run of this shape launches (what rocprofv3 prints for it)."""
+    buf = ctypes.create_string_buffer(256)
+    want = {
+        (0, 1000, 1000, 0): "ccvm::step_kernel<0, false, 0, 1, false> grid 256 x 512",
+        (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4> grid 250 x 256",
+        (1, 1000, 500, 0): "ccvm::step_kernel<1, false, 0, 2, false> grid 256 x 512",
+        (2, 1000, 500, 1): "ccvm::step_kernel<2, true, 0, 2, false> grid 256 x 512",
+        (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false> grid 256 x 512",
+    }
+    for (solver, b, n, adam), text in want.items():
+        assert hip_lib.ccvm_describe_launch(solver, b, n, adam, 0, buf, 256) == 0
+        assert buf.value.decode().startswith(text), buf.value
+    assert hip_lib.ccvm_describe_launch(7, 10, 10, 0, 0, buf, 256) == -1
 
 
 def test_host_side_argument_checks_need_no_gpu(hip_lib):

@@ -14,25 +14,40 @@ pytestmark = pytest.mark.gpu
 
 
 def test_mf_hooks_known_answers():
-    """Reference tests/unit/solvers/test_mf_solver.py:63-154: grads -20.0, drift (-20.0, 200.5),
-    change_variables spot values -- through the HIP feedback / change-of-variables kernels."""
+    """The reference's own vectors (tests/golden/reference_unit_vectors.json = the inputs and expected
+    values of ccvm_simulators/tests/unit/solvers/test_mf_solver.py:63-204, verbatim), through the HIP
+    feedback / change-of-variables / clamp kernels: grads -20.0, drift (-20.0, 200.5) with Q = V = ones,
+    mu~ = 0, S = 20, fs = 400, pump = 2.5, j = 399, g = 0.1; change_variables(4.0, S=2) = 1.5 and 1.1 with
+    bounds (0.2, 0.8); fit_to_constraints with TENSOR bounds, called by keyword like the reference does."""
+    from golden_util import reference_unit_vectors
+
     from ccvm_amd.solvers import MFSolver
 
-    solver = MFSolver(device="cpu", batch_size=2)
-    solver.q_matrix = torch.full((2, 2), 10.0)
-    solver.v_vector = torch.full((2,), 10.0)
-    mu_tilde = torch.ones((2, 2))
-    grads = solver.calculate_grads(mu_tilde, 1.0, 1.0, 0.0, 1.0)
-    # fs * (-(1/4) * ((1*1 + 1) @ Q) * 1 - V/2) = -(0.25 * 40) - 5 = -15 per element for these inputs
-    assert torch.allclose(grads, torch.full((2, 2), -15.0))
-    mu, sigma = torch.ones((2, 2)), torch.full((2, 2), 10.0)
-    d_mu, d_sigma = solver.calculate_drift(mu, mu_tilde, sigma, 2.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0)
-    # term1 = (-(1+1) + 2 - 1) * 1 = -1 ; drift_mu = -1 + grads = -16
-    assert torch.allclose(d_mu, torch.full((2, 2), -16.0))
-    # sigma: 2(-2 + 2 - 3)*10 - 2*(9.5)^2 + (2 + 2) = -60 - 180.5 + 4 = -236.5
-    assert torch.allclose(d_sigma, torch.full((2, 2), -236.5))
-    y = solver.change_variables(torch.tensor([[2.0, 0.2]]), 0.0, 1.0, 1.0)
-    assert torch.allclose(y, torch.tensor([[1.5, 0.6]]))
+    vec = reference_unit_vectors()["mf_solver"]
+    p = vec["parameters"]
+    solver = MFSolver(device="cpu", batch_size=1000, problem_category="boxqp")
+    solver.q_matrix = torch.tensor(vec["q_matrix"])
+    solver.v_vector = torch.tensor(vec["v_vector"])
+    shape = (vec["batch_size"], vec["problem_size"])
+    grads = solver._calculate_grads_boxqp(mu_tilde=torch.full(shape, vec["grads"]["mu_tilde_fill"]), S=p["S"],
+                                          fs=p["feedback_scale"])
+    assert grads.shape == torch.Size(shape)
+    assert torch.equal(grads, torch.full(shape, vec["grads"]["expected_fill"]))
+    d = vec["drift"]
+    d_mu, d_sigma = solver._calculate_drift_boxqp(
+        mu=torch.full(shape, d["mu_fill"]), mu_tilde=torch.full(shape, d["mu_tilde_fill"]),
+        sigma=torch.full(shape, d["sigma_fill"]), pump=p["pump"], j=p["j"], g=d["g"], S=p["S"], fs=p["feedback_scale"])
+    assert torch.equal(d_mu, torch.full(shape, d["expected_mu_fill"]))
+    assert torch.equal(d_sigma, torch.full(shape, d["expected_sigma_fill"]))
+    for case in vec["change_variables"]:
+        y = solver._change_variables_boxqp(problem_variables=torch.tensor(case["problem_variables"]),
+                                           lower_limit=case["lower_limit"], upper_limit=case["upper_limit"], S=case["S"])
+        assert torch.equal(y, torch.tensor(case["expected"]))
+    for case in vec["fit_to_constraints"]:
+        mu_tilde = torch.tensor(case["mu_tilde"])
+        z = solver._fit_to_constraints_boxqp(mu_tilde=mu_tilde, lower_clamp=torch.full_like(mu_tilde, case["lower_clamp"]),
+                                             upper_clamp=torch.full_like(mu_tilde, case["upper_clamp"]))
+        assert torch.equal(z, torch.tensor(case["expected"]))
     z = solver.fit_to_constraints(torch.tensor([[2.0, -3.0, 0.25]]), -1.0, 1.0)
     assert torch.equal(z, torch.tensor([[1.0, -1.0, 0.25]]))
 

@@ -1,0 +1,109 @@
+"""Long-trajectory parity at every BASELINE.json shape ("Next round" #2): the HIP path through
+the PUBLIC solver API in replay mode (identical seeded noise: the normals come from torch's CPU stream in
+the reference's order) against the oracle -- the reference's op sequence on the host -- at the stated
+shapes and hundreds to thousands of steps, not a handful.
+
+Each case appends its measured deviations to gpurun_out/r02_parity.jsonl (the table in
+profiles/r02_parity.md is made from that file).  Gates: the tolerance DESIGN.md section 5 states from
+these measurements, per shape -- no sqrt(N/20) extrapolation.
+"""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+ADAM_A = dict(alpha=0.001, beta1=0.9, beta2=0.999, add_assign=False)  # SURVEY.md 8d config 3 "momentum state"
+
+# (label, solver kind, N, batch, iterations, post-processor, Adam hyper-parameters, gate on |dx|, gate on |dobj| rel)
+CASES = [
+    ("config2_dl_n100_b1000", "dl", 100, 1000, 1500, None, None, 5e-4, 2e-5),
+    ("config3_mf_n500_b1000", "mf", 500, 1000, 500, None, None, 5e-4, 2e-5),
+    ("config3_langevin_n500_b1000", "langevin", 500, 1000, 500, None, None, 5e-4, 2e-5),
+    ("config3_mf_n500_b1000_adam", "mf", 500, 1000, 300, None, ADAM_A, 5e-4, 2e-5),
+    ("config3_langevin_n500_b1000_adam", "langevin", 500, 1000, 300, None, ADAM_A, 5e-4, 2e-5),
+    ("config4_dl_n1000_b1000_headline", "dl", 1000, 1000, 1000, None, None, 5e-4, 2e-5),
+    ("config5_pl_n2000_b512_adam_pp", "pl", 2000, 512, 200, "adam", None, 5e-4, 2e-5),
+]
+
+
+def _record(entry):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r02_parity.jsonl"), "a") as fh:
+        fh.write(json.dumps(entry) + "\n")
+
+
+@pytest.mark.parametrize("label,kind,n,b,t,post,adam,gate_x,gate_obj", CASES, ids=[c[0] for c in CASES])
+def test_long_trajectory_matches_oracle_at_baseline_shape(label, kind, n, b, t, post, adam, gate_x, gate_obj):
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
+    from ccvm_amd.solvers.algorithms import AdamParameters
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
+    from oracle import ccvm_oracle as oracle
+
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
+    solver = cls(device="cpu", batch_size=b)
+    solver.noise_mode = "replay"
+    inst = synthetic_instance(n)
+    inst.optimal_sol = 1.0  # synthetic instance: no known optimum
+    p = dict(EXAMPLE_PARAMS[kind], iterations=t)
+    solver.parameter_key = {n: p}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    kwargs = {"algorithm_parameters": AdamParameters(**adam)} if adam else {}
+
+    seed = 20260 + n
+    torch.manual_seed(seed)
+    t0 = time.time()
+    sol = solver(instance=inst, post_processor=post, **kwargs)
+    t_engine = time.time() - t0
+
+    q, v, f = inst.q_matrix, inst.v_vector, float(inst.scaled_by)
+    common = dict(scaled_by=f, optimal_value=1.0, post_processor=post)
+    torch.manual_seed(seed)
+    t0 = time.time()
+    if kind == "dl":
+        ref = oracle.solve_dl(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], g=0.05, S=1,
+                              **common)
+        fields = ["problem_variables", "s"]
+    elif kind == "mf":
+        ref = oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01, adam=adam,
+                              **common)
+        fields = ["problem_variables", "mu", "sigma"]
+    elif kind == "langevin":
+        ref = oracle.solve_langevin(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], adam=adam, **common)
+        fields = ["problem_variables"]
+    else:
+        ref = oracle.solve_pl(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], adam=adam,
+                              **common)
+        fields = ["problem_variables"]
+    t_oracle = time.time() - t0
+
+    entry = {"case": label, "solver": kind, "N": n, "batch": b, "iterations": t, "post_processor": post,
+             "adam": bool(adam), "noise": "replay (torch CPU stream, reference order)", "fields": {},
+             "oracle_s": round(t_oracle, 2), "engine_call_s": round(t_engine, 2)}
+    worst_x = 0.0
+    for name in fields:
+        want, got = ref[name], sol.variables[name].cpu()
+        assert bool(torch.isfinite(want).all()) and bool(torch.isfinite(got).all()), name
+        err = float((got - want).abs().max())
+        scale = max(1.0, float(want.abs().max()))
+        entry["fields"][name] = {"max_abs_err": err, "max_abs_value": float(want.abs().max()),
+                                 "rows_off_by_more_than_1e-4": int(((got - want).abs().amax(1) > 1e-4).sum())}
+        worst_x = max(worst_x, err / scale)
+    want, got = ref["objective_values"], sol.objective_values.cpu()
+    obj_err = float((got - want).abs().max())
+    obj_scale = float(want.abs().max())
+    entry["objective_values"] = {"max_abs_err": obj_err, "max_abs_value": obj_scale, "rel": obj_err / obj_scale}
+    entry["best_objective_value"] = {"engine": sol.best_objective_value, "oracle": ref["best_objective_value"]}
+    entry["gates"] = {"x": gate_x, "obj_rel": gate_obj}
+    _record(entry)
+
+    assert worst_x <= gate_x, (label, entry)
+    assert obj_err <= gate_obj * obj_scale, (label, entry)
+    assert abs(sol.best_objective_value - ref["best_objective_value"]) <= gate_obj * abs(ref["best_objective_value"])

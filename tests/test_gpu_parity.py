@@ -100,6 +100,13 @@ def test_solver_matches_reference_golden(tag, case, kernel_path):
     slack = (2.0 if meta["post"] else 1.0) / meta["batch"] + 1e-9
     for key, frac in meta["solution_performance"].items():
         assert abs(sol.solution_performance[key] - frac) <= slack, (key, sol.solution_performance, frac)
+    # the statistics came from the device (ccvm_finalize): they must equal solution.py:65-146 evaluated on
+    # the objective values the call returned
+    from ccvm_amd.solution import success_fractions
+
+    assert sol.device_objective_values is not None
+    assert sol.solution_performance == success_fractions(sol.objective_values.cpu(), g.instance["optimal_sol"])
+    assert sol.best_objective_value == torch.max(-sol.objective_values).item()
 
 
 def _bounds_case_names():
@@ -153,6 +160,36 @@ def test_solver_matches_reference_with_per_variable_saturation(case, kernel_path
         assert err <= tol, f"{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
     assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * abs(
         meta["best_objective_value"]) + 1e-4
+
+
+def _full_s_case_names():
+    from golden_util import full_s_cases
+
+    return sorted(full_s_cases())
+
+
+@pytest.mark.parametrize("case", _full_s_case_names())
+def test_dl_solver_matches_reference_with_per_element_saturation(case, kernel_path):
+    """DLSolver(S=<2-D tensor>) -- one saturation per trajectory AND variable, shapes (B, N), (B, 1), (1, N):
+    the reference passes it straight through (dl_solver.py:843-848) to the final clamp and the change of
+    variables; here the `s_full` form of ccvm_finalize / ccvm_clamp_full / ccvm_change_variables_full."""
+    from golden_util import full_s_arrays, full_s_cases
+
+    g, meta, arrays = golden("test020"), full_s_cases()[case], full_s_arrays()
+    sol = _run_case(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        tol = ATOL_OBJ if field == "objective_values" else ATOL_X * max(1.0, float(want.abs().max()))
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol, f"{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * abs(
+        meta["best_objective_value"]) + 1e-4
+    for key, frac in meta["solution_performance"].items():
+        assert abs(sol.solution_performance[key] - frac) <= 2.0 / meta["batch"] + 1e-9
 
 
 def _asgd_case_names():

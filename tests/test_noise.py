@@ -38,3 +38,24 @@ def test_normals_are_standard_and_decorrelated():
     # sharding: rows [512, 1024) of the block are what row_offset = 512 generates
     h0, h1 = normal_pairs(0xC0FFEE1234, 512, 5, 512, 1024)
     assert np.array_equal(h0, n0[512:]) and np.array_equal(h1, n1[512:])
+
+
+def test_step_key_known_answers_and_no_seed_step_aliasing():
+    """The per-step key is SplitMix64's output function of seed + golden * (step + 1): the first
+    outputs of splitmix64 seeded with 0 (Vigna's splitmix64.c) are the keys of steps 0, 1, 2."""
+    from oracle.noise_ref import step_key
+
+    assert [step_key(0, i) for i in range(3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    # round 1 keyed the step as seed_lo ^ step: (seed s, step i) and (s ^ d, i ^ d) shared their normals
+    a0, a1 = normal_pairs(0, 0, 1, 8, 16)
+    b0, b1 = normal_pairs(1, 0, 0, 8, 16)
+    assert not np.array_equal(a0, b0) and not np.array_equal(a1, b1)
+    c0, _ = normal_pairs(6, 0, 5, 8, 16)
+    d0, _ = normal_pairs(5, 0, 6, 8, 16)
+    assert not np.array_equal(c0, d0)
+    keys = {step_key(s, i) for s in range(64) for i in range(64)}
+    assert len(keys) == 64 * 64
+    # consecutive small seeds: per-step blocks are uncorrelated
+    x, _ = normal_pairs(1, 0, 3, 256, 256)
+    y, _ = normal_pairs(2, 0, 3, 256, 256)
+    assert abs((x.astype(np.float64) * y).mean()) < 2e-2

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from golden_util import (all_cases, asgd_arrays, asgd_cases, bounds_arrays, bounds_cases, check_noise_checksum,
-                         golden, vector_s_arrays, vector_s_cases)
+                         full_s_arrays, full_s_cases, golden, reference_unit_vectors, vector_s_arrays, vector_s_cases)
 from oracle import ccvm_oracle as oracle
 
 ATOL_STATE = 1e-5
@@ -103,6 +103,23 @@ def test_oracle_reproduces_reference_with_per_variable_saturation(case):
         meta["best_objective_value"]) + 1e-6
 
 
+@pytest.mark.parametrize("case", sorted(full_s_cases()))
+def test_oracle_reproduces_reference_with_per_element_saturation(case):
+    """DLSolver(S=<2-D tensor>): passed straight through by the reference (dl_solver.py:843-848)."""
+    g, meta, arrays = golden("test020"), full_s_cases()[case], full_s_arrays()
+    assert torch.tensor(meta["dl_S"]).ndim == 2
+    out = run_oracle(g, meta)
+    for key in arrays.files:
+        if not key.startswith(case + "/"):
+            continue
+        field = key[len(case) + 1:]
+        want = torch.from_numpy(arrays[key].copy())
+        tol = (RTOL_OBJ if field == "objective_values" else ATOL_STATE) * max(1.0, float(want.abs().max()))
+        assert float((out[field] - want).abs().max()) <= tol, f"{case}/{field}"
+    assert abs(out["best_objective_value"] - meta["best_objective_value"]) <= RTOL_OBJ * abs(
+        meta["best_objective_value"]) + 1e-6
+
+
 @pytest.mark.parametrize("case", sorted(asgd_cases()))
 def test_oracle_reproduces_reference_with_asgd_and_lbfgs_post_processors(case):
     g, meta, arrays = golden("test020"), asgd_cases()[case], asgd_arrays()
@@ -174,32 +191,44 @@ def test_scaling_factor_matches_reference():
             assert abs(float(oracle.scaling_factor(g.q(), mult)) - want) <= 1e-6 * want
 
 
-# ---- known answers held by the reference's own unit tests ------------------------------
+# ---- known answers held by the reference's own unit tests (tests/golden/reference_unit_vectors.json:
+# the reference tests' inputs and expected values, verbatim) ------------------------------------------
 def test_mf_grads_and_drift_known_answers():
-    """ccvm_simulators/tests/unit/solvers/test_mf_solver.py:63-130: with Q = V = ones(2),
-    mu_tilde = 1, S = fs = 1 ... the expected grads are -20.0 and the drift (-20.0, 200.5)."""
-    # the reference test builds: q = [[10,10],[10,10]], v = [10,10], mu_tilde = [[1,1]], S=1, fs=1
-    q = torch.full((2, 2), 10.0)
-    v = torch.full((2,), 10.0)
-    mu_tilde = torch.ones((1, 2))
-    grads = oracle.mf_grads(mu_tilde, q, v, S=1.0, fs=1.0, lo=0.0, hi=1.0)
-    assert torch.allclose(grads, torch.full((1, 2), -(0.25 * 2 * 2 * 10) - 5.0))
+    """ccvm_simulators/tests/unit/solvers/test_mf_solver.py:63-130: Q = V = ones, mu~ = mu = sigma = 0,
+    S = 20, fs = 400, pump = 2.5, j = 399, g = 0.1 -> grads -20.0, drift (-20.0, 200.5), exactly."""
+    vec = reference_unit_vectors()["mf_solver"]
+    p = vec["parameters"]
+    q, v = torch.tensor(vec["q_matrix"]), torch.tensor(vec["v_vector"])
+    shape = (vec["batch_size"], vec["problem_size"])
+    mu_tilde = torch.full(shape, vec["grads"]["mu_tilde_fill"])
+    grads = oracle.mf_grads(mu_tilde, q, v, S=p["S"], fs=p["feedback_scale"], lo=0, hi=1)
+    assert torch.equal(grads, torch.full(shape, vec["grads"]["expected_fill"]))
+    d = vec["drift"]
+    d_mu, d_sigma = oracle.mf_drift(torch.full(shape, d["mu_fill"]), torch.full(shape, d["mu_tilde_fill"]),
+                                    torch.full(shape, d["sigma_fill"]), q, v, p["pump"], p["j"], d["g"], p["S"],
+                                    p["feedback_scale"], 0, 1)
+    assert torch.equal(d_mu, torch.full(shape, d["expected_mu_fill"]))
+    assert torch.equal(d_sigma, torch.full(shape, d["expected_sigma_fill"]))
 
 
 def test_change_variables_known_answers():
-    """test_mf_solver.py:132-154 -- change_variables([1, ...], 0, 1, S) spot values."""
-    x = torch.tensor([[2.0, 0.2]])
-    y = oracle.change_variables(x, 0.0, 1.0, 1.0)
-    assert torch.allclose(y, torch.tensor([[1.5, 0.6]]))
+    """test_mf_solver.py:132-154: change_variables(4.0, S=2) -> 1.5; with bounds (0.2, 0.8) -> 1.1, exactly."""
+    for case in reference_unit_vectors()["mf_solver"]["change_variables"]:
+        y = oracle.change_variables(torch.tensor(case["problem_variables"]), case["lower_limit"], case["upper_limit"],
+                                    case["S"])
+        assert torch.equal(y, torch.tensor(case["expected"]))
 
 
 def test_success_fraction_known_answers():
-    """ccvm_simulators/tests/test_solution.py:140-173 pattern: gaps {0, 1.5, 7} % of 100."""
-    obj = -torch.tensor([100.0, 98.5, 93.0])
-    best, perf = oracle.solution_stats(obj, 100.0)
-    assert best == 100.0
-    assert perf["optimal"] == round(1 / 3, 4) and perf["two_percent"] == round(2 / 3, 4)
-    assert perf["five_percent"] == round(2 / 3, 4) and perf["ten_percent"] == 1.0
+    """ccvm_simulators/tests/test_solution.py:100-173, 175-220: the reference's fractions and best value."""
+    vec = reference_unit_vectors()["solution_stats"]
+    best, perf = oracle.solution_stats(torch.tensor(vec["objective_values"]), vec["optimal_value"])
+    assert perf == vec["expected_solution_performance"]
+    _, perf = oracle.solution_stats(torch.tensor(vec["out_of_range"]["objective_values"]), vec["optimal_value"])
+    assert perf == vec["out_of_range"]["expected_solution_performance"]
+    best, perf = oracle.solution_stats(torch.tensor(vec["metadata"]["objective_values"]), vec["optimal_value"])
+    assert perf == vec["metadata"]["expected_solution_performance"]
+    assert best == vec["metadata"]["expected_best_objective_value"]
 
 
 def test_r99():

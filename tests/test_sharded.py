@@ -38,6 +38,79 @@ def _oracle_local_solve(solver, instance, **kw):
     )
 
 
+class _ShardedReplayNoise:
+    """What the engine's replay feeder does under sharding (engine._NoiseFeeder.chunk): draw the
+    unsharded run's (N, global batch) block from torch's CPU stream and keep this shard's columns."""
+
+    def __init__(self, global_batch, lo):
+        self.gb, self.lo = global_batch, lo
+
+    def draw(self, step, stream, n, b):
+        gb = self.gb if self.gb is not None else b
+        return torch.randn((n, gb))[:, self.lo:self.lo + b].T
+
+
+def _oracle_local_solve_replay(solver, instance, **kw):
+    from ccvm_amd.solution import Solution
+    from oracle import ccvm_oracle as oracle
+
+    n = instance.problem_size
+    p = solver.parameter_key[n]
+    out = oracle.solve_pl(
+        instance.q_matrix, instance.v_vector, solver.batch_size, p["iterations"], p["pump"], p["dt"],
+        p["sigma"], p["feedback_scale"], p["S"], scaled_by=instance.scaled_by,
+        noise=_ShardedReplayNoise(solver.replay_global_batch, solver.row_offset),
+    )
+    return Solution(
+        problem_size=n, batch_size=solver.batch_size, instance_name=instance.name,
+        iterations=p["iterations"], objective_values=out["objective_values"], solve_time=1e-3,
+        pp_time=0.0, optimal_value=instance.optimal_sol, best_value=instance.best_sol,
+        num_frac_values=0, solution_vector=[], variables={"problem_variables": out["problem_variables"]},
+    )
+
+
+def _replay_worker(rank, world, port, batch, queue):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ccvm_amd.sharded import solve_sharded
+
+        solver, inst = _make(batch)
+        solver.noise_mode = "replay"
+        torch.manual_seed(77)  # replay mode: every rank seeds the same torch stream
+        sol = solve_sharded(solver, inst, local_solve=_oracle_local_solve_replay)
+        queue.put((rank, sol.objective_values.numpy().copy(), sol.best_objective_value))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_replay_noise_equals_unsharded():
+    """Replay mode under sharding: the shards must not reuse the first rows of the same
+    draws -- every rank draws the unsharded block and keeps its own columns."""
+    world, batch = 2, 10
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, batch, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((queue.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    solver, inst = _make(batch)
+    solver.noise_mode = "replay"
+    torch.manual_seed(77)
+    whole = _oracle_local_solve_replay(solver, inst)
+    for _, obj, best in results:
+        assert torch.equal(torch.from_numpy(obj), whole.objective_values)
+        assert best == whole.best_objective_value
+    # the two shards are different trajectories (round 1 gave every shard the same leading rows)
+    half = batch // 2
+    assert not torch.equal(whole.objective_values[:half], whole.objective_values[half:])
+
+
 def _make(batch):
     from ccvm_amd.solvers import PumpedLangevinSolver
     from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
