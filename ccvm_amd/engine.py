@@ -400,7 +400,8 @@ class Trajectories:
         with torch.cuda.device(self.device):
             if is_per_element(hi):
                 sat = saturation_full(hi, self.b, self.n, self.device)
-                rc = self.lib.ccvm_clamp_full(_ptr(self.state[name]), self.b, self.n, self.ld, _ptr(-sat), _ptr(sat),
+                neg = -sat  # a named tensor: a temporary would be freed (and its memory reused) before the launch
+                rc = self.lib.ccvm_clamp_full(_ptr(self.state[name]), self.b, self.n, self.ld, _ptr(neg), _ptr(sat),
                                               _stream_ptr())
             elif is_per_variable(hi):
                 cols = saturation_columns(hi, self.n, self.device)
@@ -499,9 +500,9 @@ def change_variables(x, S, lower, upper):
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
         if is_per_element(S):
-            rc = lib.ccvm_change_variables_full(_ptr(xp), _ptr(xp), b, n, xp.shape[1],
-                                                _ptr(saturation_full(S, b, n, dev)), float(lower), float(upper),
-                                                _stream_ptr())
+            sat = saturation_full(S, b, n, dev)  # named: alive until the launch is enqueued
+            rc = lib.ccvm_change_variables_full(_ptr(xp), _ptr(xp), b, n, xp.shape[1], _ptr(sat), float(lower),
+                                                float(upper), _stream_ptr())
         elif is_per_variable(S):
             cols = saturation_columns(S, n, dev)
             rc = lib.ccvm_change_variables_cols(_ptr(xp), _ptr(xp), b, n, xp.shape[1], _ptr(cols), float(lower),
@@ -524,8 +525,8 @@ def clamp(x, lo, hi):
     with torch.cuda.device(dev):
         xp = pack(xg, rows_of(b), ld_of(n))
         if not is_per_variable(hi) and not (scalar(lo) and scalar(hi)):
-            rc = lib.ccvm_clamp_full(_ptr(xp), b, n, xp.shape[1], _ptr(_full_pitched(lo, b, n, dev)),
-                                     _ptr(_full_pitched(hi, b, n, dev)), _stream_ptr())
+            lo_p, hi_p = _full_pitched(lo, b, n, dev), _full_pitched(hi, b, n, dev)  # both alive at the launch
+            rc = lib.ccvm_clamp_full(_ptr(xp), b, n, xp.shape[1], _ptr(lo_p), _ptr(hi_p), _stream_ptr())
         elif is_per_variable(hi):
             cols = saturation_columns(hi, n, dev)
             rc = lib.ccvm_clamp_cols(_ptr(xp), b, n, xp.shape[1], _ptr(cols), _stream_ptr())
@@ -693,7 +694,8 @@ def finalize_pitched(prob, state, x, b, n, S, lower, upper, scaled_by, optimal_v
         if post_processor:
             if clamp is not None:
                 if s_full is not None:
-                    rc = lib.ccvm_clamp_full(_ptr(state), b, n, prob.ld, _ptr(-s_full), _ptr(s_full), _stream_ptr())
+                    neg = -s_full
+                    rc = lib.ccvm_clamp_full(_ptr(state), b, n, prob.ld, _ptr(neg), _ptr(s_full), _stream_ptr())
                 elif s_cols is not None:
                     rc = lib.ccvm_clamp_cols(_ptr(state), b, n, prob.ld, _ptr(s_cols), _stream_ptr())
                 else:

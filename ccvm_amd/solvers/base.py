@@ -259,8 +259,8 @@ class CCVMSolver(ABC):
             isinstance(instance, ProblemInstance)
             and type(instance).compute_energy is ProblemInstance.compute_energy
             and "compute_energy" not in vars(instance)
-            and instance.q_matrix is self.q_matrix
-            and instance.v_vector is self.v_vector
+            and instance.q_matrix is getattr(self, "q_matrix", None)
+            and instance.v_vector is getattr(self, "v_vector", None)
         )
         pp = not post_processor or (isinstance(post_processor, str) and post_processor.lower() in engine.PP_DEFAULTS)
         return bool(getattr(self, "_traj", None) is not None and hooks and energy and pp
