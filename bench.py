@@ -330,7 +330,7 @@ def main():
     if rank == 0:
         na = 2 if kind == "dl" else 1
         launch = describe_launch(kind, b, n)
-        steps_per_launch = min(args.steps, 4096) if "persist_kernel" in launch else 1
+        steps_per_launch = min(args.steps, 4096) if ("persist_kernel" in launch or "cluster_kernel" in launch) else 1
         flops_per_step = 2.0 * na * n * n * b
         bytes_per_step = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
         achieved = flops_per_step / (gpu_ms_per_step * 1e-3) / 1e12

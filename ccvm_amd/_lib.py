@@ -146,6 +146,7 @@ SIGNATURES = {
     "ccvm_unpack": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "ccvm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_workspace_bytes_cols": (c_size_t, [c_int, c_int, c_int]),
+    "ccvm_status_offset": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_describe_launch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_size_t]),
     "ccvm_dl_run": (
         c_int,

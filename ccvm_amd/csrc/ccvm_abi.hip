@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../include/ccvm_hip.h"
+#include "ccvm_cluster.h"
 #include "ccvm_kernels.h"
 #include "ccvm_persist_launch.h"
 #include "ccvm_schedule.h"
@@ -84,13 +85,19 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 // Tuning knobs from the environment (tests / profiling only), read ONCE per ABI call: the per-step
 // launch loop never touches environ (getenv is a linear scan, and not safe against a concurrent
 // setenv from another host thread).
-//   CCVM_AMD_KERNEL=tile      force the per-step tile kernel where the persistent kernel would apply
+//   CCVM_AMD_KERNEL=tile      force the per-step tile kernel where a persistent kernel would apply
+//   CCVM_AMD_KERNEL=cluster   the column-cluster persistent kernel wherever it applies (256 < N <= 512,
+//                             MF / Langevin), also for batches whose clusters run in several rounds;
+//                             =nocluster keeps those sizes on the per-step tile kernel
 //   CCVM_AMD_KS=1|2           force the tile shape (32 x 128 / 32 x 64 split-K)
 //   CCVM_AMD_XCD=0            linear block -> tile map instead of the XCD rectangles
 //   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
 //   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
+constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
+
 struct Tuning {
     bool force_tile = false;
+    int cluster = CLUSTER_DEFAULT;  // 1: the cluster kernel wherever it applies, 0: never, -1: see want_cluster
     int ks = 0;          // 0: choose by grid size
     bool xcd = true;
     int xcd_xc = 0;      // 0: choose by L2 footprint
@@ -99,7 +106,11 @@ struct Tuning {
 
 Tuning read_tuning() {
     Tuning t;
-    if (const char* e = std::getenv("CCVM_AMD_KERNEL")) t.force_tile = !std::strcmp(e, "tile");
+    if (const char* e = std::getenv("CCVM_AMD_KERNEL")) {
+        t.force_tile = !std::strcmp(e, "tile");
+        if (!std::strcmp(e, "cluster")) t.cluster = 1;
+        if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = 0;
+    }
     if (const char* e = std::getenv("CCVM_AMD_KS"))
         if (e[0] == '1' || e[0] == '2') t.ks = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD")) t.xcd = e[0] != '0';
@@ -220,6 +231,34 @@ size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float);
 // the per-step kernel; read once per ABI call so a test can flip it between calls).
 bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
+// ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 512, one-stream solvers ---------
+int cluster_count(int B) { return (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS); }
+// status word (its own 128-byte line) + one 256-byte counter pair per cluster, clusters padded to 8
+size_t cluster_sync_bytes(int B) { return 128 + (size_t)((cluster_count(B) + 7) / 8 * 8) * 256; }
+// Default: only while every cluster is resident at once (<= 256 workgroups, one per CU: B <= 1024 at
+// N = 500).  There the launch-free time loop wins 10-13 % over the tile kernel (7.05 vs 8.15 us per step,
+// Langevin N = 500, B = 1000); with more clusters than CUs they run in rounds and the tile kernel's larger
+// tiles are the better use of the chip.
+bool want_cluster(int B, int N, const Tuning& tun) {
+    if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
+    const int G = (N + CL_COLS - 1) / CL_COLS;
+    if (tun.cluster < 0 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
+    return (size_t)cluster_count(B) * 2 * CL_ROWS * ccvm_ld(N) * sizeof(float) < ((size_t)1 << 31);  // 32-bit buffer offsets
+}
+// the part of ClusterArgs every solver shares; returns the counters' address (zeroed before each launch)
+unsigned* cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
+                       const ccvm_noise* nz, float* table, void* sync_area) {
+    std::memset(&ca, 0, sizeof(ca));
+    ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
+    ca.status = static_cast<unsigned*>(sync_area);
+    ca.sync = ca.status + 32;
+    ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
+    ca.B = B; ca.N = N; ca.ld = ld;
+    ca.nclusters = cluster_count(B);
+    ca.G = (N + CL_COLS - 1) / CL_COLS;
+    return ca.sync;
+}
+
 template <int MODE, bool ADAM>
 int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
     if constexpr (MODE == MODE_DL) persist_launch_dl(a, st);
@@ -263,13 +302,20 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
         case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
-        case 1: return 3 * state + qs + table_bytes();   // MF: measured-amplitude ping-pong + noise carry
-        case 2: return state + qs + table_bytes();       // Langevin: c'
+        // MF: measured-amplitude ping-pong + noise carry; Langevin: c' + a second exchange buffer of the
+        // cluster path; both: the cluster path's status word and counters
+        case 1: return 3 * state + qs + table_bytes() + cluster_sync_bytes(B);
+        case 2: return 2 * state + qs + table_bytes() + cluster_sync_bytes(B);
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
         case 5: return qs;                               // ccvm_feedback
         default: return 0;
     }
+}
+
+size_t ccvm_status_offset(int solver, int B, int N) {
+    if (solver != 1 && solver != 2) return (size_t)-1;
+    return ccvm_workspace_bytes(solver, B, N) - cluster_sync_bytes(B);
 }
 
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
@@ -283,6 +329,13 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
+    if (solver != 0 && !want_persist(N, tun) && want_cluster(B, N, tun)) {
+        const int G = (N + CL_COLS - 1) / CL_COLS;
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d> grid %d x 256 threads (%d clusters of %d workgroups), up to %d steps per launch",
+                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B) + 7) / 8 * 8 * G, cluster_count(B), G,
+                      TABLE_STEPS);
+        return CCVM_OK;
+    }
     if (want_persist(N, tun)) {
         const int nch = std::min((N + 15) / 16, 16);
         const int cw = nch == 1 ? 16 : nch == 2 ? 32 : 64;
@@ -296,7 +349,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun);
-        std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
+        std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
                       solver, ad ? "true" : "false", a.ks, (per_variable_s && solver != 0) ? "true" : "false",
                       a.nrb * a.ncb, WG_THREADS, a.xr, a.xc);
     }
@@ -475,6 +528,41 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         return CCVM_OK;
     }
 
+    if (want_cluster(B, N, tun)) {
+        // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
+        const float* qsum;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum))) return rc;
+        char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        ClusterArgs ca;
+        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        unsigned* counters = cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes());
+        ca.x0 = mu; ca.x1 = sigma; ca.xt = mu_tilde_out;
+        ca.xb0 = static_cast<float*>(ws); ca.xb1 = static_cast<float*>(ws) + state;
+        ca.in_scale = (float)(ul / S_eff); ca.in_shift = (float)up; ca.S = (float)S_eff; ca.s_cols = s_cols;
+        PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
+        AdamSched asc;
+        persist_adam(pa_ad, asc, adam, use_adam);
+        ca.ad = pa_ad.ad; ca.am = pa_ad.am; ca.av = pa_ad.av;
+        if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
+            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            if (hipMemsetAsync(counters, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess)
+                return fail(CCVM_E_HIP, "%s: memset failed", fn);
+            ca.step0 = step0 + done;
+            ca.nsteps = k;
+            ca.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
+            if (replay) ca.w0 = nz->w0 + (size_t)done * N * B;
+            cluster_launch_mf(ca, use_adam, st);
+            CCVM_CHECK_LAUNCH(fn);
+        }
+        return CCVM_OK;
+    }
+
     float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
     float* carry = static_cast<float*>(ws) + 2 * state;  // this step's normals (fused mode)
     if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
@@ -562,9 +650,10 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
 
+    // workspace: [c' = exchange buffer 0][exchange buffer 1][column sums of Q][schedule table][cluster sync]
     const size_t state = (size_t)ccvm_rows(B) * ld;
     float* buf[2] = {c, static_cast<float*>(ws)};
-    if (hipMemsetAsync(ws, 0, state * sizeof(float), st) != hipSuccess)
+    if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
@@ -572,13 +661,14 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
-    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + state, st, &a.qsum))) return rc;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
     if (s_cols) {
         a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(2, B, N), st);
         a.s_cols = s_cols;
     }
+    char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
+    float* table = reinterpret_cast<float*>(after);
     if (want_persist(N, tun)) {
-        float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = a.Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table; pa.s_cols = s_cols;
@@ -598,6 +688,33 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             rc = use_adam ? launch_persist<MODE_LANGEVIN, true>(pa, st, fn)
                           : launch_persist<MODE_LANGEVIN, false>(pa, st, fn);
             if (rc) return rc;
+        }
+        return CCVM_OK;
+    }
+    if (want_cluster(B, N, tun)) {
+        // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
+        ClusterArgs ca;
+        unsigned* counters = cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes());
+        ca.x0 = c;
+        ca.xb0 = static_cast<float*>(ws); ca.xb1 = static_cast<float*>(ws) + state;
+        ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.s_cols = s_cols;
+        PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
+        AdamSched asc;
+        persist_adam(pa_ad, asc, adam, use_adam);
+        ca.ad = pa_ad.ad; ca.am = pa_ad.am; ca.av = pa_ad.av;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
+                       step0 + done, k, asc};
+            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            if (hipMemsetAsync(counters, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess)
+                return fail(CCVM_E_HIP, "%s: memset failed", fn);
+            ca.step0 = step0 + done;
+            ca.nsteps = k;
+            if (ca.replay) ca.w0 = nz->w0 + (size_t)done * N * B;
+            cluster_launch_lv(ca, use_adam, st);
+            CCVM_CHECK_LAUNCH(fn);
         }
         return CCVM_OK;
     }

@@ -16,6 +16,12 @@ namespace ccvm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void unroll_indices(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
 enum Mode : int {
     MODE_DL = 0,        // two-state DL-CCVM step
     MODE_MF = 1,        // mean-field step (mu, sigma) + next measured amplitude

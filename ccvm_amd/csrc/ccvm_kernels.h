@@ -34,7 +34,6 @@ constexpr int KT = 32;        // K tile
 constexpr int NTHREADS = 256; // consumer threads (the tile mapping)
 constexpr int NPW = 4;        // producer waves (one per SIMD)
 constexpr int WG_THREADS = NTHREADS + 64 * NPW;
-constexpr int NSTAGE = 4;     // LDS ring depth = DMA prefetch distance in tiles
 constexpr int A_TILE = BM * KT;   // floats, 128-B rows, XOR-swizzled 16-B chunks
 constexpr int Q_TILE = KT * BN;   // floats, 512-B rows, linear
 
@@ -121,6 +120,18 @@ __device__ __forceinline__ unsigned long long stamp_delta(unsigned long long a, 
 #define CCVM_NOISE_PROLOGUE_P 4
 #endif
 
+// s_waitcnt vmcnt(min(tiles, K) * P): the counter is an instruction immediate, so a wave-uniform value
+// walks down a chain of compile-time cases (producer waves only; scalar compares and branches).
+template <int P, int K>
+__device__ __forceinline__ void wait_vm_tiles(int tiles) {
+    if constexpr (K == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (tiles >= K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * P) : "memory");
+        else wait_vm_tiles<P, K - 1>(tiles);
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void global_cvoid;
 
@@ -136,7 +147,12 @@ typedef const __attribute__((address_space(1))) void global_cvoid;
 // epilogue work stays balanced.
 // VS: per-variable saturation (StepArgs::s_cols).  A template parameter, not a run-time test of the
 // pointer: with the run-time form the scalar path of the N = 500 kernels lost 0.4 us per step.
-template <int MODE, bool ADAM, int ABL = 0, int KS = 1, bool VS = false>
+// RING: LDS ring depth = DMA prefetch distance in tiles (0 = the default of 4; even, >= 4; a tuning knob
+// for tools/ablate_mid.hip).  Deeper rings are SLOWER for the short-tile kernels (Langevin N = 500,
+// 32 x 64 tiles: 8.14 / 8.30 / 8.49 / 8.73 us per step at depth 4 / 6 / 8 / 10): those kernels are bound by
+// the per-CU LDS-DMA rate (192 KB per workgroup and step at ~68 GB/s per CU), not by its latency, and
+// more tiles queued in front only delay the first one.
+template <int MODE, bool ADAM, int ABL = 0, int KS = 1, bool VS = false, int RING = 0>
 __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     static_assert(KS == 1 || KS == 2, "KS");
     static_assert(!VS || MODE == MODE_MF || MODE == MODE_LANGEVIN, "per-variable saturation: MF and Langevin steps");
@@ -149,7 +165,9 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     constexpr int NQA = 4 / KS;              // b128 A-fragment reads per accumulator and tile
     constexpr int NG = 8 / KS;               // fragment read groups per tile
     constexpr int NR = 16 / KS;              // accumulator registers a wave finishes (epilogue rows)
-    constexpr int NOISE_LDS = NOISY ? 2 * 16 * NTHREADS : 0;
+    constexpr int NSTAGE = RING ? RING : 4;
+    static_assert(NSTAGE >= 4 && NSTAGE % 2 == 0, "ring depth: the consumer loop alternates two fragment sets");
+    constexpr int NOISE_LDS = NOISY ? NA * 16 * NTHREADS : 0;  // DL: (W_c, W_s) per accumulator register
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE + NOISE_LDS];
     float* const lds_noise = lds + NSTAGE * STAGE;
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         }
         auto dma_tile = [&](int kt) {
             if constexpr (ABL & 1) return;
-            const int k0 = min(kt, last) * KT;  // clamped: a duplicate tile in an unread slot is harmless
+            const int k0 = kt * KT;
             float* sbase = lds + (kt % NSTAGE) * STAGE;
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
@@ -431,28 +449,37 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                     : "memory");
             }
         };
-        // tile kt must have landed before the barrier that precedes its first fragment read:
-        // with tiles kt+1 .. kt+2 allowed in flight that is vmcnt(2 * PMAX).  No lgkmcnt wait: the
-        // noise ds_writes are only consumed behind the final barrier.
-        auto publish = [&]() {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
+        // Only real tiles are issued (`issued` of them so far: no duplicate loads of the last tile into
+        // unread slots, 12 % of the L2 reads at N = 1000 with a ring of 4).  Tile kt must have landed
+        // before the barrier that precedes its first fragment read: with `later` tiles issued after it
+        // that is vmcnt(later * PMAX), at most NSTAGE - 2 of them in the steady state.  No lgkmcnt
+        // wait: the noise ds_writes are only consumed behind the final barrier.
+        int issued = 0;
+        auto issue_next = [&]() {
+            if (issued < nkt) {  // wave-uniform
+                dma_tile(issued);
+                ++issued;
+            }
+        };
+        auto publish = [&](int landed) {  // tiles 0 .. landed are in the ring when the barrier opens
+            wait_vm_tiles<PMAX, NSTAGE - 2>(issued - 1 - landed);
             if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
         };
 #pragma unroll
-        for (int kt = 0; kt < NSTAGE; ++kt) dma_tile(kt);
+        for (int kt = 0; kt < NSTAGE; ++kt) issue_next();
         if (gen_noise) {
 #pragma unroll
             for (int u = NPRO_C; u < NPRO_C + NPRO_P; ++u) make_noise(u);
         }
-        publish();  // tiles 0, 1 visible
+        publish(1);  // tiles 0, 1 visible
         // the consumers read tile 0's fragments right after that barrier: slot 0 may only be
         // refilled (with tile NSTAGE) once they are done
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nkt; ++t) {
-            dma_tile(t + NSTAGE);  // into the slot of tile t, whose fragments are already in registers
+            issue_next();  // tile t + NSTAGE into the slot of tile t, whose fragments are already in registers
             constexpr int NLOOP = NUNIT - NPRO_C - NPRO_P;
             if (gen_noise && t < NLOOP) make_noise(NPRO_C + NPRO_P + t);
-            publish();             // tile t + 2 visible
+            publish(t + 2);  // tile t + 2 visible
         }
         if (gen_noise)
             for (int u = NPRO_C + NPRO_P + min(nkt, NUNIT - NPRO_C - NPRO_P); u < NUNIT; ++u) make_noise(u);
@@ -587,22 +614,23 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     };
     {
         if constexpr (ABL & 128) c_last = stamp();
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        using S2 = std::integral_constant<int, 2>;
-        using S3 = std::integral_constant<int, 3>;
-        static_assert(NSTAGE == 4, "the consumer loop is unrolled by the ring depth");
-        // iteration t reads the fragments of tile t+1 from ring stage (t+1) % 4
+        // iteration t reads the fragments of tile t+1 from ring stage (t+1) % NSTAGE: unrolled by the ring
+        // depth so that every stage index is a compile-time constant (LDS addresses = base + immediate);
+        // the two fragment sets alternate (NSTAGE is even)
+        auto iteration = [&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            using Stage = std::integral_constant<int, (i + 1) % NSTAGE>;
+            if constexpr (i % 2 == 0) c_iteration(f0, f1, Stage{});
+            else c_iteration(f1, f0, Stage{});
+        };
         int t = 0;
-        for (; t + 3 < nkt; t += 4) {
-            c_iteration(f0, f1, S1{});
-            c_iteration(f1, f0, S2{});
-            c_iteration(f0, f1, S3{});
-            c_iteration(f1, f0, S0{});
-        }
-        if (t < nkt) { c_iteration(f0, f1, S1{}); ++t; }
-        if (t < nkt) { c_iteration(f1, f0, S2{}); ++t; }
-        if (t < nkt) { c_iteration(f0, f1, S3{}); ++t; }
+        for (; t + NSTAGE - 1 < nkt; t += NSTAGE) unroll_indices(iteration, std::make_integer_sequence<int, NSTAGE>{});
+        unroll_indices([&](auto i_tag) {  // the remaining nkt % NSTAGE tiles
+            if (t < nkt) {
+                iteration(i_tag);
+                ++t;
+            }
+        }, std::make_integer_sequence<int, NSTAGE - 1>{});
     }
     if constexpr (ADAM) {
         // Adam moments: fetched here, not at kernel start (holding 2 x NR more registers through the

@@ -354,7 +354,10 @@ class Trajectories:
             self.adam = _adam_struct(adam, self.adam_m, self.adam_v)
             size_of = self.lib.ccvm_workspace_bytes_cols if self.s_cols is not None else self.lib.ccvm_workspace_bytes
             ws_bytes = size_of(self._SOLVER_ID[kind], self.b, self.n)
-            self.ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=self.device)
+            # zeroed: the workspace holds the run's status word (ccvm_status_offset), which run calls never clear
+            self.ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=self.device)
+            off = self.lib.ccvm_status_offset(self._SOLVER_ID[kind], self.b, self.n)
+            self._status = self.ws[off:off + 4] if off != ctypes.c_size_t(-1).value else None
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
 
     def _set_saturation(self, cp, S):
@@ -414,8 +417,19 @@ class Trajectories:
 
     def compact(self, name):
         """Logical (B, N) copy of one state array, on the GPU."""
+        self.check()
         with torch.cuda.device(self.device):
             return unpack(self.state[name], self.b, self.n)
+
+    def check(self):
+        """Raise if a kernel of this run reported a failure through the workspace's status word (the
+        column-cluster persistent path gives up a bounded wait when its workgroups cannot become resident,
+        e.g. another process holding the GPU).  Synchronises (4 bytes to the host)."""
+        if self._status is not None and int(self._status.cpu().view(torch.int32).item()) != 0:
+            raise _lib.EngineError(
+                f"ccvm_{self.kind}_run: the column-cluster kernel timed out waiting for its workgroups (is another "
+                "process using this GPU?); the trajectories are invalid -- rerun, or set CCVM_AMD_KERNEL=nocluster"
+            )
 
     def view(self, name):
         """The logical (B, N) region of one pitched state array as a strided GPU view (no copy)."""
@@ -430,6 +444,7 @@ class Trajectories:
         ``rescale_after_pp``: the DL solver applies the change of variables again AFTER a
         post-processor (dl_solver.py:936-958: the reported variables are the post-processed ones, the
         scored configuration is change_variables of them)."""
+        self.check()
         with torch.cuda.device(self.device):
             x = torch.zeros_like(self.state[name])
             return finalize_pitched(self.p, self.state[name], x, self.b, self.n, S, lower, upper, scaled_by,

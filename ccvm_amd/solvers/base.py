@@ -412,4 +412,7 @@ class CCVMSolver(ABC):
         """Per-instance solve time (dl_solver.py:933) -- with the device sync the
         reference forgets."""
         self._sync()
-        return (time.time() - start) / batch_size
+        elapsed = time.time() - start
+        if getattr(self, "_traj", None) is not None:
+            self._traj.check()  # a kernel-side failure of the run (status word) raises here
+        return elapsed / batch_size

@@ -1,0 +1,175 @@
+"""GPU tests of the column-cluster persistent kernel (ccvm_amd/csrc/ccvm_cluster.h): 256 < N <= 512,
+MF / Langevin / pumped Langevin and their Adam variants, whole chunks of steps in one launch with the
+cluster's workgroups exchanging the GEMM input through sc1 stores / loads and one counter per step.
+
+Every word of every trajectory is compared with the oracle (fused noise through oracle/noise_ref.py),
+over enough steps that a single stale exchange read would be amplified into a visible difference, on
+grids from one cluster to many more workgroups than the chip holds at once (in-order dispatch)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ATOL_X = 5e-4
+
+_ADAMS = {
+    None: None,
+    "second_moment": {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False},
+    "add_assign": {"alpha": 0.01, "beta1": 0.8, "beta2": 0.99, "add_assign": True},
+    "first_moment_only": {"alpha": 0.002, "beta1": 0.9, "beta2": 1.0, "add_assign": True},
+}
+
+
+@pytest.fixture
+def cluster(monkeypatch):
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+
+
+def _run_engine(kind, n, b, t, adam, seed, row_offset, chunks=None, replay_generator=None):
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    q, v, _ = scaled_qv(n, kind)
+    p = dict(EXAMPLE_PARAMS[kind])
+    noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=row_offset)
+    prob = engine.DeviceProblem(q, v)
+    if kind == "mf":
+        traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=0.01), (0.0, 1.0), noise, adam=adam)
+    else:
+        traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl"), (0.0, 1.0), noise, adam=adam)
+    for k in (chunks or [t]):
+        traj.advance(k)
+    return traj
+
+
+def _run_oracle(kind, n, b, t, adam, seed, row_offset):
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from oracle import ccvm_oracle as oracle
+    from oracle.noise_ref import FusedNoise
+
+    q, v, _ = scaled_qv(n, kind)
+    p = dict(EXAMPLE_PARAMS[kind])
+    ref_noise = FusedNoise(seed, row_offset, single=True)
+    if kind == "mf":
+        mu, mu_tilde, sigma = oracle.mf_loop(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], 0.01,
+                                             (0.0, 1.0), True, adam, ref_noise)
+        return [("mu", mu), ("sigma", sigma), ("mu_tilde", mu_tilde)]
+    if kind == "pl":
+        c = oracle.pl_loop(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], (0.0, 1.0), True,
+                           adam, ref_noise)
+    else:
+        c = oracle.langevin_loop(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], (0.0, 1.0), adam,
+                                 ref_noise)
+    return [("c", c)]
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    # BASELINE config 3 shapes
+    ("langevin", 500, 1000, 40, None), ("mf", 500, 1000, 40, None),
+    ("mf", 500, 1000, 25, "second_moment"), ("langevin", 500, 1000, 25, "add_assign"),
+    # every cluster size G = 5..8 and both K (384, 512), ragged batches and columns, odd shard starts
+    ("pl", 257, 33, 30, None), ("mf", 320, 100, 24, None), ("langevin", 321, 31, 24, "first_moment_only"),
+    ("pl", 384, 70, 20, "second_moment"), ("mf", 385, 64, 20, "add_assign"), ("langevin", 448, 129, 16, None),
+    ("pl", 449, 32, 16, None), ("mf", 512, 256, 12, "first_moment_only"), ("pl", 512, 1, 12, None),
+    # more workgroups than the chip holds at once: clusters run in dispatch order
+    ("pl", 300, 5000, 8, None), ("mf", 500, 3000, 6, None),
+])
+def test_cluster_kernel_matches_oracle(cluster, kind, n, b, t, adam):
+    hp = _ADAMS[adam]
+    seed, row_offset = 0xC1A5_7E12_3456, 128 + (n % 2)
+    traj = _run_engine(kind, n, b, t, hp, seed, row_offset)
+    gate = (max(n, 20) / 20.0) ** 0.5
+    for name, want in _run_oracle(kind, n, b, t, hp, seed, row_offset):
+        got = traj.compact(name).cpu()
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= ATOL_X * gate * scale, f"{kind} N={n} {name}: {err:.3e}"
+    for name, arr in traj.state.items():  # padding stays zero
+        assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
+        assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
+
+
+def test_cluster_kernel_is_what_ran(cluster):
+    """The path under test is the cluster kernel: it differs from the tile kernel in summation order only
+    (close, not bit-identical), and CCVM_AMD_KERNEL=nocluster gives the tile kernel's bits back."""
+    import os
+
+    a = _run_engine("langevin", 400, 96, 20, None, 77, 0).compact("c").cpu()
+    os.environ["CCVM_AMD_KERNEL"] = "nocluster"
+    b_ = _run_engine("langevin", 400, 96, 20, None, 77, 0).compact("c").cpu()
+    os.environ["CCVM_AMD_KERNEL"] = "tile"
+    c = _run_engine("langevin", 400, 96, 20, None, 77, 0).compact("c").cpu()
+    os.environ["CCVM_AMD_KERNEL"] = "cluster"
+    assert torch.equal(b_, c)
+    assert not torch.equal(a, b_) and float((a - b_).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("kind", ["mf", "pl"])
+def test_cluster_chunking_and_sharding_are_exact(cluster, kind):
+    """Chunked launches (evolution sampling, replay staging) and batch shards reproduce the one-launch,
+    unsharded run bit for bit."""
+    n, b, t = 300, 96, 30
+    adam = _ADAMS["add_assign"]
+    whole = _run_engine(kind, n, b, t, adam, 99, 0)
+    parts = _run_engine(kind, n, b, t, adam, 99, 0, chunks=[1, 7, 2, 20])
+    for name in whole.state:
+        assert torch.equal(whole.compact(name), parts.compact(name)), name
+    lo = _run_engine(kind, n, 40, t, adam, 99, 0)
+    hi = _run_engine(kind, n, b - 40, t, adam, 99, 40)
+    for name in whole.state:
+        assert torch.equal(whole.compact(name), torch.cat([lo.compact(name), hi.compact(name)])), name
+
+
+@pytest.mark.parametrize("kind,post", [("mf", None), ("langevin", "adam"), ("pl", "grad-descent")])
+def test_cluster_replay_mode_through_the_public_api(cluster, kind, post):
+    """Replay noise (torch's CPU stream in the reference's order) through Solver.__call__ and the fused
+    finalize, against the oracle's solve_* on the same seed."""
+    from ccvm_amd.solvers import LangevinSolver, MFSolver, PumpedLangevinSolver
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
+    from oracle import ccvm_oracle as oracle
+
+    n, b, t = 300, 70, 60
+    cls = {"mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
+    solver = cls(device="cpu", batch_size=b)
+    solver.noise_mode = "replay"
+    inst = synthetic_instance(n)
+    inst.optimal_sol = 1.0
+    p = dict(EXAMPLE_PARAMS[kind], iterations=t)
+    solver.parameter_key = {n: p}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    torch.manual_seed(31)
+    sol = solver(instance=inst, post_processor=post)
+    q, v, f = inst.q_matrix, inst.v_vector, float(inst.scaled_by)
+    common = dict(scaled_by=f, optimal_value=1.0, post_processor=post)
+    torch.manual_seed(31)
+    if kind == "mf":
+        ref = oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01, **common)
+    elif kind == "langevin":
+        ref = oracle.solve_langevin(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], **common)
+    else:
+        ref = oracle.solve_pl(q, v, b, t, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], **common)
+    assert float((sol.variables["problem_variables"] - ref["problem_variables"]).abs().max()) <= 5e-4
+    want = ref["objective_values"]
+    assert float((sol.objective_values - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_cluster_long_trajectory_under_uneven_load(cluster):
+    """500 steps at the BASELINE shape while a second stream keeps other kernels on the chip (uneven load
+    is what exposes a wrong hand-off): still equal to the undisturbed run bit for bit."""
+    n, b, t = 500, 1000, 500
+    quiet = _run_engine("pl", n, b, t, None, 5, 0).compact("c").cpu()
+    side = torch.cuda.Stream()
+    busy = torch.randn((2048, 2048), device="cuda")
+    stop = False
+    traj = None
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            busy = busy @ busy * 1e-3
+    traj = _run_engine("pl", n, b, t, None, 5, 0, chunks=[100] * 5)
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            busy = busy @ busy * 1e-3
+    loaded = traj.compact("c").cpu()
+    side.synchronize()
+    assert torch.equal(quiet, loaded)
+    assert bool(torch.isfinite(loaded).all())

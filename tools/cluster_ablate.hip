@@ -1,0 +1,59 @@
+// Ablation harness for the column-cluster persistent kernel (developer tool): Langevin, N = 500, B = 1000.
+//   for b in 0 1 2 4 ...; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DCCVM_CLUSTER_ABL=$b tools/cluster_ablate.hip -o tools/cluster_ablate_$b; done
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../ccvm_amd/csrc/ccvm_cluster.h"
+#include "../ccvm_amd/csrc/ccvm_schedule.h"
+using namespace ccvm;
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 500, B = argc > 2 ? atoi(argv[2]) : 1000;
+    const int ld = (N + 127) / 128 * 128, rows = (B + 63) / 64 * 64, steps = 4096;
+    const size_t state = (size_t)rows * ld;
+    float *Q, *V, *c, *xb0, *xb1, *table; unsigned* sync;
+    hipMalloc(&Q, (size_t)ld * ld * 4); hipMalloc(&V, ld * 4); hipMalloc(&c, state * 4); hipMalloc(&xb0, state * 4);
+    hipMalloc(&xb1, state * 4); hipMalloc(&table, steps * TABLE_WORDS * 4); hipMalloc(&sync, 1 << 20);
+    std::vector<float> h((size_t)ld * ld, 0.f);
+    unsigned rng = 1;
+    auto rnd = [&] { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f); };
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) h[(size_t)i * ld + j] = rnd() * 0.02f;
+    hipMemcpy(Q, h.data(), (size_t)ld * ld * 4, hipMemcpyHostToDevice);
+    hipMemcpy(V, h.data(), ld * 4, hipMemcpyHostToDevice);
+    hipMemset(c, 0, state * 4); hipMemset(xb0, 0, state * 4); hipMemset(xb1, 0, state * 4);
+    LvSched sc{0.002, 0.5, 1.0, 0.5, 2.0, 1.0, 1, 1, 15000, 0, steps, AdamSched{}};
+    hipLaunchKernelGGL(lv_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
+    ClusterArgs a; memset(&a, 0, sizeof(a));
+    a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
+    a.status = sync; a.sync = sync + 32;
+    a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
+    a.nclusters = (B + 31) / 32; a.G = (N + 63) / 64;
+    const int grid = (a.nclusters + 7) / 8 * 8 * a.G;
+    unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 8 * 8); hipMemset(dbg, 0, (size_t)grid * 8 * 8);
+    a.dbg = dbg;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(sync, 0, 1 << 20);
+        hipEventRecord(e0, 0);
+        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 4>), dim3(grid), dim3(256), 0, 0, a);
+        else hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 3>), dim3(grid), dim3(256), 0, 0, a);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
+        if (rep == 2) printf("ABL=%2d N=%d B=%d grid %d: %.3f us/step%s\n", CCVM_CLUSTER_ABL, N, B, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
+    }
+    if (CCVM_CLUSTER_ABL & 64) {
+        std::vector<unsigned long long> hd((size_t)grid * 8);
+        hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[8] = {"stage + wait for input loads", "chunks before X", "drain wait", "barrier at X (+signal)",
+                                "chunks X..Y", "poll wait", "barrier at Y + load issue", "rest: chunks, epilogue, publish"};
+        for (int k = 0; k < 8; ++k) {
+            std::vector<double> v;
+            for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 8 + k] / (2.0 * steps));
+            std::sort(v.begin(), v.end());
+            printf("%-34s: min %7.0f  median %7.0f  max %7.0f cycles/phase (100 MHz ticks x?)\n", names[k], v.front(), v[v.size() / 2], v.back());
+        }
+    }
+    return 0;
+}
