@@ -30,8 +30,10 @@
 // same: on a timeout the workgroup sets the launch's status word and leaves (the host raises).
 //
 // Per wave: 16 of the member's 64 columns, both row sets, full K.  K order is natural (k = 4 t + g for
-// MFMA t, lane group g): with LDS row strides == 4 (mod 64) floats every ds_read_b32 of an A or B
-// operand hits 64 distinct banks.  Same noise definition, folded affine map and pinned update
+// MFMA t, lane group g).  LDS operand layout: row strides == 4 (mod 32) floats and rows 8..15 of every
+// 16 shifted by 2 floats, so the 32 lanes of a half-wave (16 rows x 2 k residues) of every ds_read_b32 hit
+// 32 distinct banks (4 r + 2 (r >> 3) + g; with the plain stride-4 layout rows r and r + 8 collided and
+// SQ_LDS_BANK_CONFLICT was a quarter of the kernel: profiles/r02_langevin_n500_b1000_pmc.json history).  Same noise definition, folded affine map and pinned update
 // arithmetic as the other two kernels; only the summation order of the contraction differs.
 #pragma once
 #include "ccvm_persist.h"
@@ -85,11 +87,16 @@ struct ClusterArgs {
 // other set's next input is polled for and fetched after chunk CCVM_CL_Y (> X: a workgroup must signal before
 // it polls, or every member waits for signals nobody has sent).  CCVM_CL_WAVESIG: every storing wave signals
 // for itself right after its own drain (counter target 4 G per input) instead of one lane behind a barrier.
+// Measured at N = 500, B = 1000 (us per step): (X, Y) = (0, 1) 6.61, (0, 2) 6.46, (1, 2) 6.52; per-wave
+// signalling and the poll's sleep length (0 / 1 / 4) change nothing.
 #ifndef CCVM_CL_X
 #define CCVM_CL_X 0
 #endif
 #ifndef CCVM_CL_Y
-#define CCVM_CL_Y 1
+#define CCVM_CL_Y 2
+#endif
+#ifndef CCVM_CL_SLEEP
+#define CCVM_CL_SLEEP 4
 #endif
 #ifndef CCVM_CL_WAVESIG
 #define CCVM_CL_WAVESIG 0
@@ -115,18 +122,20 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     static_assert(MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: one-stream solvers");
     static_assert(KCH == 3 || KCH == 4, "K = 384 or 512");
     constexpr int K = KCH * CL_KC;
-    constexpr int QS = K + 4;        // panel row stride (floats): == 4 (mod 64)
-    constexpr int AS = CL_KC + 4;    // A chunk row stride (floats): == 4 (mod 64)
-    constexpr int ABUF = CL_ROWS * AS;
+    constexpr int QS = K + 4;        // panel row stride (floats): == 4 (mod 32)
+    constexpr int AS = CL_KC + 4;    // A chunk row stride (floats): == 4 (mod 32)
+    constexpr int ABUF = CL_ROWS * AS + 4;  // + the 2-float shift of rows 8..15
+    auto shift = [](int r) { return 2 * ((r >> 3) & 1); };  // bank de-conflicting shift of row / column r
     constexpr int TS = CL_COLS + 4;  // publish tile row stride
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
-    __shared__ __attribute__((aligned(16))) float lds[CL_COLS * QS + 3 * ABUF + CL_ROWS * TS + 4];
-    float* const qp = lds;                    // [64 columns][K + 4]
-    float* const abuf = lds + CL_COLS * QS;   // 3 x [16 rows][128 + 4]
+    constexpr int QPANEL = CL_COLS * QS + 4;
+    __shared__ __attribute__((aligned(16))) float lds[QPANEL + 3 * ABUF + CL_ROWS * TS + 4];
+    float* const qp = lds;                    // [64 columns][K + 4] (+ shift)
+    float* const abuf = lds + QPANEL;         // 3 x [16 rows][128 + 4] (+ shift)
     float* const tile = abuf + 3 * ABUF;      // [16 rows][64 + 4]: a set's new input on its way out
     // lds[DEAD] != 0: a bounded spin gave up.  Written by thread 0 before a barrier, read by everyone behind it
     // (plain LDS accesses: a generic or volatile access would wait for the exchange loads in flight)
-    constexpr int DEAD = CL_COLS * QS + 3 * ABUF + CL_ROWS * TS;
+    constexpr int DEAD = QPANEL + 3 * ABUF + CL_ROWS * TS;
 
     // ---- who am I -----------------------------------------------------------------------------------
     const int tid = threadIdx.x;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     {
         const int c = tid & 63, kk = tid >> 6;
 #pragma unroll 8
-        for (int k = kk; k < K; k += 4) qp[c * QS + k] = a.Q[(size_t)k * ld + col0 + c];
+        for (int k = kk; k < K; k += 4) qp[c * QS + shift(c) + k] = a.Q[(size_t)k * ld + col0 + c];
     }
     const float vj = col_ok ? a.V[col] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[col];
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                     lds[DEAD] = 1.0f;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(CCVM_CL_SLEEP);
             }
         }
     };
@@ -259,7 +268,11 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = tid + 256 * j, r = p >> 5, q4 = p & 31;
-            *reinterpret_cast<f32x4c*>(dst + r * AS + 4 * q4) = ar.v[c][j];
+            // rows 8..15 sit 8 bytes off the 16-byte grid: two 8-byte writes
+            typedef float f32x2c __attribute__((ext_vector_type(2)));
+            float* d = dst + r * AS + shift(r) + 4 * q4;
+            *reinterpret_cast<f32x2c*>(d) = f32x2c{ar.v[c][j][0], ar.v[c][j][1]};
+            *reinterpret_cast<f32x2c*>(d + 2) = f32x2c{ar.v[c][j][2], ar.v[c][j][3]};
         }
     };
 
@@ -291,8 +304,8 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     load_a(ar[0], 0, 0);
 
     // operand read addresses: A row c16, B column 16 wave + c16, k residue g
-    const float* const a_rd = abuf + c16 * AS + g;
-    const float* const b_rd = qp + (16 * wave + c16) * QS + g;
+    const float* const a_rd = abuf + c16 * AS + shift(c16) + g;
+    const float* const b_rd = qp + (16 * wave + c16) * QS + shift(c16) + g;
     float bq[2][32];  // B operands of a chunk (double-buffered across chunks); the first chunk's now
 #pragma unroll
     for (int m = 0; m < 32; ++m) bq[0][m] = b_rd[4 * m];
@@ -367,10 +380,10 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The exchange rides on the chunk barriers, one phase's latencies behind the MFMAs of the next:
-                //   after chunk 0: the previous phase's publish stores have had ~0.6 us -> drain, barrier, signal;
-                //   after chunk 1: the peers' signals (same point of THEIR phase) have had a chunk to arrive ->
+                //   after chunk CX: the previous phase's publish stores have had ~0.5 us -> drain, barrier, signal;
+                //   after chunk CY: the peers' signals (same point of THEIR phase) have had time to arrive ->
                 //     poll, barrier, and the other set's next input starts travelling into registers, with the
-                //     remaining chunks and the epilogue (~1.3 us) to land before it is staged.
+                //     remaining chunk(s) and the epilogue (~1.2 us) to land before it is staged.
                 constexpr int CX = (KCH == 4) ? CCVM_CL_X : 0, CY = (KCH == 4) ? CCVM_CL_Y : 1;
                 static_assert(CX < CY && CY + 1 < KCH, "signal before poll; both on chunk barriers");
                 if constexpr (c == CX) {
