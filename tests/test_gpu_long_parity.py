@@ -22,13 +22,13 @@ ADAM_A = dict(alpha=0.001, beta1=0.9, beta2=0.999, add_assign=False)  # SURVEY.m
 
 # (label, solver kind, N, batch, iterations, post-processor, Adam hyper-parameters, gate on |dx|, gate on |dobj| rel)
 CASES = [
-    ("config2_dl_n100_b1000", "dl", 100, 1000, 1500, None, None, 5e-4, 2e-5),
-    ("config3_mf_n500_b1000", "mf", 500, 1000, 500, None, None, 5e-4, 2e-5),
-    ("config3_langevin_n500_b1000", "langevin", 500, 1000, 500, None, None, 5e-4, 2e-5),
-    ("config3_mf_n500_b1000_adam", "mf", 500, 1000, 300, None, ADAM_A, 5e-4, 2e-5),
-    ("config3_langevin_n500_b1000_adam", "langevin", 500, 1000, 300, None, ADAM_A, 5e-4, 2e-5),
-    ("config4_dl_n1000_b1000_headline", "dl", 1000, 1000, 1000, None, None, 5e-4, 2e-5),
-    ("config5_pl_n2000_b512_adam_pp", "pl", 2000, 512, 200, "adam", None, 5e-4, 2e-5),
+    ("config2_dl_n100_b1000", "dl", 100, 1000, 1500, None, None, 3e-4, 1e-5),
+    ("config3_mf_n500_b1000", "mf", 500, 1000, 500, None, None, 3e-4, 1e-5),
+    ("config3_langevin_n500_b1000", "langevin", 500, 1000, 500, None, None, 3e-4, 1e-5),
+    ("config3_mf_n500_b1000_adam", "mf", 500, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
+    ("config3_langevin_n500_b1000_adam", "langevin", 500, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
+    ("config4_dl_n1000_b1000_headline", "dl", 1000, 1000, 1000, None, None, 3e-4, 1e-5),
+    ("config5_pl_n2000_b512_adam_pp", "pl", 2000, 512, 200, "adam", None, 3e-4, 1e-5),
 ]
 
 
