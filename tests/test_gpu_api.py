@@ -222,6 +222,44 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_engine():
     assert c.shape == (b, n) and torch.equal(c.cpu(), traj.compact("c").cpu()) and torch.equal(s.cpu(), traj.compact("s").cpu())
 
 
+def test_integration_md_finalize_stub_runs_and_matches_the_engine():
+    """The second stub of INTEGRATION.md (the steps right after the loop through ccvm_finalize) executed as
+    written, on the pitched arrays of an engine run: objective values bit-identical to Trajectories.score, best
+    value and success fractions equal to Solution's."""
+    import re
+
+    from ccvm_amd import engine
+    from ccvm_amd.solution import fractions_from_counts, success_fractions
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    first = next(b for b in blocks if "def _solve(self" in b)
+    second = next(b for b in blocks if "def _score(" in b)
+    lib_path = os.path.join(ROOT, "ccvm_amd", "libccvm_hip.so")
+    ns = {}
+    exec(compile(first.replace('ctypes.CDLL("libccvm_hip.so")', f'ctypes.CDLL("{lib_path}")'), "INTEGRATION.md", "exec"), ns)
+    exec(compile(second, "INTEGRATION.md", "exec"), ns)
+
+    n, b, t, S = 20, 50, 40, 0.8
+    q, v, f = scaled_qv(n, "dl")
+    p = EXAMPLE_PARAMS["dl"]
+    run = lambda: engine.Trajectories(engine.DeviceProblem(q, v), b, "dl", t, dict(p, g=0.05), (0.0, 1.0),
+                                      engine.NoiseSpec(mode="fused", seed=77))
+    a, ref = run(), run()
+    a.advance(t)
+    ref.advance(t)
+    optimal = 100.0
+    obj, best, perf = ns["_score"](a.p.q, a.p.v, a.state["c"], b, n, S, (0.0, 1.0), float(f), optimal)
+    torch.cuda.synchronize()
+    want = ref.score("c", S, float(f), 0.0, 1.0, optimal_value=optimal, clamp=(-S, S))
+    assert torch.equal(obj.cpu(), want.objective_values.cpu())
+    assert torch.equal(a.state["c"], ref.state["c"])            # both clamped in place
+    wbest, within, rows, _ = engine.read_stats(want.stats)
+    assert best == wbest == float(torch.max(-obj).item())
+    assert perf == fractions_from_counts(within, rows) == success_fractions(obj.cpu(), optimal)
+
+
 def test_post_processors_reject_mismatched_shapes():
     """Reference unit tests test_postprocess_error_for_invalid_c_dimension / _invalid_v_vector_shape
     (tests/unit/postprocessor/test_adam.py, test_grad_descent.py): any exception; here a ValueError
