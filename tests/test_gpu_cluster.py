@@ -173,3 +173,21 @@ def test_cluster_long_trajectory_under_uneven_load(cluster):
     side.synchronize()
     assert torch.equal(quiet, loaded)
     assert bool(torch.isfinite(loaded).all())
+
+
+def test_status_word_is_checked_at_synchronisation_points(cluster):
+    """A kernel-side failure (the cluster path giving up a bounded wait) is reported through the run's status
+    word in the workspace (ccvm_status_offset); the engine raises at its next synchronisation point."""
+    from ccvm_amd import _lib, engine
+
+    traj = _run_engine("langevin", 300, 64, 5, None, 3, 0)
+    traj.check()                                     # a normal run leaves it at 0
+    assert traj._status is not None and int(traj._status.cpu().view(torch.int32).item()) == 0
+    traj._status.view(torch.int32)[0] = 1            # what a timed-out workgroup stores
+    with pytest.raises(_lib.EngineError, match="cluster kernel timed out"):
+        traj.compact("c")
+    with pytest.raises(_lib.EngineError):
+        traj.score("c", 0.5, 1.0)
+    dl = engine.Trajectories(traj.p, 8, "dl", 3, {"pump": 2.0, "dt": 0.001, "noise_ratio": 2.0, "feedback_scale": 1.0,
+                                                   "g": 0.05}, (0.0, 1.0), engine.NoiseSpec(mode="fused", seed=1))
+    assert dl._status is None                        # DL has no cluster path: no status word
