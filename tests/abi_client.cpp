@@ -5,6 +5,8 @@
 //   * every solver entry point runs (tile and persistent sizes), results are finite, padding stays 0;
 //   * chunked runs equal single runs bit for bit (step0 / nsteps contract);
 //   * two halves of a batch with row_offset equal the full batch bit for bit (sharding contract);
+//   * ccvm_finalize (clamp -> change of variables -> energy -> success statistics in one call) equals the
+//     separate calls bit for bit, its counters equal a host recount, the run's status word stays 0;
 //   * errors come back as codes + ccvm_last_error(), never as exceptions.
 #include <hip/hip_runtime.h>
 
@@ -131,9 +133,41 @@ static int run_case(int N, int B) {
         ccvm_langevin_params lv = {0.002, 0.5, 1.0, 0.5, 2.0, 0.0, 1.0, pumped, 1};
         Dev wl(ccvm_workspace_bytes(2, B, N) / 4 + 1), x(state), obj(B), we(ccvm_workspace_bytes(3, B, N) / 4 + 1);
         REQUIRE(ccvm_langevin_run(Q.p, V.p, x.p, B, N, ld, 0, T, T, &lv, nullptr, &nz, wl.p, wl.n * 4, nullptr) == CCVM_OK);
+        // the steps right after the loop in ONE call (on a copy), against the separate calls below
+        Dev xcopy(state), xf(state), objf(B), stats(16);
+        hipMemcpy(xcopy.p, x.p, state * 4, hipMemcpyDeviceToDevice);
+        ccvm_finalize_params fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.S = 0.5; fp.lower = 0.0; fp.upper = 1.0; fp.clamp = 1; fp.clamp_lo = -0.5; fp.clamp_hi = 0.5;
+        fp.change_variables = 1; fp.scaled_by = 1.0; fp.optimal_value = 0.05;
+        REQUIRE(ccvm_finalize(Q.p, V.p, xcopy.p, xf.p, B, N, ld, &fp, objf.p,
+                              reinterpret_cast<ccvm_solution_stats*>(stats.p), we.p, we.n * 4, nullptr) == CCVM_OK);
         REQUIRE(ccvm_change_variables(x.p, x.p, B, N, ld, 0.5, 0.0, 1.0, nullptr) == CCVM_OK);
         REQUIRE(ccvm_energy(Q.p, V.p, x.p, B, N, ld, 1.0, obj.p, we.p, we.n * 4, nullptr) == CCVM_OK);
         const std::vector<float> hx = x.host(), ho = obj.host();
+        REQUIRE(ho == objf.host() && hx == xf.host());
+        {
+            ccvm_solution_stats st;
+            hipMemcpy(&st, stats.p, sizeof(st), hipMemcpyDeviceToHost);
+            const float thr[7] = {0.1f, 1.f, 2.f, 3.f, 4.f, 5.f, 10.f};
+            int want[7] = {0, 0, 0, 0, 0, 0, 0};
+            float best = -INFINITY;
+            for (int b = 0; b < B; ++b) {
+                const float found = -ho[b], gap = ((float)fp.optimal_value - found) * 100.0f / std::fabs(found);
+                best = std::fmax(best, found);
+                for (int k = 0; k < 7; ++k) want[k] += gap <= thr[k];
+            }
+            REQUIRE(st.rows == B && st.nonfinite == 0 && st.best_objective_value == best);
+            for (int k = 0; k < 7; ++k) REQUIRE(st.within[k] == want[k]);
+            // the run's status word (MF / Langevin workspaces): zeroed by the caller, still 0 after the run
+            const size_t off = ccvm_status_offset(2, B, N);
+            REQUIRE(off != (size_t)-1 && off + 4 <= wl.n * 4 && ccvm_status_offset(0, B, N) == (size_t)-1);
+            unsigned status = 7;
+            hipMemcpy(&status, reinterpret_cast<char*>(wl.p) + off, 4, hipMemcpyDeviceToHost);
+            REQUIRE(status == 0);
+            char what[256];
+            REQUIRE(ccvm_describe_launch(2, B, N, 0, 0, what, sizeof(what)) == CCVM_OK && strstr(what, "_kernel<2, false") != nullptr);
+        }
         REQUIRE(all_finite(hx) && all_finite(ho));
         for (int b = 0; b < B; ++b)
             for (int j = 0; j < N; ++j) REQUIRE(hx[(size_t)b * ld + j] >= 0.0f && hx[(size_t)b * ld + j] <= 1.0f);
@@ -153,7 +187,8 @@ int main() {
     if (ccvm_abi_version() != CCVM_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
     if (run_case(37, 50)) return 1;    // persistent kernel (one wave per row set)
     if (run_case(100, 70)) return 1;   // persistent kernel (two waves side by side)
-    if (run_case(300, 96)) return 1;   // per-step tile kernel
+    if (run_case(300, 96)) return 1;   // per-step tile kernel (DL), column-cluster persistent kernel (MF, Langevin)
+    if (run_case(600, 64)) return 1;   // per-step tile kernel for every solver
     printf("ABI_CLIENT_OK\n");
     return 0;
 }
