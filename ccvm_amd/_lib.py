@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -74,6 +74,7 @@ class DlParams(Structure):
         ("upper", c_double),
         ("pump_rate_flag", c_int32),
         ("reserved", c_int32),
+        ("qsum", c_void_p),
     ]
 
 
@@ -90,6 +91,7 @@ class MfParams(Structure):
         ("pump_rate_flag", c_int32),
         ("reserved", c_int32),
         ("s_cols", c_void_p),
+        ("qsum", c_void_p),
     ]
 
 
@@ -105,6 +107,7 @@ class LangevinParams(Structure):
         ("use_pump", c_int32),
         ("pump_rate_flag", c_int32),
         ("s_cols", c_void_p),
+        ("qsum", c_void_p),
     ]
 
 
@@ -147,6 +150,7 @@ SIGNATURES = {
     "ccvm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_workspace_bytes_cols": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_status_offset": (c_size_t, [c_int, c_int, c_int]),
+    "ccvm_column_sums": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
     "ccvm_describe_launch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_size_t]),
     "ccvm_dl_run": (
         c_int,

@@ -169,7 +169,13 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
 // Column sums of Q into `area` ((QSUM_SLICES + 1) * ld floats); returns the qsum pointer.
 size_t qsum_area_bytes(int N) { return (size_t)(QSUM_SLICES + 1) * ccvm_ld(N) * sizeof(float); }
 
-int compute_qsum(const float* Q, int N, int ld, float* area, hipStream_t st, const float** out) {
+// `given`: column sums the caller computed once for this Q (ccvm_column_sums): nothing to launch then.
+int compute_qsum(const float* Q, int N, int ld, float* area, hipStream_t st, const float** out,
+                 const float* given = nullptr) {
+    if (given) {
+        *out = given;
+        return CCVM_OK;
+    }
     float* part = area + ld;
     hipLaunchKernelGGL(qsum_partial_kernel, dim3((ld + 127) / 128, QSUM_SLICES), dim3(128), 0, st, Q, N, ld, part);
     hipLaunchKernelGGL(qsum_final_kernel, dim3((ld + 127) / 128), dim3(128), 0, st, part, ld, area);
@@ -324,6 +330,19 @@ size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
     return (solver == 1 || solver == 2) ? base + ld * ld * sizeof(float) : base;
 }
 
+int ccvm_column_sums(const float* Q, int N, int ld, float* qsum, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "ccvm_column_sums";
+    int rc;
+    if (!Q || !qsum || !ws) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
+    if ((rc = check_layout(fn, 1, N, ld))) return rc;
+    if (ws_bytes < ccvm_workspace_bytes(5, 1, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    const float* out;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws), (hipStream_t)stream, &out))) return rc;
+    if (hipMemcpyAsync(qsum, out, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return fail(CCVM_E_HIP, "%s: copy failed", fn);
+    return CCVM_OK;
+}
+
 int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0 || solver < 0 || solver > 2 || B <= 0 || N <= 0)
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
@@ -410,7 +429,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
-    if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
+    if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
     if (nsteps > 0 && want_persist(N, tun)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N));
@@ -501,7 +520,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (want_persist(N, tun)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         const float* qsum;
-        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum))) return rc;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum, p->qsum))) return rc;
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
@@ -531,7 +550,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (want_cluster(B, N, tun)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         const float* qsum;
-        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum))) return rc;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum, p->qsum))) return rc;
         char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
@@ -580,7 +599,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / S_eff);
     a.in_shift = (float)up;
-    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum))) return rc;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum, p->qsum))) return rc;
     if (s_cols) {
         a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st);
         a.s_cols = s_cols;
@@ -661,7 +680,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     base_args(a, Q, V, B, N, ld, tun);
     a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
-    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum))) return rc;
+    if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
     if (s_cols) {
         a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(2, B, N), st);
         a.s_cols = s_cols;

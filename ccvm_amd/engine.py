@@ -248,6 +248,13 @@ class DeviceProblem:
         with torch.cuda.device(self.device):
             self.q = pack(q_matrix.detach().to(self.device), self.ld, self.ld)
             self.v = pack(v_vector.detach().to(self.device), 1, self.ld).reshape(-1)
+            # column sums of Q once per staged problem: every run call would otherwise recompute them
+            lib = _lib.load()
+            self.qsum = torch.empty((self.ld,), dtype=torch.float32, device=self.device)
+            ws = torch.empty((max(lib.ccvm_workspace_bytes(_lib.WS_FEEDBACK, 1, self.n), 16),), dtype=torch.uint8,
+                             device=self.device)
+            _lib.check(lib.ccvm_column_sums(_ptr(self.q), self.n, self.ld, _ptr(self.qsum), _ptr(ws), ws.numel(),
+                                            _stream_ptr()), "ccvm_column_sums")
 
 
 _problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device index, DeviceProblem, ready event)
@@ -273,6 +280,7 @@ def device_problem(q_matrix, v_vector):
             cur.wait_event(ready)  # staged on another stream, perhaps
             prob.q.record_stream(cur)
             prob.v.record_stream(cur)
+            prob.qsum.record_stream(cur)
             return prob
     prob = DeviceProblem(q_matrix, v_vector)
     ready = torch.cuda.Event()
@@ -345,6 +353,7 @@ class Trajectories:
                 cp.pump = float(params.get("pump", 0.0))
                 cp.pump_rate_flag = 1 if params.get("pump_rate_flag", True) else 0
             cp.lower, cp.upper = lo, hi
+            cp.qsum = problem.qsum.data_ptr()
             self.cparams = cp
             self.adam_m = self.adam_v = None
             if adam is not None:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 3
+#define CCVM_ABI_VERSION 4
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -90,6 +90,8 @@ typedef struct ccvm_dl_params {
     double lower, upper;     /* solution_bounds */
     int32_t pump_rate_flag;  /* rate = (i+1)/T when set, else 1 */
     int32_t reserved;
+    const float* qsum;       /* column sums of Q from ccvm_column_sums (ld floats, device), or NULL: computed by
+                                every run call (two small kernels, ~15 us: worth passing for short chunks) */
 } ccvm_dl_params;
 
 /* MF-CCVM: reference mf_solver.py:493-593 (_solve), :595-764 (_solve_adam),
@@ -104,6 +106,7 @@ typedef struct ccvm_mf_params {
      * scalar S above (which is ignored otherwise).  Needs the larger workspace of
      * ccvm_workspace_bytes_cols. */
     const float* s_cols;
+    const float* qsum;       /* as in ccvm_dl_params (always the sums of the ORIGINAL Q, also with s_cols) */
 } ccvm_mf_params;
 
 /* Langevin (use_pump = 0): reference langevin_solver.py:368-435, :437-561, :117-166.
@@ -117,6 +120,7 @@ typedef struct ccvm_langevin_params {
     int32_t pump_rate_flag;  /* p_i = pump*(i+1)/T when set, else pump */
     const float* s_cols;     /* per-variable saturation, as in ccvm_mf_params (langevin_solver.py:630-635,
                                 pumped_langevin_solver.py:519-524); NULL = scalar S */
+    const float* qsum;       /* as in ccvm_dl_params */
 } ccvm_langevin_params;
 
 /* ---- library / layout ------------------------------------------------------- */
@@ -145,6 +149,12 @@ size_t ccvm_workspace_bytes(int solver, int B, int N);
 size_t ccvm_status_offset(int solver, int B, int N);
 /* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
+
+/* Column sums of Q (the constant term of the folded affine input map: (x a + b) @ Q = a (x @ Q) + b colsum(Q)),
+ * deterministic two-pass reduction; qsum: ld floats.  Optional: pass the result in the run parameters' `qsum`
+ * field to save the per-call recomputation.  workspace: ccvm_workspace_bytes(5, 1, N). */
+int ccvm_column_sums(const float* Q, int N, int ld, float* qsum,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Which kernel instantiation and grid ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2)
  * launch for this shape under the current tuning environment, as text (the name is what rocprofv3

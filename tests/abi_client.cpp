@@ -79,8 +79,13 @@ static int run_case(int N, int B) {
     Dev ws(ccvm_workspace_bytes(0, B, N) / 4 + 1);
     Dev c1(state), s1(state), c2(state), s2(state);
     REQUIRE(ccvm_dl_run(Q.p, V.p, c1.p, s1.p, B, N, ld, 0, T, T, &dl, &nz, ws.p, ws.n * 4, nullptr) == CCVM_OK);
-    REQUIRE(ccvm_dl_run(Q.p, V.p, c2.p, s2.p, B, N, ld, 0, 5, T, &dl, &nz, ws.p, ws.n * 4, nullptr) == CCVM_OK);
-    REQUIRE(ccvm_dl_run(Q.p, V.p, c2.p, s2.p, B, N, ld, 5, T - 5, T, &dl, &nz, ws.p, ws.n * 4, nullptr) == CCVM_OK);
+    // the chunked run passes column sums computed once (ccvm_column_sums) instead of letting every call recompute them
+    Dev qsum(ld), wq(ccvm_workspace_bytes(5, 1, N) / 4 + 1);
+    REQUIRE(ccvm_column_sums(Q.p, N, ld, qsum.p, wq.p, wq.n * 4, nullptr) == CCVM_OK);
+    ccvm_dl_params dlq = dl;
+    dlq.qsum = qsum.p;
+    REQUIRE(ccvm_dl_run(Q.p, V.p, c2.p, s2.p, B, N, ld, 0, 5, T, &dlq, &nz, ws.p, ws.n * 4, nullptr) == CCVM_OK);
+    REQUIRE(ccvm_dl_run(Q.p, V.p, c2.p, s2.p, B, N, ld, 5, T - 5, T, &dlq, &nz, ws.p, ws.n * 4, nullptr) == CCVM_OK);
     REQUIRE(hipDeviceSynchronize() == hipSuccess);
     const std::vector<float> hc1 = c1.host(), hs1 = s1.host();
     REQUIRE(all_finite(hc1) && all_finite(hs1));
