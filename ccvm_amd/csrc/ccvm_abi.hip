@@ -501,12 +501,14 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     const float* s_cols = p->s_cols;
     if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(1, B, N) : ccvm_workspace_bytes(1, B, N)))
         return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
-    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || p->S > 0) || !(p->j > 0))
+    const float* s_full = p->s_full;
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0) || !(p->j > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0, j > 0", fn);
+    if (s_cols && s_full) return fail(CCVM_E_INVALID, "%s: s_cols and s_full are exclusive", fn);
     if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
     // per-variable saturation: every 1 / S factor of the scalars is left out (S_eff = 1) and applied per
     // column -- 1 / S_k of the input map through the row-scaled copy Qs, 1 / S_j in the epilogue
-    const double S_eff = s_cols ? 1.0 : p->S;
+    const double S_eff = (s_cols || s_full) ? 1.0 : p->S;
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
@@ -516,6 +518,67 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     const double sdt = std::sqrt(p->dt);
     auto j_at = [&](int i) { return p->j * std::exp(-(double)(i + 1) / (double)T * 3.0); };  // :550
     const bool replay = nz->mode == CCVM_NOISE_REPLAY;
+
+    if (s_full) {
+        // one saturation per trajectory AND variable: composed path (ccvm_kernels.h, fulls_* kernels):
+        // workspace = [xs = mt / S][y = AFFINE result][mt]
+        float* xs = static_cast<float*>(ws);
+        float* y = xs + state;
+        float* mtb = xs + 2 * state;
+        if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        StepArgs a;
+        base_args(a, Q, V, B, N, ld, tun);
+        a.in_scale = (float)ul;
+        a.in_shift = (float)up;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum, p->qsum))) return rc;
+        a.a0 = xs;
+        a.o0 = y;
+        a.s.pp.step = (float)(-p->feedback_scale * 0.25 * ul);  // f_q for S = 1; 1 / S_bj in the update kernel
+        a.s.pp.eps = (float)(-p->feedback_scale * ul / 2.0);    // f_v
+        FullSArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.x0 = mu; fa.x1 = sigma; fa.mt = mtb; fa.xs = xs; fa.y = y; fa.s_full = s_full;
+        fa.seed = nz->seed; fa.row_offset = nz->row_offset; fa.B = B; fa.N = N; fa.ld = ld;
+        fa.adam = use_adam;
+        if (use_adam) { fa.am = adam->m; fa.av = adam->v; }
+        const size_t blk = (size_t)N * B;
+        fa.step = step0;
+        fa.w0 = replay ? nz->w0 : nullptr;
+        hipLaunchKernelGGL(fulls_mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, fa,
+                           (float)(std::sqrt(1.0 / (4.0 * j_at(step0))) / sdt));
+        CCVM_CHECK_LAUNCH(fn);
+        for (int i = step0; i < step0 + nsteps; ++i) {
+            const bool has_next = (i + 1 < step0 + nsteps);
+            if ((rc = launch_step<MODE_AFFINE, false>(a, st, fn))) return rc;
+            const double j_i = j_at(i);
+            const double rate = p->pump_rate_flag ? (double)(i + 1) / (double)T : 1.0;
+            const double p_i = p->pump * rate + 1.0 + j_i;
+            MfScalars k;
+            k.a0 = (float)(-(1.0 + j_i) + p_i);
+            k.g2 = (float)(p->g * p->g);
+            k.f_q = a.s.pp.step;
+            k.f_v = a.s.pp.eps;
+            k.j_i = (float)j_i;
+            k.one_j = (float)(1.0 + j_i);
+            k.sqrt_j = (float)std::sqrt(j_i);
+            k.inv_sdt = (float)(1.0 / sdt);
+            k.dt = (float)p->dt;
+            k.k_next = has_next ? (float)(std::sqrt(1.0 / (4.0 * j_at(i + 1))) / sdt) : 0.0f;
+            k.S = 1.0f;
+            k.has_next = has_next;
+            if (use_adam) fill_adam(fa.ad, adam, i);
+            fa.step = i;
+            fa.w0 = replay ? nz->w0 + (size_t)(i - step0) * blk : nullptr;
+            fa.w0n = (replay && has_next) ? nz->w0 + (size_t)(i + 1 - step0) * blk : nullptr;
+            hipLaunchKernelGGL(fulls_mf_update_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, fa, k);
+            CCVM_CHECK_LAUNCH(fn);
+        }
+        if (mu_tilde_out &&
+            hipMemcpyAsync(mu_tilde_out, mtb, state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy of mu_tilde failed", fn);
+        return CCVM_OK;
+    }
 
     if (want_persist(N, tun)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
@@ -661,10 +724,12 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     const float* s_cols = p->s_cols;
     if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(2, B, N) : ccvm_workspace_bytes(2, B, N)))
         return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
-    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || p->S > 0))
+    const float* s_full = p->s_full;
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0", fn);
+    if (s_cols && s_full) return fail(CCVM_E_INVALID, "%s: s_cols and s_full are exclusive", fn);
     if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
-    const double S_eff = s_cols ? 1.0 : p->S;  // see ccvm_mf_run
+    const double S_eff = (s_cols || s_full) ? 1.0 : p->S;  // see ccvm_mf_run
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
@@ -687,6 +752,46 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     }
     char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
     float* table = reinterpret_cast<float*>(after);
+    if (s_full) {
+        // one saturation per trajectory AND variable: composed path (see ccvm_mf_run): workspace = [xs = c / S][y]
+        float* xs = static_cast<float*>(ws);
+        float* y = xs + state;
+        hipLaunchKernelGGL(fulls_scale_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, c, s_full, xs, B, N, ld);
+        CCVM_CHECK_LAUNCH(fn);
+        a.a0 = xs;
+        a.o0 = y;
+        a.s.pp.step = (float)(-ul / 2.0);  // g_q for S = 1; 1 / S_bj in the update kernel
+        a.s.pp.eps = (float)(-ul / 2.0);   // g_v
+        const float f_q = a.s.pp.step, f_v = a.s.pp.eps;
+        FullSArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.x0 = c; fa.xs = xs; fa.y = y; fa.s_full = s_full;
+        fa.seed = nz->seed; fa.row_offset = nz->row_offset; fa.B = B; fa.N = N; fa.ld = ld;
+        fa.adam = use_adam;
+        if (use_adam) { fa.am = adam->m; fa.av = adam->v; }
+        const bool replay = nz->mode == CCVM_NOISE_REPLAY;
+        for (int i = step0; i < step0 + nsteps; ++i) {
+            a.s.pp.step = f_q;  // (the scalar union is shared with the solver scalars below)
+            a.s.pp.eps = f_v;
+            if ((rc = launch_step<MODE_AFFINE, false>(a, st, fn))) return rc;
+            LvScalars k;
+            k.g_q = f_q;
+            k.g_v = f_v;
+            const double p_i = p->pump_rate_flag ? p->pump * (double)(i + 1) / (double)T : p->pump;
+            k.pm = (float)(-1.0 + p_i);
+            k.dt = (float)p->dt;
+            k.dt_fs = (float)(p->dt * p->feedback_scale);
+            k.w = (float)(p->sigma * std::sqrt(p->dt));
+            k.S = 1.0f;
+            k.use_pump = p->use_pump;
+            if (use_adam) fill_adam(fa.ad, adam, i);
+            fa.step = i;
+            fa.w0 = replay ? nz->w0 + (size_t)(i - step0) * N * B : nullptr;
+            hipLaunchKernelGGL(fulls_langevin_update_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, fa, k);
+            CCVM_CHECK_LAUNCH(fn);
+        }
+        return CCVM_OK;
+    }
     if (want_persist(N, tun)) {
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));

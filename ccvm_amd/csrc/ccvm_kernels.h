@@ -847,6 +847,103 @@ __global__ void change_variables_full_kernel(const float* x, float* y, int B, in
     }
 }
 
+// ---- one saturation per trajectory AND variable inside the loop (MF / Langevin / pumped Langevin) -------------
+// The reference passes a 2-D tensor S straight through (mf_solver.py:834-839 and the same lines of the other
+// solvers), so 1 / S_bk sits inside the GEMM's input map per ELEMENT and cannot be folded into Q (per-variable
+// S: the row-scaled copy Qs) or into a scalar.  Rare input, composed path ("support on a
+// slower path or reject loudly"): per step the MODE_AFFINE launch of step_kernel contracts the pre-scaled input
+// xs = x / S, and one elementwise kernel does noise, Adam, update, clamp and the next xs.  Same pinned update
+// helpers and noise definition as the fused kernels.
+__global__ void fulls_scale_kernel(const float* __restrict__ x, const float* __restrict__ s_full, float* xs, int B,
+                                   int N, int ld) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        const size_t idx = (size_t)r * ld + c;
+        xs[idx] = x[idx] / s_full[idx];
+    }
+}
+
+struct FullSArgs {
+    float* x0;            // Langevin: c; MF: mu (in place)
+    float* x1;            // MF: sigma (in place)
+    float* mt;            // MF: clamped measured amplitude fed to the next step (in/out)
+    float* xs;            // GEMM input of the next step: x / S (Langevin) or mt / S (MF)
+    const float* y;       // f_q * (A(xs) @ Q) + f_v * V of this step (MODE_AFFINE), scalars built for S = 1
+    const float* s_full;  // pitched saturation
+    float* am;
+    float* av;
+    const float* w0;      // REPLAY: this step's [N][B] block
+    const float* w0n;     // REPLAY (MF): next step's block
+    uint64_t seed;
+    int64_t row_offset;
+    int step, B, N, ld;
+    AdamScalars ad;
+    int adam;
+};
+
+__device__ __forceinline__ float fulls_adam(const FullSArgs& a, float g, size_t idx) {
+    if (!a.adam) return g;
+    float m, v;
+    const float out = adam_precondition(a.ad, g, a.am[idx], a.ad.use_v ? a.av[idx] : 0.0f, m, v);
+    a.am[idx] = m;
+    if (a.ad.use_v) a.av[idx] = v;
+    return out;
+}
+
+__global__ void fulls_langevin_update_kernel(const FullSArgs a, const LvScalars k) {
+    const size_t total = (size_t)a.B * a.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.N), j = (int)(i - (size_t)b * a.N);
+        const size_t idx = (size_t)b * a.ld + j;
+        const float S = a.s_full[idx];
+        const float n0 = a.w0 ? a.w0[(size_t)j * a.B + b] : normal_single(a.seed, a.row_offset + b, a.step, j);
+        const float g = fulls_adam(a, a.y[idx] / S, idx);
+        const float x = lv_update(k, a.x0[idx], g, n0, S);
+        a.x0[idx] = x;
+        a.xs[idx] = x / S;
+    }
+}
+
+// MF first step of a chunk: mt = clamp(mu + k0 W_step0, -S, S) (mf_solver.py:551-554), xs = mt / S.
+__global__ void fulls_mf_prepare_kernel(const FullSArgs a, float k0) {
+    const size_t total = (size_t)a.B * a.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.N), j = (int)(i - (size_t)b * a.N);
+        const size_t idx = (size_t)b * a.ld + j;
+        const float S = a.s_full[idx];
+        const float n0 = a.w0 ? a.w0[(size_t)j * a.B + b] : normal_single(a.seed, a.row_offset + b, a.step, j);
+        const float mt = clampf(__builtin_fmaf(k0, n0, a.x0[idx]), -S, S);
+        a.mt[idx] = mt;
+        a.xs[idx] = mt / S;
+    }
+}
+
+__global__ void fulls_mf_update_kernel(const FullSArgs a, const MfScalars k) {
+    const size_t total = (size_t)a.B * a.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.N), j = (int)(i - (size_t)b * a.N);
+        const size_t idx = (size_t)b * a.ld + j;
+        const float S = a.s_full[idx];
+        const float n0 = a.w0 ? a.w0[(size_t)j * a.B + b] : normal_single(a.seed, a.row_offset + b, a.step, j);
+        const float fb = fulls_adam(a, a.y[idx] / S, idx);
+        float mun, sgn;
+        mf_update(k, a.x0[idx], a.x1[idx], fb, n0, mun, sgn);
+        a.x0[idx] = mun;
+        a.x1[idx] = sgn;
+        if (k.has_next) {  // the last step's input is what mu_tilde_out returns: no new measurement after it
+            const float n1 = a.w0n ? a.w0n[(size_t)j * a.B + b] : normal_single(a.seed, a.row_offset + b, a.step + 1, j);
+            const float mt = clampf(__builtin_fmaf(k.k_next, n1, mun), -S, S);
+            a.mt[idx] = mt;
+            a.xs[idx] = mt / S;
+        }
+    }
+}
+
 // y = 0.5 * x / S * (u - l) + 0.5 * (u + l), in the reference's operation order.
 __global__ void change_variables_kernel(const float* x, float* y, int B, int N, int ld,
                                         float S, float ul, float half_up) {

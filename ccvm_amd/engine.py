@@ -370,8 +370,13 @@ class Trajectories:
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
 
     def _set_saturation(self, cp, S):
-        """Scalar S, or a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs)."""
-        if is_per_variable(S):
+        """Scalar S; a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs); a 2-D
+        tensor: one saturation per trajectory and variable (``s_full``, composed path)."""
+        self.s_full = None
+        if is_per_element(S):
+            self.s_full = saturation_full(S, self.b, self.n, self.device)
+            cp.S, cp.s_cols, cp.s_full = 1.0, None, self.s_full.data_ptr()
+        elif is_per_variable(S):
             self.s_cols = saturation_columns(S, self.n, self.device)
             cp.S, cp.s_cols = 1.0, self.s_cols.data_ptr()
         else:
@@ -497,7 +502,11 @@ def _full_pitched(t, b, n, dev):
 
 def saturation_full(S, b, n, dev):
     """The pitched device array the ``*_full`` entry points and ``s_full`` take (positive entries)."""
-    if tuple(torch.broadcast_shapes(tuple(S.shape), (b, n))) != (b, n):
+    try:
+        fits = tuple(torch.broadcast_shapes(tuple(S.shape), (b, n))) == (b, n)
+    except RuntimeError:
+        fits = False
+    if not fits:
         raise ValueError(f"a 2-D saturation must broadcast to (batch, N) = ({b}, {n}); got {tuple(S.shape)}")
     if not bool((S > 0).all()):
         raise ValueError("every entry of the saturation S must be positive")
@@ -583,7 +592,7 @@ def saturated_feedback(x, q_matrix, v_vector, S, in_scale, in_shift, f_q, f_v):
         (f_q * ((x / S * in_scale + in_shift) @ Q) + f_v * V) / S
     with the scalars given for S = 1.  S: float, or a per-variable 1-D tensor (then x / S and the final
     1 / S are applied per column around the device kernel)."""
-    if is_per_variable(S):
+    if is_per_variable(S) or is_per_element(S):
         s = S.detach().to(device=x.device, dtype=torch.float32)
         return feedback(x / s, q_matrix, v_vector, in_scale, in_shift, f_q, f_v) / s
     S = float(S)

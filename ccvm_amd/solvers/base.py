@@ -200,17 +200,13 @@ class CCVMSolver(ABC):
                 f"The parameter '{exc.args[0]}' for the given instance size is not defined."
             ) from exc
 
-    #: whether a (batch, N) saturation tensor is supported: the DL solver only uses S after the loop
-    #: (final clamp + change of variables: elementwise kernels); in the other solvers S sits inside
-    #: the loop's GEMM input map
-    _FULL_SATURATION = False
-
     def _broadcast_saturation(self, S, problem_size):
         """The reference repeats a 1-D tensor S of length N over the batch (dl_solver.py:843-848 and the
         same lines of the other solvers).  The engine keeps it as the per-variable vector it is: the
         kernels apply S_j per column (``s_cols`` of the C ABI).  Any other tensor is passed straight through
-        by the reference, i.e. a 2-D S is one saturation per trajectory AND variable: supported where the
-        saturation only acts after the loop (DL: ``s_full``), rejected loudly elsewhere."""
+        by the reference, i.e. a 2-D S is one saturation per trajectory AND variable (``s_full``): elementwise
+        kernels after the loop for DL, a composed per-step path (GEMM launch + elementwise launch) for MF /
+        Langevin / pumped Langevin, where 1 / S sits inside the loop's GEMM input map per element."""
         if torch.is_tensor(S):
             if S.ndim == 1 and S.size(dim=0) != problem_size and S.numel() != 1:
                 raise ValueError("Tensor S size should be equal to problem size.")
@@ -218,11 +214,11 @@ class CCVMSolver(ABC):
                 return float(S.item())
             if S.ndim == 1:
                 return S.detach().to(device="cpu", dtype=torch.float32)
-            if S.ndim == 2 and self._FULL_SATURATION:
+            if S.ndim == 2:
                 return S.detach().to(dtype=torch.float32)
             raise NotImplementedError(
-                "a (batch, N) saturation tensor is not supported by this solver on the HIP engine; pass a "
-                "float or a 1-D tensor of length N"
+                f"a saturation tensor with {S.ndim} dimensions is not supported; pass a float, a 1-D tensor of "
+                "length N or a 2-D tensor that broadcasts to (batch, N)"
             )
         return S
 

@@ -27,7 +27,6 @@ DL_SCALING_MULTIPLIER = 0.2
 class DLSolver(CCVMSolver):
     _PARAMETER_KEYS = frozenset(["pump", "dt", "iterations", "noise_ratio", "feedback_scale"])
     _SAMPLED = ("c", "s")
-    _FULL_SATURATION = True  # S only enters the final clamp and the change of variables (dl_solver.py:567, :956)
 
     def __init__(self, device, problem_category="boxqp", batch_size=1000, S=1):
         super().__init__(device)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 4
+#define CCVM_ABI_VERSION 5
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -107,6 +107,11 @@ typedef struct ccvm_mf_params {
      * ccvm_workspace_bytes_cols. */
     const float* s_cols;
     const float* qsum;       /* as in ccvm_dl_params (always the sums of the ORIGINAL Q, also with s_cols) */
+    /* One saturation per trajectory AND variable (the reference passes a 2-D tensor S straight through,
+     * mf_solver.py:834-839): pitched [rows][ld] device array, S > 0 on the logical B x N region; exclusive with
+     * s_cols.  1 / S_bk then sits inside the GEMM's input map per element: this rare input runs on a composed
+     * path (one GEMM launch + one elementwise launch per step) instead of the fused kernels. */
+    const float* s_full;
 } ccvm_mf_params;
 
 /* Langevin (use_pump = 0): reference langevin_solver.py:368-435, :437-561, :117-166.
@@ -121,6 +126,7 @@ typedef struct ccvm_langevin_params {
     const float* s_cols;     /* per-variable saturation, as in ccvm_mf_params (langevin_solver.py:630-635,
                                 pumped_langevin_solver.py:519-524); NULL = scalar S */
     const float* qsum;       /* as in ccvm_dl_params */
+    const float* s_full;     /* as in ccvm_mf_params (langevin_solver.py:630-635, pumped_langevin_solver.py:519-524) */
 } ccvm_langevin_params;
 
 /* ---- library / layout ------------------------------------------------------- */

@@ -64,7 +64,7 @@ def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, s
     """``s_vector``: per-variable saturation (1-D tensor of length N) -- DL takes it in the constructor,
     the other solvers in the parameter key, scaled to the magnitude of their scalar default."""
     if kind == "dl" and s_vector is not None:
-        dl_S = s_vector
+        dl_S = s_vector  # (also a 2-D tensor: full_s_cases)
     solver = SOLVERS[kind](device="cpu", batch_size=batch, **({"S": dl_S} if dl_S is not None else {}))
     inst = ProblemInstance(instance_type="test", file_path=os.path.join(REFERENCE, path), device="cpu",
                            solution_bounds=bounds)
@@ -188,6 +188,20 @@ def full_s_cases():
                 store[f"{name}/{k}"] = v
             manifest["cases"][name] = meta
             print("fullS", name, meta["best_objective_value"])
+    # MF / Langevin / pumped Langevin: the 2-D S of the parameter key acts INSIDE the loop (clamp bound and the
+    # 1 / S of the feedback term per element): mf_solver.py:834-839, langevin_solver.py:630-635,
+    # pumped_langevin_solver.py:519-524 pass it through
+    for kind in ("mf", "langevin", "pl"):
+        for label in ("BN", "B1"):
+            s_full = 0.5 + 1.5 * torch.rand(shapes[label], generator=g)  # x the solver's scalar default
+            for adam, post in ((None, None), ("adamA", None), ("adamC", "grad-descent")):
+                name = f"{kind}_T30_fullS_{label}" + (f"_{adam}" if adam else "") + (f"_{post}" if post else "")
+                arrays, meta = run_case(kind, INSTANCES["test020"], 30, adam=adam, post=post, batch=batch,
+                                        s_vector=s_full)
+                for k, v in arrays.items():
+                    store[f"{name}/{k}"] = v
+                manifest["cases"][name] = meta
+                print("fullS", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_fullS.npz"), **store)
     with open(os.path.join(OUT, "test020_fullS.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)

@@ -169,10 +169,12 @@ def _full_s_case_names():
 
 
 @pytest.mark.parametrize("case", _full_s_case_names())
-def test_dl_solver_matches_reference_with_per_element_saturation(case, kernel_path):
-    """DLSolver(S=<2-D tensor>) -- one saturation per trajectory AND variable, shapes (B, N), (B, 1), (1, N):
-    the reference passes it straight through (dl_solver.py:843-848) to the final clamp and the change of
-    variables; here the `s_full` form of ccvm_finalize / ccvm_clamp_full / ccvm_change_variables_full."""
+def test_solver_matches_reference_with_per_element_saturation(case, kernel_path):
+    """A 2-D tensor S -- one saturation per trajectory AND variable, shapes (B, N), (B, 1), (1, N): the reference
+    passes it straight through (dl_solver.py:843-848, mf_solver.py:834-839, langevin_solver.py:630-635,
+    pumped_langevin_solver.py:519-524).  DL: final clamp and change of variables only (the `s_full` form of
+    ccvm_finalize / ccvm_clamp_full / ccvm_change_variables_full); MF / Langevin / pumped Langevin (+ Adam
+    variants): inside the loop, on the composed per-step path of ccvm_mf_run / ccvm_langevin_run."""
     from golden_util import full_s_arrays, full_s_cases
 
     g, meta, arrays = golden("test020"), full_s_cases()[case], full_s_arrays()
@@ -607,8 +609,14 @@ def test_unsupported_requests_fail_loudly():
     with pytest.raises(TypeError):  # same exception type as the reference's broken call
         dl(instance=inst, algorithm_parameters=AdamParameters())
     mf = MFSolver(device="cpu", batch_size=8)
-    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(8, 20))}  # one bound per row AND variable
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(2, 3, 20))}  # 3-D: no meaning
     with pytest.raises(NotImplementedError):
+        mf(instance=inst)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(5, 20))}  # 2-D but not (batch, N)
+    with pytest.raises(ValueError, match="broadcast"):
+        mf(instance=inst)
+    mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=-torch.ones(8, 20))}  # 2-D, not positive
+    with pytest.raises(ValueError, match="positive"):
         mf(instance=inst)
     mf.parameter_key = {20: dict(g.cases["mf_T1"]["params"], S=torch.ones(19))}     # wrong length
     with pytest.raises(ValueError, match="Tensor S size should be equal to problem size"):

@@ -105,9 +105,10 @@ def test_oracle_reproduces_reference_with_per_variable_saturation(case):
 
 @pytest.mark.parametrize("case", sorted(full_s_cases()))
 def test_oracle_reproduces_reference_with_per_element_saturation(case):
-    """DLSolver(S=<2-D tensor>): passed straight through by the reference (dl_solver.py:843-848)."""
+    """A 2-D tensor S -- DLSolver(S=...) or the parameter key's S of MF / Langevin / pumped Langevin -- is passed
+    straight through by the reference (dl_solver.py:843-848, mf_solver.py:834-839, ...)."""
     g, meta, arrays = golden("test020"), full_s_cases()[case], full_s_arrays()
-    assert torch.tensor(meta["dl_S"]).ndim == 2
+    assert torch.tensor(meta["dl_S"] if meta["kind"] == "dl" else meta["params"]["S"]).ndim == 2
     out = run_oracle(g, meta)
     for key in arrays.files:
         if not key.startswith(case + "/"):
