@@ -17,7 +17,10 @@ done
 for n in 320 384 448; do
   for k in auto nocluster; do
     if [ $k = auto ]; then unset CCVM_AMD_KERNEL; else export CCVM_AMD_KERNEL=nocluster; fi
-    rocprofv3 --kernel-trace --stats -d $OUT/lv_n${n}_${k}_stats -o s --output-format csv -- python3 tools/time_small.py langevin:$n:1000 mf:$n:1000 > $OUT/lv_n${n}_${k}.txt 2>&1 || exit 1
+    # timing WITHOUT the profiler (its per-dispatch overhead inflates a per-step kernel by 2-6 us and leaves a
+    # persistent kernel untouched), then the same run under the profiler for the kernel names and launch counts
+    python3 tools/time_small.py langevin:$n:1000 mf:$n:1000 > $OUT/lv_n${n}_${k}.txt 2>&1 || exit 1
+    rocprofv3 --kernel-trace --stats -d $OUT/lv_n${n}_${k}_stats -o s --output-format csv -- python3 tools/time_small.py langevin:$n:1000 mf:$n:1000 > $OUT/lv_n${n}_${k}_profiled.txt 2>&1 || exit 1
   done
   unset CCVM_AMD_KERNEL
   echo "mid $n done"
