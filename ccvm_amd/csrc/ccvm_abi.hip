@@ -356,15 +356,9 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return CCVM_OK;
     }
     if (want_persist(N, tun)) {
-        const int nch = std::min((N + 15) / 16, 16);
-        const int cw = nch == 1 ? 16 : nch == 2 ? 32 : 64;
-        const int ncg = nch <= 4 ? 1 : nch <= 8 ? 2 : 4;
-        const int br4 = (solver == 0 ? 2 : 4) * (64 / cw);
-        int ru = ((B + br4 - 1) / br4) * ncg >= 768 ? 4 : 2;
-        if (tun.persist_ru) ru = tun.persist_ru;
-        const int per = br4 * ru / 4 * (4 / ncg);
+        const PersistShape sh = persist_shape(solver == 0, B, N, tun.persist_ru);
         std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d> grid %d x 256 threads, up to %d steps per launch",
-                      solver, ad ? "true" : "false", cw, ncg, nch, ru, (B + per - 1) / per, TABLE_STEPS);
+                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.grid, TABLE_STEPS);
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun);

@@ -16,23 +16,35 @@ void persist_launch_mf_adam(const PersistArgs& a, hipStream_t st);
 void persist_launch_lv(const PersistArgs& a, hipStream_t st);
 void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 
+// The launch shape of the persistent kernel for (solver, B, N): ONE definition, used by the launcher below and
+// by ccvm_describe_launch (so that the name a benchmark line reports is the instantiation that runs).
+struct PersistShape {
+    int cw, ncg, nch, ru, grid;
+};
+inline PersistShape persist_shape(bool dl, int B, int N, int ru_override) {
+    PersistShape s;
+    s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
+    s.cw = s.nch == 1 ? 16 : s.nch == 2 ? 32 : 64;                   // columns a wave covers
+    s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : 4;                     // waves side by side
+    const int br4 = (dl ? 2 : 4) * (64 / s.cw);                      // batch rows per row set at RU = 4
+    s.ru = ((B + br4 - 1) / br4) * s.ncg >= 768 ? 4 : 2;
+    if (ru_override == 2 || ru_override == 4) s.ru = ru_override;
+    const int per = br4 * s.ru / 4 * (4 / s.ncg);                    // batch rows per workgroup
+    s.grid = (B + per - 1) / per;
+    return s;
+}
+
 // Shape by N (columns a wave covers x waves side by side) and rows in use per 4-row group: 4 when
 // that still gives (nearly) every one of the 1024 SIMDs a wave, else 2 (shorter per-step chain per
 // wave, twice the waves).  PersistArgs::ru_override (CCVM_AMD_PERSIST_RU=2|4, read by the ABI) forces one.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
-    constexpr int RG = 64 / CW;
-    const int br4 = ((MODE == MODE_DL) ? 2 : 4) * RG;  // batch rows per workgroup at RU = 4
-    int ru = ((a.B + br4 - 1) / br4) * NCG >= 768 ? 4 : 2;
-    if (a.ru_override == 2 || a.ru_override == 4) ru = a.ru_override;
+    const PersistShape sh = persist_shape(MODE == MODE_DL, a.B, a.N, a.ru_override);  // sh.cw == CW etc. by construction
     const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
-    if (ru == 4) {
-        const int per = br4 * (4 / NCG);
-        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4>), dim3((a.B + per - 1) / per), block, 0, st, a);
-    } else {
-        const int per = br4 / 2 * (4 / NCG);
-        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2>), dim3((a.B + per - 1) / per), block, 0, st, a);
-    }
+    if (sh.ru == 4)
+        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4>), dim3(sh.grid), block, 0, st, a);
+    else
+        hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2>), dim3(sh.grid), block, 0, st, a);
 }
 
 template <int MODE, bool ADAM>
