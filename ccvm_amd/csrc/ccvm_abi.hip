@@ -245,24 +245,37 @@ size_t cluster_sync_bytes(int B) { return 128 + (size_t)((cluster_count(B) + 7) 
 // N = 500).  There the launch-free time loop wins 10-13 % over the tile kernel (7.05 vs 8.15 us per step,
 // Langevin N = 500, B = 1000); with more clusters than CUs they run in rounds and the tile kernel's larger
 // tiles are the better use of the chip.
+// the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h, CCVM_CL_LL), one per
+// element of the clusters' rows; nothing at the sizes the cluster kernel does not serve
+size_t cluster_exchange_bytes(int B, int N) {
+    if (N < CL_MIN_N || N > CL_MAX_N) return 0;
+    return 2 * (size_t)cluster_count(B) * 2 * CL_ROWS * round_up(N, 128) * 8;
+}
 bool want_cluster(int B, int N, const Tuning& tun) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
     if (tun.cluster < 0 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
-    return (size_t)cluster_count(B) * 2 * CL_ROWS * ccvm_ld(N) * sizeof(float) < ((size_t)1 << 31);  // 32-bit buffer offsets
+    return cluster_exchange_bytes(B, N) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
-// the part of ClusterArgs every solver shares; returns the counters' address (zeroed before each launch)
-unsigned* cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
-                       const ccvm_noise* nz, float* table, void* sync_area) {
+// the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:
+// [exchange buffer 0][exchange buffer 1][status word + counters].  Zeroes the exchange buffers (once per call: the
+// tags are global step numbers, unique across the launches of a call) and the status word's neighbours.
+int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
+                 const ccvm_noise* nz, float* table, void* area, hipStream_t st) {
     std::memset(&ca, 0, sizeof(ca));
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
-    ca.status = static_cast<unsigned*>(sync_area);
+    const size_t xb = cluster_exchange_bytes(B, N);
+    ca.xb0 = static_cast<float*>(area);
+    ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
+    if (hipMemsetAsync(area, 0, xb, st) != hipSuccess) return CCVM_E_HIP;
+    ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + xb);
     ca.sync = ca.status + 32;
+    if (hipMemsetAsync(ca.sync, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld;
     ca.nclusters = cluster_count(B);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
-    return ca.sync;
+    return CCVM_OK;
 }
 
 template <int MODE, bool ADAM>
@@ -308,10 +321,10 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
         case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
-        // MF: measured-amplitude ping-pong + noise carry; Langevin: c' + a second exchange buffer of the
-        // cluster path; both: the cluster path's status word and counters
-        case 1: return 3 * state + qs + table_bytes() + cluster_sync_bytes(B);
-        case 2: return 2 * state + qs + table_bytes() + cluster_sync_bytes(B);
+        // MF: measured-amplitude ping-pong + noise carry; Langevin: c' (+ one spare state); both: the cluster
+        // path's exchange buffers, status word and counters
+        case 1: return 3 * state + qs + table_bytes() + cluster_exchange_bytes(B, N) + cluster_sync_bytes(B);
+        case 2: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N) + cluster_sync_bytes(B);
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
         case 5: return qs;                               // ccvm_feedback
@@ -612,23 +625,19 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
         const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
-        unsigned* counters = cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes());
+        if (cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = mu; ca.x1 = sigma; ca.xt = mu_tilde_out;
-        ca.xb0 = static_cast<float*>(ws); ca.xb1 = static_cast<float*>(ws) + state;
         ca.in_scale = (float)(ul / S_eff); ca.in_shift = (float)up; ca.S = (float)S_eff; ca.s_cols = s_cols;
         PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
         std::memset(&pa_ad, 0, sizeof(pa_ad));
         AdamSched asc;
         persist_adam(pa_ad, asc, adam, use_adam);
         ca.ad = pa_ad.ad; ca.am = pa_ad.am; ca.av = pa_ad.av;
-        if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
-            return fail(CCVM_E_HIP, "%s: memset failed", fn);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
             hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
-            if (hipMemsetAsync(counters, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess)
-                return fail(CCVM_E_HIP, "%s: memset failed", fn);
             ca.step0 = step0 + done;
             ca.nsteps = k;
             ca.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
@@ -812,9 +821,9 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (want_cluster(B, N, tun)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         ClusterArgs ca;
-        unsigned* counters = cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes());
+        if (cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = c;
-        ca.xb0 = static_cast<float*>(ws); ca.xb1 = static_cast<float*>(ws) + state;
         ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.s_cols = s_cols;
         PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
         std::memset(&pa_ad, 0, sizeof(pa_ad));
@@ -826,8 +835,6 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
             hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
-            if (hipMemsetAsync(counters, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess)
-                return fail(CCVM_E_HIP, "%s: memset failed", fn);
             ca.step0 = step0 + done;
             ca.nsteps = k;
             if (ca.replay) ca.w0 = nz->w0 + (size_t)done * N * B;

@@ -110,6 +110,22 @@ struct ClusterArgs {
 #ifndef CCVM_CL_SLEEP
 #define CCVM_CL_SLEEP 4
 #endif
+// CCVM_CL_LL = 1: flag-in-data exchange.  Every exchanged element is an 8-byte pair {value, tag} (tag = global step
+// number of the GEMM it feeds + 1; buffers zeroed before the call), written by ONE lane with ONE 8-byte sc1 store and
+// read as half of a 16-byte sc1 load: a reader that finds the expected tag has the value that was stored with it.
+// No drain, no counter, no poll, no barrier for the hand-off: the chain store -> counter -> poll -> load (three
+// memory round trips) becomes store -> load.  A lane whose packets have not all landed re-issues its loads (bounded).
+// Ping-pong safety is the counter protocol's: a member publishes input j + 1 only after it has consumed input j from
+// every member, so nobody overwrites input j (with j + 2) while anybody still reads it, and every stale tag a reader
+// can meet is SMALLER than the one it waits for (min over the tags == expected  <=>  all arrived).
+#ifndef CCVM_CL_LL
+#define CCVM_CL_LL 1
+#endif
+// LL: the other set's input is fetched after chunk CCVM_CL_LLY of a phase (its stores were issued at the end of the
+// previous phase)
+#ifndef CCVM_CL_LLY
+#define CCVM_CL_LLY 1
+#endif
 #ifndef CCVM_CL_WAVESIG
 #define CCVM_CL_WAVESIG 0
 #endif
@@ -129,7 +145,10 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
 
 // KCH = K / 128 (3 or 4): K = ld = N rounded up to 128.
-template <int MODE, bool ADAM, int KCH>
+// REPLAY is a template parameter, not a run-time branch: with the replay loads in the same code as the fused
+// noise hipcc guards the registers they share with s_waitcnt vmcnt(0) in BOTH paths, which made every epilogue wait
+// for the other set's input in flight (~0.5 us per phase) -- the very latency the two row sets exist to hide.
+template <int MODE, bool ADAM, int KCH, bool REPLAY>
 __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     static_assert(MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: one-stream solvers");
     static_assert(KCH == 3 || KCH == 4, "K = 384 or 512");
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
         if constexpr (CCVM_CLUSTER_ABL & 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) out[i] = 0.25f;
-        } else if (a.replay) {
+        } else if constexpr (REPLAY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 out[i] = ok[s][i] ? a.w0[((size_t)it * N + col) * a.B + brow[s][i]] : 0.0f;
@@ -229,9 +248,18 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
         }
     };
 
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    auto mark = [&](int k) {
+        if constexpr (CCVM_CLUSTER_ABL & 64) {
+            const unsigned long long t = cl_stamp();
+            seg[k] += t - t_last;
+            t_last = t;
+        }
+    };
     // ---- exchange plumbing --------------------------------------------------------------------------
     // buffer descriptors of the two exchange buffers (wave-uniform: kernel arguments only)
-    const size_t xbytes = (size_t)(a.nclusters * 2 * CL_ROWS) * ld * sizeof(float);
+    constexpr unsigned XE = CCVM_CL_LL ? 8 : 4;  // bytes per exchanged element
+    const size_t xbytes = (size_t)(a.nclusters * 2 * CL_ROWS) * ld * XE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.xb0, 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.xb1, 0, (int)xbytes, 0x00020000);
     constexpr int SC1 = 16;  // aux bits of the buffer builtins: sc1
@@ -240,7 +268,20 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     // into exchange buffer `par`: through an LDS tile so that each lane stores 16 bytes and every 128-byte
     // line is written whole by one instruction.  The stores are NOT waited for here: `signal` (drain by every
     // storing wave, barrier, ONE counter add) runs one chunk into the next phase, behind ~0.6 us of MFMAs.
-    auto publish_stores = [&](int s, int par, const float (&x)[4]) {
+    typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+    // LL: this lane's elements are its own 8-byte packets: rows 4 g + i, column `col` -- a store instruction writes
+    // 4 rows x 16 columns x 8 bytes = four whole 128-byte lines; no LDS tile, no barrier
+    const unsigned pub_off = (unsigned)(((size_t)(crow0 + 4 * g) * ld + col) * XE);
+    auto publish_stores = [&](int s, int par, const float (&x)[4], unsigned tag) {
+        if constexpr (CCVM_CL_LL) {
+            if constexpr (CCVM_CLUSTER_ABL & 16) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x2c v = {__builtin_bit_cast(unsigned, ok[s][i] ? x[i] : 0.0f), tag};
+                __builtin_amdgcn_raw_buffer_store_b64(v, par ? rs1 : rs0, pub_off, (CL_ROWS * s + i) * ld * XE, SC1);
+            }
+            return;
+        }
         if constexpr (CCVM_CLUSTER_ABL & 16) { __syncthreads(); return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) tile[(4 * g + i) * TS + 16 * wave + c16] = ok[s][i] ? x[i] : 0.0f;
@@ -275,9 +316,22 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
 
     // the full input rows of set s from buffer `par`, in flight into registers: chunk c, piece j of this
     // lane = row (tid + 256 j) / 32, floats 4 ((tid + 256 j) % 32) of the chunk's 128
-    struct AReg { f32x4c v[KCH][2]; };
+    // LL: piece (c, j) is two 16-byte packets pairs {x0, tag, x1, tag}, {x2, tag, x3, tag}
+    struct AReg { f32x4c v[KCH][2]; u32x4c w[CCVM_CL_LL ? KCH : 1][2][2]; };
+    const unsigned ld_off = (unsigned)(((size_t)(crow0 + (tid >> 5)) * ld + 4 * (tid & 31)) * XE);
     auto load_a = [&](AReg& ar, int s, int par) {
         if constexpr (CCVM_CLUSTER_ABL & 8) return;
+        if constexpr (CCVM_CL_LL) {
+#pragma unroll
+            for (int c = 0; c < KCH; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        ar.w[c][j][h] = __builtin_amdgcn_raw_buffer_load_b128(
+                            par ? rs1 : rs0, ld_off, ((CL_ROWS * s + 8 * j) * ld + CL_KC * c + 2 * h) * XE, SC1);
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < KCH; ++c)
 #pragma unroll
@@ -288,13 +342,54 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                 ar.v[c][j] = __builtin_bit_cast(f32x4c, raw);
             }
     };
+    // LL: have all packets of this lane's pieces arrived?  (stale tags are smaller than `want`, see CCVM_CL_LL; the
+    // columns >= 64 G of the last chunk are never published: their tags are ignored, their values stay 0)
+    const unsigned pad_tag = (CL_KC * (KCH - 1) + 4 * (tid & 31) >= CL_COLS * G) ? 0xFFFFFFFFu : 0u;
+    auto arrived = [&](const AReg& ar, unsigned want) {
+        unsigned lo = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned t0 = ar.w[c][j][h][1], t1 = ar.w[c][j][h][3];
+                    lo = (c == KCH - 1) ? min(lo, min(t0 | pad_tag, t1 | pad_tag)) : min(lo, min(t0, t1));
+                }
+        return __builtin_amdgcn_ballot_w64(lo != want) == 0;
+    };
+    // LL: wait (bounded) until set s's input `want` is complete in ar -- normally it is when the phase starts
+    auto await_a = [&](AReg& ar, int s, int par, unsigned want) {
+        if constexpr (!CCVM_CL_LL || (CCVM_CLUSTER_ABL & (4 | 8 | 16))) return;
+        // the first check stands alone (straight-line code behind the previous phase's publish stores, which stay in
+        // flight: inside the retry loop the merged wait counts would drain them)
+        if (__builtin_expect(arrived(ar, want), 1)) return;
+        unsigned spins = 0;
+        do {
+            if constexpr (CCVM_CLUSTER_ABL & 64) seg[7] += 1;
+            if (++spins > (CL_SPIN_LIMIT >> 3)) {  // ~2 us per round
+                if (lane == 0) {
+                    __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lds[DEAD] = 1.0f;  // read by everyone behind the next barrier
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(CCVM_CL_SLEEP);
+            load_a(ar, s, par);
+        } while (!arrived(ar, want));
+    };
     auto stage_a = [&](const AReg& ar, int c) {  // chunk c -> A buffer c % 3
         float* dst = abuf + (c % 3) * ABUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = tid + 256 * j, r = p >> 5, q4 = p & 31;
             float* d = dst + rowpos(r) * AS + shift(r) + 4 * q4;
-            if constexpr (CCVM_CL_WIDE) {
+            if constexpr (CCVM_CL_LL) {
+                static_assert(CCVM_CL_WIDE, "LL exchange: wide image only");
+                const u32x4c lo = ar.w[c][j][0], hi = ar.w[c][j][1];
+                const u32x4c x = {lo[0], lo[2], hi[0], hi[2]};
+                *reinterpret_cast<f32x4c*>(d) = __builtin_bit_cast(f32x4c, x);
+            } else if constexpr (CCVM_CL_WIDE) {
                 *reinterpret_cast<f32x4c*>(d) = ar.v[c][j];
             } else {  // rows 8..15 sit 8 bytes off the 16-byte grid: two 8-byte writes
                 typedef float f32x2c __attribute__((ext_vector_type(2)));
@@ -315,21 +410,25 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                 const float bound = a.s_cols ? sat_j : a.S;
                 mt[s][i] = ok[s][i] ? clampf(__builtin_fmaf(a.k_first, wc[s][i], s0[s][i]), -bound, bound) : 0.0f;
             }
-            publish_stores(s, 0, mt[s]);
+            publish_stores(s, 0, mt[s], (unsigned)a.step0 + 1u);
         } else {
-            publish_stores(s, 0, s0[s]);
+            publish_stores(s, 0, s0[s], (unsigned)a.step0 + 1u);
         }
-        drain();
-        if (CCVM_CL_WAVESIG) signal(s);
-        __syncthreads();
-        if (!CCVM_CL_WAVESIG) signal(s);
+        if constexpr (!CCVM_CL_LL) {
+            drain();
+            if (CCVM_CL_WAVESIG) signal(s);
+            __syncthreads();
+            if (!CCVM_CL_WAVESIG) signal(s);
+        }
     }
 
     AReg ar[2];
-    poll(0, 0);
-    __syncthreads();
-    if (lds[DEAD] != 0.0f) return;
-    load_a(ar[0], 0, 0);
+    if constexpr (!CCVM_CL_LL) {
+        poll(0, 0);
+        __syncthreads();
+        if (lds[DEAD] != 0.0f) return;
+    }
+    load_a(ar[0], 0, 0);  // LL: whatever has not landed yet is fetched again by await_a
 
     // operand read addresses: A row c16, B column 16 wave + c16, k residue g
     // operand m of a chunk sits at rd[OPS * m]: natural order k = 4 m + g, or (wide) k = 32 g + m, contiguous per lane
@@ -355,14 +454,6 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
     struct Row { float w[TABLE_WORDS]; };
     Row rnext = *reinterpret_cast<const Row*>(a.table);
     bool pending = false;  // publish stores of the previous phase not yet drained / signalled
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
-    auto mark = [&](int k) {
-        if constexpr (CCVM_CLUSTER_ABL & 64) {
-            const unsigned long long t = cl_stamp();
-            seg[k] += t - t_last;
-            t_last = t;
-        }
-    };
     if constexpr (CCVM_CLUSTER_ABL & 64) t_last = cl_stamp();
 
     for (int it = 0; it < a.nsteps; ++it) {
@@ -374,6 +465,9 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             // ---- stage this set's first chunks (its input arrived in registers during the previous phase) ----
+            if constexpr (CCVM_CL_LL) mark(6);
+            await_a(ar[s], s, it & 1, (unsigned)step + 1u);
+            if constexpr (CCVM_CL_LL) mark(0);
             stage_a(ar[s], 0);
             stage_a(ar[s], 1);
             stage_a(ar[s], 2);
@@ -381,7 +475,12 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
             const int oj = (s == 0) ? it : it + 1;      // ... needs input number oj next
             const bool fetch = (s == 0) || has_next;
             __syncthreads();
-            mark(0);
+            if constexpr (CCVM_CL_LL) {
+                if (lds[DEAD] != 0.0f) return;
+                mark(1);
+            } else {
+                mark(0);
+            }
 
             // ---- acc = X[set rows][:] @ Q[:, this wave's 16 columns] ------------------------------------
             f32x4c acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -447,7 +546,18 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                 //     remaining chunk(s) and the epilogue (~1.2 us) to land before it is staged.
                 constexpr int CX = (KCH == 4) ? CCVM_CL_X : 0, CY = (KCH == 4) ? CCVM_CL_Y : 1;
                 static_assert(CX < CY && CY + 1 < KCH, "signal before poll; both on chunk barriers");
-                if constexpr (c == CX) {
+                if constexpr (CCVM_CL_LL) {
+                    // the peers stored this input at the end of THEIR previous phase, (LLY + 1) chunks ago; it has
+                    // the remaining chunks and the epilogue to travel
+                    constexpr int LLY = CCVM_CL_LLY < KCH ? CCVM_CL_LLY : KCH - 1;
+                    if constexpr (c == LLY) {
+                        mark(2);
+                        if (fetch) load_a(ar[os], os, oj & 1);
+                        mark(3);
+                    }
+                    if constexpr (c + 1 == KCH) mark(4);
+                    if constexpr (c + 1 < KCH) __syncthreads();  // chunk c's buffer may be refilled; chunk c + 1 is complete
+                } else if constexpr (c == CX) {
                     mark(1);
                     if (pending) drain();
                     mark(2);
@@ -521,7 +631,9 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                     mt[s][i] = nxt ? clampf(__builtin_fmaf(k.k_next, nz[i], s0[s][i]), -bound, bound) : mt[s][i];
                     wc[s][i] = nxt ? nz[i] : wc[s][i];
                 }
-                if (has_next) publish_stores(s, (it + 1) & 1, mt[s]);
+                // LL: published every step (a conditional store makes the next tag check drain it); after the last
+                // step with tag 0, which nobody waits for
+                if (CCVM_CL_LL || has_next) publish_stores(s, (it + 1) & 1, mt[s], has_next ? (unsigned)step + 2u : 0u);
             } else {
                 const LvScalars k = *reinterpret_cast<const LvScalars*>(trow);
 #pragma unroll
@@ -529,11 +641,17 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
                     const float gr = adam(__builtin_fmaf(k.g_q, qx[i], k.g_v * vj) * inv_sat_j, i);
                     s0[s][i] = lv_update(k, s0[s][i], gr, nz[i], a.s_cols ? sat_j : k.S);
                 }
-                if (has_next) publish_stores(s, (it + 1) & 1, s0[s]);
+                if (CCVM_CL_LL || has_next) publish_stores(s, (it + 1) & 1, s0[s], has_next ? (unsigned)step + 2u : 0u);
             }
-            if (has_next) pending = true;  // drained and signalled one chunk into the next phase
-            else __syncthreads();          // the A buffers may be restaged: every wave is past its last chunk
-            mark(7);
+            if constexpr (CCVM_CL_LL) {
+                mark(5);
+                __syncthreads();               // the A buffers may be restaged: every wave is past its last chunk
+                __builtin_amdgcn_sched_barrier(0);  // no part of the next tag check (a wait for the loads) up here
+            } else {
+                if (has_next) pending = true;  // drained and signalled one chunk into the next phase
+                else __syncthreads();          // the A buffers may be restaged: every wave is past its last chunk
+            }
+            if constexpr (!CCVM_CL_LL) mark(7);
         }
     }
 
@@ -562,16 +680,21 @@ __global__ __launch_bounds__(256) void cluster_kernel(const ClusterArgs a) {
 void cluster_launch_mf(const ClusterArgs& a, bool adam, hipStream_t st);
 void cluster_launch_lv(const ClusterArgs& a, bool adam, hipStream_t st);
 
+template <int MODE, bool ADAM, bool REPLAY>
+void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
+    if (a.ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(256), 0, st, a);
+}
+
 template <int MODE>
 void launch_cluster(const ClusterArgs& a, bool adam, hipStream_t st) {
     const int grid = ((a.nclusters + 7) / 8) * 8 * a.G;
-    const bool k4 = a.ld == 512;
     if (adam) {
-        if (k4) hipLaunchKernelGGL((cluster_kernel<MODE, true, 4>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((cluster_kernel<MODE, true, 3>), dim3(grid), dim3(256), 0, st, a);
+        if (a.replay) launch_cluster_variant<MODE, true, true>(a, grid, st);
+        else launch_cluster_variant<MODE, true, false>(a, grid, st);
     } else {
-        if (k4) hipLaunchKernelGGL((cluster_kernel<MODE, false, 4>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((cluster_kernel<MODE, false, 3>), dim3(grid), dim3(256), 0, st, a);
+        if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
+        else launch_cluster_variant<MODE, false, false>(a, grid, st);
     }
 }
 

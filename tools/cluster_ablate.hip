@@ -13,15 +13,15 @@ int main(int argc, char** argv) {
     const int ld = (N + 127) / 128 * 128, rows = (B + 63) / 64 * 64, steps = 4096;
     const size_t state = (size_t)rows * ld;
     float *Q, *V, *c, *xb0, *xb1, *table; unsigned* sync;
-    hipMalloc(&Q, (size_t)ld * ld * 4); hipMalloc(&V, ld * 4); hipMalloc(&c, state * 4); hipMalloc(&xb0, state * 4);
-    hipMalloc(&xb1, state * 4); hipMalloc(&table, steps * TABLE_WORDS * 4); hipMalloc(&sync, 1 << 20);
+    hipMalloc(&Q, (size_t)ld * ld * 4); hipMalloc(&V, ld * 4); hipMalloc(&c, state * 4); hipMalloc(&xb0, state * 8);
+    hipMalloc(&xb1, state * 8); hipMalloc(&table, steps * TABLE_WORDS * 4); hipMalloc(&sync, 1 << 20);
     std::vector<float> h((size_t)ld * ld, 0.f);
     unsigned rng = 1;
     auto rnd = [&] { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f); };
     for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) h[(size_t)i * ld + j] = rnd() * 0.02f;
     hipMemcpy(Q, h.data(), (size_t)ld * ld * 4, hipMemcpyHostToDevice);
     hipMemcpy(V, h.data(), ld * 4, hipMemcpyHostToDevice);
-    hipMemset(c, 0, state * 4); hipMemset(xb0, 0, state * 4); hipMemset(xb1, 0, state * 4);
+    hipMemset(c, 0, state * 4); 
     LvSched sc{0.002, 0.5, 1.0, 0.5, 2.0, 1.0, 1, 1, 15000, 0, steps, AdamSched{}};
     hipLaunchKernelGGL(lv_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
     ClusterArgs a; memset(&a, 0, sizeof(a));
@@ -35,9 +35,11 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(sync, 0, 1 << 20);
+        hipMemset(xb0, 0, state * 8); hipMemset(xb1, 0, state * 8);  // LL exchange: no stale tags
+        hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 4>), dim3(grid), dim3(256), 0, 0, a);
-        else hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 3>), dim3(grid), dim3(256), 0, 0, a);
+        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 4, false>), dim3(grid), dim3(256), 0, 0, a);
+        else hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 3, false>), dim3(grid), dim3(256), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
@@ -46,8 +48,11 @@ int main(int argc, char** argv) {
     if (CCVM_CLUSTER_ABL & 64) {
         std::vector<unsigned long long> hd((size_t)grid * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-        const char* names[8] = {"stage + wait for input loads", "chunks before X", "drain wait", "barrier at X (+signal)",
-                                "chunks X..Y", "poll wait", "barrier at Y + load issue", "rest: chunks, epilogue, publish"};
+        const char* names_old[8] = {"stage + wait for input loads", "chunks before X", "drain wait", "barrier at X (+signal)",
+                                    "chunks X..Y", "poll wait", "barrier at Y + load issue", "rest: chunks, epilogue, publish"};
+        const char* names_ll[8] = {"tag check (+ retries)", "stage + barrier", "chunks up to LLY", "load issue",
+                                   "remaining chunks", "epilogue + publish", "end barrier", "RETRY ROUNDS (count)"};
+        const char** names = CCVM_CL_LL ? names_ll : names_old;
         for (int k = 0; k < 8; ++k) {
             std::vector<double> v;
             for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 8 + k] / (2.0 * steps));
