@@ -239,8 +239,8 @@ bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 512, one-stream solvers ---------
 int cluster_count(int B) { return (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS); }
-// status word (its own 128-byte line) + one 256-byte counter pair per cluster, clusters padded to 8
-size_t cluster_sync_bytes(int B) { return 128 + (size_t)((cluster_count(B) + 7) / 8 * 8) * 256; }
+// the launch status word (its own 128-byte line), last in the workspace
+size_t cluster_sync_bytes(int) { return 128; }
 // Default: only while every cluster is resident at once (<= 256 workgroups, one per CU: B <= 1024 at
 // N = 500).  There the launch-free time loop wins 10-13 % over the tile kernel (7.05 vs 8.15 us per step,
 // Langevin N = 500, B = 1000); with more clusters than CUs they run in rounds and the tile kernel's larger
@@ -258,8 +258,8 @@ bool want_cluster(int B, int N, const Tuning& tun) {
     return cluster_exchange_bytes(B, N) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:
-// [exchange buffer 0][exchange buffer 1][status word + counters].  Zeroes the exchange buffers (once per call: the
-// tags are global step numbers, unique across the launches of a call) and the status word's neighbours.
+// [exchange buffer 0][exchange buffer 1][status word].  Zeroes the exchange buffers (once per call: the tags are
+// global step numbers, unique across the launches of a call).
 int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
                  const ccvm_noise* nz, float* table, void* area, hipStream_t st) {
     std::memset(&ca, 0, sizeof(ca));
@@ -269,8 +269,6 @@ int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* q
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
     if (hipMemsetAsync(area, 0, xb, st) != hipSuccess) return CCVM_E_HIP;
     ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + xb);
-    ca.sync = ca.status + 32;
-    if (hipMemsetAsync(ca.sync, 0, cluster_sync_bytes(B) - 128, st) != hipSuccess) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld;
     ca.nclusters = cluster_count(B);
@@ -363,7 +361,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     const bool ad = adam && solver != 0;
     if (solver != 0 && !want_persist(N, tun) && want_cluster(B, N, tun)) {
         const int G = (N + CL_COLS - 1) / CL_COLS;
-        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d> grid %d x 256 threads (%d clusters of %d workgroups), up to %d steps per launch",
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups), up to %d steps per launch",
                       solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B) + 7) / 8 * 8 * G, cluster_count(B), G,
                       TABLE_STEPS);
         return CCVM_OK;

@@ -48,13 +48,19 @@ def test_layout_helpers_and_version(hip_lib):
     state = 1024 * 1024 * 4
     qs = 33 * 1024 * 4  # column sums of Q + 32 slice partials
     table = 4096 * 16 * 4  # schedule table of the persistent small-N path
-    sync = 128 + 32 * 256  # status word + one counter pair per cluster of 32 rows (clusters padded to 8)
+    sync = 128  # the cluster path's launch status word (its own 128-byte line), last in the workspace
     assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table
     assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs + table + sync
     assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == 2 * state + qs + table + sync
     assert hip_lib.ccvm_status_offset(1, 1000, 1000) == 3 * state + qs + table
     assert hip_lib.ccvm_status_offset(2, 1000, 1000) == 2 * state + qs + table
     assert hip_lib.ccvm_status_offset(0, 1000, 1000) == ctypes.c_size_t(-1).value
+    # 256 < N <= 512: + the cluster path's two exchange buffers of 8-byte {value, tag} packets
+    state5, qs5 = 1024 * 512 * 4, 33 * 512 * 4
+    xchg = 2 * 32 * 32 * 512 * 8
+    assert hip_lib.ccvm_workspace_bytes(2, 1000, 500) == 2 * state5 + qs5 + table + xchg + sync
+    assert hip_lib.ccvm_workspace_bytes(1, 1000, 500) == 3 * state5 + qs5 + table + xchg + sync
+    assert hip_lib.ccvm_status_offset(2, 1000, 500) == 2 * state5 + qs5 + table + xchg
     assert hip_lib.ccvm_workspace_bytes(3, 1000, 1000) == 32 * 1024 * 4
     assert hip_lib.ccvm_workspace_bytes(4, 1000, 1000) == 2 * state
     assert hip_lib.ccvm_workspace_bytes(5, 1000, 1000) == qs
@@ -84,8 +90,8 @@ def test_describe_launch_names_the_instantiation(hip_lib):
     want = {
         (0, 1000, 1000, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 256 x 512",
         (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4> grid 250 x 256",
-        (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4> grid 256 x 256 threads (32 clusters of 8 workgroups)",
-        (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4> grid 256 x 256 threads (32 clusters of 8 workgroups)",
+        (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
+        (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 4000, 500, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 500 x 512",
         (1, 1000, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 160 x 512",
         (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",

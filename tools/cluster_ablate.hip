@@ -26,11 +26,11 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(lv_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
     ClusterArgs a; memset(&a, 0, sizeof(a));
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
-    a.status = sync; a.sync = sync + 32;
+    a.status = sync;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
     a.nclusters = (B + 31) / 32; a.G = (N + 63) / 64;
     const int grid = (a.nclusters + 7) / 8 * 8 * a.G;
-    unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 8 * 8); hipMemset(dbg, 0, (size_t)grid * 8 * 8);
+    unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 16 * 8); hipMemset(dbg, 0, (size_t)grid * 16 * 8);
     a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
@@ -38,26 +38,25 @@ int main(int argc, char** argv) {
         hipMemset(xb0, 0, state * 8); hipMemset(xb1, 0, state * 8);  // LL exchange: no stale tags
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 4, false>), dim3(grid), dim3(256), 0, 0, a);
-        else hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 3, false>), dim3(grid), dim3(256), 0, 0, a);
+        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 4, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a);
+        else hipLaunchKernelGGL((cluster_kernel<MODE_LANGEVIN, false, 3, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
         if (rep == 2) printf("ABL=%2d N=%d B=%d grid %d: %.3f us/step%s\n", CCVM_CLUSTER_ABL, N, B, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
     }
     if (CCVM_CLUSTER_ABL & 64) {
-        std::vector<unsigned long long> hd((size_t)grid * 8);
+        std::vector<unsigned long long> hd((size_t)grid * 16);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-        const char* names_old[8] = {"stage + wait for input loads", "chunks before X", "drain wait", "barrier at X (+signal)",
-                                    "chunks X..Y", "poll wait", "barrier at Y + load issue", "rest: chunks, epilogue, publish"};
-        const char* names_ll[8] = {"tag check (+ retries)", "stage + barrier", "chunks up to LLY", "load issue",
-                                   "remaining chunks", "epilogue + publish", "end barrier", "RETRY ROUNDS (count)"};
-        const char** names = CCVM_CL_LL ? names_ll : names_old;
-        for (int k = 0; k < 8; ++k) {
+        const char* names[16] = {"MFMA wave: wait at B_0", "MFMA wave: first read + chunks", "MFMA wave: update + publish", "", "", "", "", "",
+                                 "fetch wave: wait at B_0", "fetch wave: staging + inner barriers", "fetch wave: load issue",
+                                 "fetch wave: wait at last barrier", "fetch wave: tag check + stage next", "fetch wave: RETRY ROUNDS per phase", "", ""};
+        for (int k = 0; k < 16; ++k) {
+            if (!names[k][0]) continue;
             std::vector<double> v;
-            for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 8 + k] / (2.0 * steps));
+            for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 16 + k] / (2.0 * steps));
             std::sort(v.begin(), v.end());
-            printf("%-34s: min %7.0f  median %7.0f  max %7.0f cycles/phase (100 MHz ticks x?)\n", names[k], v.front(), v[v.size() / 2], v.back());
+            printf("%-38s: min %8.1f  median %8.1f  max %8.1f ticks/phase\n", names[k], v.front(), v[v.size() / 2], v.back());
         }
     }
     return 0;
