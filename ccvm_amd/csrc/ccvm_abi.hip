@@ -247,24 +247,25 @@ size_t cluster_sync_bytes(int) { return 128; }
 // tiles are the better use of the chip.
 // the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h, CCVM_CL_LL), one per
 // element of the clusters' rows; nothing at the sizes the cluster kernel does not serve
-size_t cluster_exchange_bytes(int B, int N) {
+// (planes: DL exchanges c and s, the one-stream solvers one array)
+size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
-    return 2 * (size_t)cluster_count(B) * 2 * CL_ROWS * round_up(N, 128) * 8;
+    return 2 * (size_t)cluster_count(B) * 2 * CL_ROWS * planes * round_up(N, 128) * CL_XE;
 }
-bool want_cluster(int B, int N, const Tuning& tun) {
+bool want_cluster(int B, int N, const Tuning& tun, int planes = 1) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
     if (tun.cluster < 0 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
-    return cluster_exchange_bytes(B, N) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
+    return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:
 // [exchange buffer 0][exchange buffer 1][status word].  Zeroes the exchange buffers (once per call: the tags are
 // global step numbers, unique across the launches of a call).
 int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
-                 const ccvm_noise* nz, float* table, void* area, hipStream_t st) {
+                 const ccvm_noise* nz, float* table, void* area, hipStream_t st, int planes = 1) {
     std::memset(&ca, 0, sizeof(ca));
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
-    const size_t xb = cluster_exchange_bytes(B, N);
+    const size_t xb = cluster_exchange_bytes(B, N, planes);
     ca.xb0 = static_cast<float*>(area);
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
     if (hipMemsetAsync(area, 0, xb, st) != hipSuccess) return CCVM_E_HIP;
@@ -318,11 +319,12 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t state = rows * ld * sizeof(float);
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
-        case 0: return 2 * state + qs + table_bytes();   // DL: c', s' (+ schedule table of the persistent path)
+        // DL: c', s', the schedule table of the persistent paths, the cluster path's exchange buffers and status word
+        case 0: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 2) + cluster_sync_bytes(B);
         // MF: measured-amplitude ping-pong + noise carry; Langevin: c' (+ one spare state); both: the cluster
         // path's exchange buffers, status word and counters
-        case 1: return 3 * state + qs + table_bytes() + cluster_exchange_bytes(B, N) + cluster_sync_bytes(B);
-        case 2: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N) + cluster_sync_bytes(B);
+        case 1: return 3 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
+        case 2: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
         case 5: return qs;                               // ccvm_feedback
@@ -331,7 +333,7 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
 }
 
 size_t ccvm_status_offset(int solver, int B, int N) {
-    if (solver != 1 && solver != 2) return (size_t)-1;
+    if (solver < 0 || solver > 2) return (size_t)-1;
     return ccvm_workspace_bytes(solver, B, N) - cluster_sync_bytes(B);
 }
 
@@ -359,7 +361,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
-    if (solver != 0 && !want_persist(N, tun) && want_cluster(B, N, tun)) {
+    if (!want_persist(N, tun) && want_cluster(B, N, tun, solver == 0 ? 2 : 1)) {
         const int G = (N + CL_COLS - 1) / CL_COLS;
         std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups), up to %d steps per launch",
                       solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B) + 7) / 8 * 8 * G, cluster_count(B), G,
@@ -456,6 +458,31 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 pa.w1 = nz->w1 + (size_t)done * N * B;
             }
             if ((rc = launch_persist<MODE_DL, false>(pa, st, fn))) return rc;
+        }
+        return CCVM_OK;
+    }
+    if (nsteps > 0 && want_cluster(B, N, tun, 2)) {
+        // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
+        char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        ClusterArgs ca;
+        if (cluster_base(ca, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, 2))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        ca.x0 = c; ca.x1 = s;
+        ca.in_scale = a.in_scale; ca.in_shift = a.in_shift;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
+                       step0 + done, k};
+            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            ca.step0 = step0 + done;
+            ca.nsteps = k;
+            if (ca.replay) {
+                ca.w0 = nz->w0 + (size_t)done * N * B;
+                ca.w1 = nz->w1 + (size_t)done * N * B;
+            }
+            cluster_launch_dl(ca, st);
+            CCVM_CHECK_LAUNCH(fn);
         }
         return CCVM_OK;
     }

@@ -76,15 +76,16 @@ struct ClusterArgs {
     const float* Q;      // [ld][ld] (the row-scaled copy with a per-variable saturation)
     const float* V;
     const float* qsum;
-    float* x0;           // Langevin: c;  MF: mu        (pitched, in/out; owner-only data)
-    float* x1;           // MF: sigma
+    float* x0;           // DL, Langevin: c;  MF: mu   (pitched, in/out; owner-only data)
+    float* x1;           // DL: s;  MF: sigma
     float* xt;           // MF: measured amplitude fed to the LAST step of this launch (out, may be NULL)
-    float* xb0;          // exchange buffers: GEMM input of even / odd steps, [clusters * 32 rows][ld] packets
-    float* xb1;          //   {value, tag}; zeroed by the host before the call (tags are global step numbers)
+    float* xb0;          // exchange buffers: GEMM input of even / odd steps, [clusters][planes][32 rows][ld] packets
+    float* xb1;          //   {value, tag} (planes: DL c and s, else one); zeroed by the host before the call
     float* am;           // Adam moments (in/out)
     float* av;
     const float* table;  // [nsteps][TABLE_WORDS] schedule rows (the persistent kernel's tables)
     const float* w0;     // REPLAY noise for the chunk: [nsteps][N][B]
+    const float* w1;     // DL: the second Wiener stream
     unsigned* status;    // 0 = ok; set to 1 when a bounded spin gave up
     unsigned long long* dbg;  // ablation stamps only: [grid][16]
     uint64_t seed;
@@ -102,7 +103,8 @@ struct ClusterArgs {
 
 // Ablation bits for tools/cluster_ablate.hip (0 in the product; timing only, results are wrong): 1 no MFMA,
 // 2 no noise, 8 no exchange (no loads, no tag checks, no publish), 32 no LDS operand reads, 64 s_memtime stamps:
-// a.dbg[block][0..2] MFMA wave 0: waiting at B_0, first operand read + chunks, update + publish;
+// a.dbg[block][0..7] MFMA wave 0: waiting at B_0, first operand read + chunks, update + publish, waiting at the inner
+// barriers (total; at B_1, B_2, B_3 and later), the publish stores;
 // [8..12] fetch wave 4: waiting at B_0, staging + inner barriers, load issue, waiting at the last barrier,
 // tag check + staging of the next phase's first chunks; [13] retry rounds.
 #ifndef CCVM_CLUSTER_ABL
@@ -110,6 +112,12 @@ struct ClusterArgs {
 #endif
 #ifndef CCVM_CL_SLEEP
 #define CCVM_CL_SLEEP 4
+#endif
+#ifndef CCVM_CL_FETCH_PRIO
+#define CCVM_CL_FETCH_PRIO 1
+#endif
+#ifndef CCVM_CL_STAGE_ASM
+#define CCVM_CL_STAGE_ASM 0
 #endif
 
 __device__ __forceinline__ unsigned long long cl_stamp() {
@@ -129,9 +137,13 @@ typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 // noise hipcc guards the registers they share with s_waitcnt vmcnt(0) in BOTH paths.
 template <int MODE, bool ADAM, int KCH, bool REPLAY>
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
-    static_assert(MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: one-stream solvers");
+    static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: solver loops only");
+    static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant");
     static_assert(KCH == 3 || KCH == 4, "K = 384 or 512");
     constexpr int K = KCH * CL_KC;
+    // DL contracts two input planes (c, then s) against the same panel: 2 KCH chunks per phase, two accumulator sets
+    constexpr int NPL = (MODE == MODE_DL) ? 2 : 1;
+    constexpr int NC = NPL * KCH;
     constexpr int QS = 512 + 4;             // panel row stride (floats): == 4 (mod 32); a 128-float block per lane group
     constexpr int AS = CL_KC + 4;           // A chunk row stride (floats): == 1 slot (mod 16)
     constexpr int ABUF = CL_ROWS * AS + 4;
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     const int N = a.N, ld = a.ld;
     const int col0 = member * CL_COLS;
     const int crow0 = cluster * 2 * CL_ROWS;       // first batch row of the cluster
+    const int xrow0 = crow0 * NPL;                 // its first row in the exchange buffers: + 32 plane + 16 set + row
     const int nphases = 2 * a.nsteps;              // phase P: step P / 2 of the launch, row set P % 2
     if (tid == 0) lds[DEAD] = 0.0f;
 
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         for (int k = kk; k < K; k += CL_THREADS / 64) qp[c * QS + kpos(k)] = a.Q[(size_t)k * ld + col0 + c];
     }
     // buffer descriptors of the two exchange buffers (wave-uniform: kernel arguments only)
-    const size_t xbytes = (size_t)(a.nclusters * 2 * CL_ROWS) * ld * CL_XE;
+    const size_t xbytes = (size_t)(a.nclusters * 2 * CL_ROWS * NPL) * ld * CL_XE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.xb0, 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.xb1, 0, (int)xbytes, 0x00020000);
     constexpr int SC1 = 16;  // aux bits of the buffer builtins: sc1
@@ -189,48 +202,75 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         // =============================== fetch waves =====================================================
         // piece j (0, 1) of a chunk: row hr + 8 j, floats 4 hq .. 4 hq + 3 of the chunk's 128 = two 16-byte loads
         // {x0, tag, x1, tag}, {x2, tag, x3, tag}
+        // a little above the MFMA waves: a fetch wave's few instructions go first when both are ready (DL N = 500:
+        // 10.9 -> 10.4 us / step, Langevin 5.13 -> 4.93; priorities 1 and 3 measure the same)
+        __builtin_amdgcn_s_setprio(CCVM_CL_FETCH_PRIO);
         const int ht = tid - 256, hr = ht >> 5, hq = ht & 31;
-        const unsigned ld_off = (unsigned)(((size_t)(crow0 + hr) * ld + 4 * hq) * CL_XE);
-        // the columns >= 64 G of the last chunk are never published: their tags are ignored, their values stay 0
+        const unsigned ld_off = (unsigned)(((size_t)(xrow0 + hr) * ld + 4 * hq) * CL_XE);
+        // the columns >= 64 G of a plane's last chunk are never published: their tags are ignored, their values stay 0
         const unsigned pad_tag = (CL_KC * (KCH - 1) + 4 * hq >= CL_COLS * G) ? 0xFFFFFFFFu : 0u;
-        float* const st0 = abuf + rowpos(hr) * AS + 4 * hq;
-        float* const st1 = abuf + rowpos(hr + 8) * AS + 4 * hq;
-        u32x4c w[KCH][2][2];
-        unsigned long long hseg[6] = {0, 0, 0, 0, 0, 0};
-        // the loads of chunks [C0, C1) of set s's input in buffer `par`
-        auto load_a = [&](int s, int par, auto c0_tag, auto c1_tag) {
-            if constexpr (NO_XCHG) return;
-            constexpr int C0 = decltype(c0_tag)::value, C1 = decltype(c1_tag)::value;
+        // The fetch waves' VALU instructions are the expensive ones: next to a wave that issues MFMAs back to back a
+        // sibling's VALU instruction gets a slot about once per MFMA (~32 cycles; stamps: 60 of them took 1900
+        // cycles), so staging and checking must not need any beyond the tag minima: staging addresses are
+        // registers per (buffer, piece) selected at compile time (the phase loop is unrolled over the ring's
+        // period), values go to LDS with ds_write2_b32 straight from the loaded {x, tag, x, tag} registers.
+        typedef __attribute__((address_space(3))) float lds_float;
+        unsigned stb[3][2];  // LDS byte addresses
 #pragma unroll
-            for (int c = C0; c < C1; ++c)
+        for (int bf = 0; bf < 3; ++bf) {
+            stb[bf][0] = (unsigned)(size_t)(lds_float*)(abuf + bf * ABUF + rowpos(hr) * AS + 4 * hq);
+            stb[bf][1] = (unsigned)(size_t)(lds_float*)(abuf + bf * ABUF + rowpos(hr + 8) * AS + 4 * hq);
+        }
+        // the compiler does not track the inline-asm LDS writes: every barrier of the fetch waves drains them itself
+        auto fetch_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        u32x4c w[NC][2][2];  // chunk cc of a phase = chunk cc % KCH of plane cc / KCH
+        unsigned long long hseg[6] = {0, 0, 0, 0, 0, 0};
+        // An input travels in PAIRS of chunks (8 loads per wave): never more loads between two barriers than the MFMA
+        // waves' chunk covers -- issuing a whole input at once (16 loads per wave, 64 KB per workgroup at the
+        // texture path's 64 B/clk) held the fetch waves ~1800 cycles and the MFMA waves waited for them at the next
+        // barrier.  Pair k = chunks [2 k, min(2 k + 2, NC)).
+        constexpr int NPAIR = (NC + 1) / 2;
+        auto load_pair = [&](int s, int par, auto k_tag) {
+            if constexpr (NO_XCHG) return;
+            constexpr int C0 = 2 * decltype(k_tag)::value, C1 = (C0 + 2 < NC) ? C0 + 2 : NC;
+#pragma unroll
+            for (int cc = C0; cc < C1; ++cc)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        w[c][j][h] = __builtin_amdgcn_raw_buffer_load_b128(
-                            par ? rs1 : rs0, ld_off, ((CL_ROWS * s + 8 * j) * ld + CL_KC * c + 2 * h) * CL_XE, SC1);
+                        w[cc][j][h] = __builtin_amdgcn_raw_buffer_load_b128(
+                            par ? rs1 : rs0, ld_off,
+                            ((2 * CL_ROWS * (cc / KCH) + CL_ROWS * s + 8 * j) * ld + CL_KC * (cc % KCH) + 2 * h) * CL_XE, SC1);
         };
-        auto arrived = [&](unsigned want, auto c0_tag, auto c1_tag) {
-            constexpr int C0 = decltype(c0_tag)::value, C1 = decltype(c1_tag)::value;
-            unsigned lo = 0xFFFFFFFFu;
+        auto arrived = [&](unsigned want, auto k_tag) {
+            constexpr int C0 = 2 * decltype(k_tag)::value, C1 = (C0 + 2 < NC) ? C0 + 2 : NC;
+            unsigned lo = 0xFFFFFFFFu, lo_pad = 0xFFFFFFFFu;  // tags of full chunks / of a plane's last chunk
 #pragma unroll
-            for (int c = C0; c < C1; ++c)
+            for (int cc = C0; cc < C1; ++cc)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const unsigned t0 = w[c][j][h][1], t1 = w[c][j][h][3];
-                        lo = (c == KCH - 1) ? min(lo, min(t0 | pad_tag, t1 | pad_tag)) : min(lo, min(t0, t1));
+                        const unsigned t0 = w[cc][j][h][1], t1 = w[cc][j][h][3];
+                        // one v_min3_u32 per packet (left to itself hipcc builds a tree of v_min_u32 + v_min3_u32,
+                        // half as many instructions again)
+                        if (cc % KCH == KCH - 1) asm("v_min3_u32 %0, %1, %2, %3" : "=v"(lo_pad) : "v"(lo_pad), "v"(t0), "v"(t1));
+                        else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(t0), "v"(t1));
                     }
+            lo = min(lo, lo_pad | pad_tag);
             // (a lane whose pieces are all padding keeps lo = ~0)
             return __builtin_amdgcn_ballot_w64(lo != want && lo != 0xFFFFFFFFu) == 0;
         };
-        // wait (bounded) until chunks [C0, C1) of input `want` of set s are complete in w
-        auto await_a = [&](int s, int par, unsigned want, auto c0_tag, auto c1_tag) {
+        // wait (bounded) until pair k of input `want` of set s is complete in w
+        auto await_pair = [&](int s, int par, unsigned want, auto k_tag) {
             if constexpr (NO_XCHG) return;
             // the first check stands alone: straight-line code whose wait counts leave the younger loads (the
-            // input's other group) in flight; the merged counts of a loop header would wait for everything
-            if (__builtin_expect(arrived(want, c0_tag, c1_tag), 1)) return;
+            // input's other pairs) in flight; the merged counts of a loop header would wait for everything
+            if (__builtin_expect(arrived(want, k_tag), 1)) return;
             unsigned spins = 0;
 #pragma nounroll
             do {
@@ -243,60 +283,81 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     break;
                 }
                 __builtin_amdgcn_s_sleep(CCVM_CL_SLEEP);
-                load_a(s, par, c0_tag, c1_tag);
-            } while (!arrived(want, c0_tag, c1_tag));
+                load_pair(s, par, k_tag);
+            } while (!arrived(want, k_tag));
         };
-        auto stage = [&](int c, int buf) {  // chunk c of the input in w -> A buffer buf
+        auto stage = [&](int cc, int buf) {  // chunk cc of the input in w -> A buffer buf (both compile-time after unrolling)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const u32x4c lo = w[c][j][0], hi = w[c][j][1];
-                const u32x4c x = {lo[0], lo[2], hi[0], hi[2]};
-                *reinterpret_cast<f32x4c*>((j ? st1 : st0) + buf * ABUF) = __builtin_bit_cast(f32x4c, x);
+#if CCVM_CL_STAGE_ASM
+                // (hipcc turns four scalar stores into v_mov x 4 + ds_write_b128: hence the asm)
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3"
+                             :: "v"(stb[buf][j]), "v"(w[cc][j][0][0]), "v"(w[cc][j][0][2]), "v"(w[cc][j][1][0]),
+                                "v"(w[cc][j][1][2]) : "memory");
+#else
+                const u32x4c x = {w[cc][j][0][0], w[cc][j][0][2], w[cc][j][1][0], w[cc][j][1][2]};
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4c*>(stb[buf][j]) = x;
+#endif
             }
         };
-        // An input travels in two groups: chunks {0, 1} (needed before the phase starts) and {2 ..} (needed one and
-        // two barriers into it).  Never more loads between two barriers than the MFMA waves' chunk covers: issuing
-        // a whole input at once (16 loads per wave, 64 KB per workgroup at the texture path's 64 B/clk) held the
-        // fetch waves ~1800 cycles and the MFMA waves waited for them at the next barrier.
-        constexpr std::integral_constant<int, 0> c_0{};
-        constexpr std::integral_constant<int, 2> c_2{};
-        constexpr std::integral_constant<int, KCH> c_end{};
 
-        // first input: whatever has not landed yet (the peers may not even run yet) is fetched again by await_a
-        load_a(0, 0, c_0, c_2);
-        load_a(0, 0, c_2, c_end);
-        await_a(0, 0, (unsigned)a.step0 + 1u, c_0, c_2);
+        // first input: whatever has not landed yet (the peers may not even run yet) is fetched again by await_pair
+        unroll_indices([&](auto k_tag) { load_pair(0, 0, k_tag); }, std::make_integer_sequence<int, NPAIR>{});
+        await_pair(0, 0, (unsigned)a.step0 + 1u, std::integral_constant<int, 0>{});
         stage(0, 0);
         stage(1, 1);
-        int b0 = 0;  // buffer of chunk 0 of the current phase
+        // Pair k of the NEXT phase's input is requested behind barrier B_(L0 + k): its peers stored it at the end of
+        // their previous phase, >= L0 chunks ago, and its registers are free (this phase's chunks 2 k, 2 k + 1 were
+        // staged behind B_(2 k - 2), B_(2 k - 1)).
+        constexpr int L0 = (NC == 3) ? 1 : 2;
         if constexpr (CCVM_CLUSTER_ABL & 64) t_last = cl_stamp();
-        for (int P = 0; P < nphases; ++P) {
-            __syncthreads();  // B_0: chunks 0, 1 of this phase are staged
-            if (lds[DEAD] != 0.0f) return;
-            mark(hseg[0]);
-            // the rest of this phase's input: issued behind the last barrier of the previous phase
-            await_a(P & 1, (P >> 1) & 1, (unsigned)(a.step0 + (P >> 1)) + 1u, c_2, c_end);
-#pragma unroll
-            for (int c = 2; c < KCH; ++c) {
-                stage(c, (b0 + c) % 3);   // buffer of chunk c - 3 of the launch: done before B_(c-2)
-                __syncthreads();          // B_(c-1)
-            }
-            mark(hseg[1]);
+        bool dead = false;
+        // one phase; B0 = buffer of its chunk 0 (compile time)
+        auto phase = [&](int P, auto b0_tag) {
+            constexpr int B0 = decltype(b0_tag)::value;
+            const int cs = P & 1, cpar = (P >> 1) & 1;          // this phase's set and exchange buffer
+            const unsigned cwant = (unsigned)(a.step0 + (P >> 1)) + 1u;
             const bool next = P + 1 < nphases;
-            const int ns = (P + 1) & 1, nj = (P + 1) >> 1;  // the next phase's set and input number
-            // the peers stored it at the end of their previous phase, KCH - 1 chunks ago
-            if (next) load_a(ns, nj & 1, c_0, c_2);
-            mark(hseg[2]);
-            __syncthreads();  // B_(KCH-1)
-            mark(hseg[3]);
-            b0 = (b0 + KCH) % 3;
-            if (next) {
-                load_a(ns, nj & 1, c_2, c_end);
-                await_a(ns, nj & 1, (unsigned)(a.step0 + nj) + 1u, c_0, c_2);
-                stage(0, b0);             // buffers of chunks KCH-3, KCH-2 of this phase: done before B_(KCH-1)
-                stage(1, (b0 + 1) % 3);
-            }
-            mark(hseg[4]);
+            const int ns = (P + 1) & 1, nj = (P + 1) >> 1;      // the next phase's set and input number
+            const unsigned nwant = (unsigned)(a.step0 + nj) + 1u;
+            unroll_indices([&](auto c_tag) {
+                constexpr int c = decltype(c_tag)::value;
+                if (dead) return;
+                fetch_barrier();  // B_c.  B_0: chunks 0, 1 of this phase are staged
+                if constexpr (c == 0) {
+                    if (lds[DEAD] != 0.0f) { dead = true; return; }
+                    mark(hseg[0]);
+                }
+                if constexpr (c + 2 < NC) {
+                    // chunk c + 2 into the buffer of chunk c - 1 (done: every MFMA wave is past B_c)
+                    if constexpr (c % 2 == 0) await_pair(cs, cpar, cwant, std::integral_constant<int, (c + 2) / 2>{});
+                    stage(c + 2, (B0 + c + 2) % 3);
+                }
+                if constexpr (c >= L0 && c - L0 < NPAIR) {
+                    // unconditional (behind the last phase it fetches packets nobody looks at): with a branch around
+                    // the loads the wait counts of the tag checks that follow must assume the shorter path and
+                    // would wait for these very loads
+                    load_pair(ns, nj & 1, std::integral_constant<int, c - L0>{});
+                }
+                if constexpr (c == NC - 1) {
+                    mark(hseg[1]);
+                    if (next) {
+                        await_pair(ns, nj & 1, nwant, std::integral_constant<int, 0>{});
+                        stage(0, (B0 + NC) % 3);      // buffers of chunks NC-3, NC-2 of this phase: done before B_(NC-1)
+                        stage(1, (B0 + NC + 1) % 3);
+                    }
+                    mark(hseg[4]);
+                }
+            }, std::make_integer_sequence<int, NC>{});
+        };
+        // the ring's period: chunk 0 of phase P sits in buffer (NC P) % 3
+        for (int P = 0;;) {
+            phase(P, std::integral_constant<int, 0>{});
+            if (dead || ++P >= nphases) break;
+            phase(P, std::integral_constant<int, NC % 3>{});
+            if (dead || ++P >= nphases) break;
+            phase(P, std::integral_constant<int, (2 * NC) % 3>{});
+            if (dead || ++P >= nphases) break;
         }
         if constexpr (CCVM_CLUSTER_ABL & 64) {
             if (tid == 256)
@@ -328,7 +389,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             ok[s][i] = col_ok && brow[s][i] < a.B;
             gidx[s][i] = (size_t)brow[s][i] * ld + col;  // inside the padded arrays for every lane
             s0[s][i] = a.x0[gidx[s][i]];
-            s1[s][i] = (MODE == MODE_MF) ? a.x1[gidx[s][i]] : 0.0f;
+            s1[s][i] = (MODE != MODE_LANGEVIN) ? a.x1[gidx[s][i]] : 0.0f;
             mt[s][i] = wc[s][i] = am[s][i] = av[s][i] = 0.0f;
             if constexpr (ADAM) {
                 am[s][i] = a.am[gidx[s][i]];
@@ -352,16 +413,39 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
     };
 
+    // DL: the (W_c, W_s) pairs of this lane's four elements of set s
+    auto pair_normals = [&](int s, int step, int it, float* n0, float* n1) {
+        if constexpr (CCVM_CLUSTER_ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) n0[i] = n1[i] = 0.25f;
+        } else if constexpr (REPLAY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t wi = ((size_t)it * N + col) * a.B + brow[s][i];
+                n0[i] = ok[s][i] ? a.w0[wi] : 0.0f;
+                n1[i] = ok[s][i] ? a.w1[wi] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {  // two generator calls in lockstep
+                NormalPair pa, pb;
+                normal_pair_x2(a.seed, a.row_offset + brow[s][i], a.row_offset + brow[s][i + 1], step, col, pa, pb);
+                n0[i] = pa.n0; n1[i] = pa.n1; n0[i + 1] = pb.n0; n1[i + 1] = pb.n1;
+            }
+        }
+    };
+
     // Publish set s's new GEMM input x[i] (rows 4 g + i, column col) with tag `tag` into exchange buffer `par`: this
     // lane's elements are its own 8-byte packets; a store instruction writes 4 rows x 16 columns x 8 bytes = four
     // whole 128-byte lines.  Never waited for.
-    const unsigned pub_off = (unsigned)(((size_t)(crow0 + 4 * g) * ld + col) * CL_XE);
-    auto publish = [&](int s, int par, const float (&x)[4], unsigned tag) {
+    const unsigned pub_off = (unsigned)(((size_t)(xrow0 + 4 * g) * ld + col) * CL_XE);
+    auto publish = [&](int s, int par, const float (&x)[4], unsigned tag, int plane = 0) {
         if constexpr (NO_XCHG) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32x2c v = {__builtin_bit_cast(unsigned, ok[s][i] ? x[i] : 0.0f), tag};
-            __builtin_amdgcn_raw_buffer_store_b64(v, par ? rs1 : rs0, pub_off, (CL_ROWS * s + i) * ld * CL_XE, SC1);
+            __builtin_amdgcn_raw_buffer_store_b64(v, par ? rs1 : rs0, pub_off,
+                                                  (2 * CL_ROWS * plane + CL_ROWS * s + i) * ld * CL_XE, SC1);
         }
     };
 
@@ -378,6 +462,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             publish(s, 0, mt[s], (unsigned)a.step0 + 1u);
         } else {
             publish(s, 0, s0[s], (unsigned)a.step0 + 1u);
+            if constexpr (MODE == MODE_DL) publish(s, 0, s1[s], (unsigned)a.step0 + 1u, 1);
         }
     }
 
@@ -396,7 +481,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
 
     struct Row { float w[TABLE_WORDS]; };
     Row rnext = *reinterpret_cast<const Row*>(a.table);
-    unsigned long long seg[3] = {0, 0, 0};
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int b0 = 0;  // buffer of chunk 0 of the current phase
     if constexpr (CCVM_CLUSTER_ABL & 64) t_last = cl_stamp();
 
@@ -413,19 +498,22 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             mark(seg[0]);
             // chunk c of this phase sits in buffer (b0 + c) % 3
             const float* const ab[3] = {a_rd + b0 * ABUF, a_rd + ((b0 + 1) % 3) * ABUF, a_rd + ((b0 + 2) % 3) * ABUF};
-            b0 = (b0 + KCH) % 3;
+            b0 = (b0 + NC) % 3;
 
-            // ---- acc = X[set rows][:] @ Q[:, this wave's 16 columns] ------------------------------------
-            f32x4c acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            // ---- acc[plane] = X_plane[set rows][:] @ Q[:, this wave's 16 columns] ------------------------
+            f32x4c acc[NPL][2];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) acc[pl][0] = acc[pl][1] = f32x4c{0.0f, 0.0f, 0.0f, 0.0f};
             float aq[2][32];
             __builtin_amdgcn_sched_barrier(0);
-            read_ops(aq[(KCH * s) & 1], ab[0]);  // chunk 0: the one exposed LDS latency
+            read_ops(aq[(NC * s) & 1], ab[0]);  // chunk 0: the one exposed LDS latency
             __builtin_amdgcn_sched_barrier(0);
             unroll_indices([&](auto c_tag) {
-                constexpr int c = decltype(c_tag)::value;
-                // operand double buffer: chunk n of the iteration (n = KCH s + c) computes from [n & 1] (s is a
-                // constant after unrolling; 2 KCH flips per iteration bring the first chunk back to [0])
-                const int cb = (KCH * s + c) & 1, nb = cb ^ 1;
+                constexpr int c = decltype(c_tag)::value;  // chunk c % KCH of plane c / KCH
+                constexpr int pl = c / KCH;
+                // operand double buffer: chunk n of the iteration (n = NC s + c) computes from [n & 1] (s is a
+                // constant after unrolling; 2 NC flips per iteration bring the first chunk back to [0])
+                const int cb = (NC * s + c) & 1, nb = cb ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 32; ++m) {
@@ -436,7 +524,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                         if (m % 4 == 0) {  // one b128 per operand and four MFMAs
                             const f32x4c vb = *reinterpret_cast<const f32x4c*>(b_rd + 32 * ((c + 1) % KCH) + m);
                             bq[nb][m] = vb[0]; bq[nb][m + 1] = vb[1]; bq[nb][m + 2] = vb[2]; bq[nb][m + 3] = vb[3];
-                            if constexpr (c + 1 < KCH) {
+                            if constexpr (c + 1 < NC) {
                                 const f32x4c va = *reinterpret_cast<const f32x4c*>(ab[(c + 1) % 3] + m);
                                 aq[nb][m] = va[0]; aq[nb][m + 1] = va[1]; aq[nb][m + 2] = va[2]; aq[nb][m + 3] = va[3];
                             }
@@ -446,13 +534,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                         aq[nb][m] = aq[cb][m];
                     }
                     if constexpr (CCVM_CLUSTER_ABL & 1) {
-                        acc0[m & 3] += aq[cb][m] * bq[cb][m];  // keeps the operands live
+                        acc[pl][0][m & 3] += aq[cb][m] * bq[cb][m];  // keeps the operands live
                     } else {
-                        if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bq[cb][m], acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bq[cb][m], acc0, 0, 0, 0);
+                        acc[pl][m & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bq[cb][m], acc[pl][m & 1], 0, 0, 0);
                     }
                 }
-                constexpr int NRD = (c + 1 < KCH) ? 2 : 1;  // next chunk's operand reads per four MFMAs
+                constexpr int NRD = (c + 1 < NC) ? 2 : 1;  // next chunk's operand reads per four MFMAs
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
@@ -460,19 +547,32 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // 3 MFMAs
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (c + 1 < KCH) __syncthreads();  // B_(c+1): chunk c's buffer may be refilled; chunk c + 2 is staged
-            }, std::make_integer_sequence<int, KCH>{});
+                if constexpr (c + 1 < NC) {
+                    mark(seg[1]);
+                    __syncthreads();  // B_(c+1): chunk c's buffer may be refilled; chunk c + 2 is staged
+                    if constexpr (CCVM_CLUSTER_ABL & 64) {
+                        const unsigned long long before = t_last;
+                        mark(seg[3]);
+                        seg[(c < 2) ? 4 + c : 6] += t_last - before;
+                    }
+                }
+            }, std::make_integer_sequence<int, NC>{});
             mark(seg[1]);
             // ---- this step's / the next step's normals -------------------------------------------
-            float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (MODE == MODE_MF) {
+            float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nz1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (MODE == MODE_DL) {
+                pair_normals(s, step, it, nz, nz1);
+            } else if constexpr (MODE == MODE_MF) {
                 if (has_next) stream_normals(s, step + 1, it + 1, nz);
             } else {
                 stream_normals(s, step, it, nz);
             }
-            float qx[4];
+            float qx[4], qx1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qx[i] = __builtin_fmaf(a.in_scale, acc0[i] + acc1[i], shift_j);
+            for (int i = 0; i < 4; ++i) {
+                qx[i] = __builtin_fmaf(a.in_scale, acc[0][0][i] + acc[0][1][i], shift_j);
+                qx1[i] = __builtin_fmaf(a.in_scale, acc[NPL - 1][0][i] + acc[NPL - 1][1][i], shift_j);
+            }
 
             AdamScalars ad;
             if constexpr (ADAM) {
@@ -493,7 +593,20 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             };
 
             // ---- update (pinned arithmetic of ccvm_common.h) ---------------------------------------------
-            if constexpr (MODE == MODE_MF) {
+            if constexpr (MODE == MODE_DL) {
+                const DlScalars k = *reinterpret_cast<const DlScalars*>(trow);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float cn, sn;
+                    dl_update(k, s0[s][i], s1[s][i], qx[i], qx1[i], vj, nz[i], nz1[i], cn, sn);
+                    s0[s][i] = cn;  // lanes outside B x N carry don't-care values: never published (0) nor written back
+                    s1[s][i] = sn;
+                }
+                const unsigned tag = has_next ? (unsigned)step + 2u : 0u;
+                mark(seg[2]);
+                publish(s, (it + 1) & 1, s0[s], tag);
+                publish(s, (it + 1) & 1, s1[s], tag, 1);
+            } else if constexpr (MODE == MODE_MF) {
                 const MfScalars k = *reinterpret_cast<const MfScalars*>(trow);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -510,6 +623,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                 }
                 // published every step (no branch around the stores); after the last step with tag 0, which nobody
                 // waits for
+                mark(seg[2]);
                 publish(s, (it + 1) & 1, mt[s], has_next ? (unsigned)step + 2u : 0u);
             } else {
                 const LvScalars k = *reinterpret_cast<const LvScalars*>(trow);
@@ -518,15 +632,16 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     const float gr = adam(__builtin_fmaf(k.g_q, qx[i], k.g_v * vj) * inv_sat_j, i);
                     s0[s][i] = lv_update(k, s0[s][i], gr, nz[i], a.s_cols ? sat_j : k.S);
                 }
+                mark(seg[2]);
                 publish(s, (it + 1) & 1, s0[s], has_next ? (unsigned)step + 2u : 0u);
             }
-            mark(seg[2]);
+            mark(seg[7]);
         }
     }
 
     if constexpr (CCVM_CLUSTER_ABL & 64) {
         if (tid == 0)
-            for (int k = 0; k < 3; ++k) a.dbg[(size_t)blockIdx.x * 16 + k] = seg[k];
+            for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 16 + k] = seg[k];
     }
     // ---- write the state back (owner-only data: plain stores) ---------------------------------------
 #pragma unroll
@@ -535,6 +650,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         for (int i = 0; i < 4; ++i) {
             if (!ok[s][i]) continue;
             a.x0[gidx[s][i]] = s0[s][i];
+            if constexpr (MODE == MODE_DL) a.x1[gidx[s][i]] = s1[s][i];
             if constexpr (MODE == MODE_MF) {
                 a.x1[gidx[s][i]] = s1[s][i];
                 if (a.xt) a.xt[gidx[s][i]] = mt[s][i];
@@ -546,6 +662,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
 }
 
+void cluster_launch_dl(const ClusterArgs& a, hipStream_t st);
 void cluster_launch_mf(const ClusterArgs& a, bool adam, hipStream_t st);
 void cluster_launch_lv(const ClusterArgs& a, bool adam, hipStream_t st);
 
@@ -558,7 +675,10 @@ void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
 template <int MODE>
 void launch_cluster(const ClusterArgs& a, bool adam, hipStream_t st) {
     const int grid = ((a.nclusters + 7) / 8) * 8 * a.G;
-    if (adam) {
+    if constexpr (MODE == MODE_DL) {
+        if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
+        else launch_cluster_variant<MODE, false, false>(a, grid, st);
+    } else if (adam) {
         if (a.replay) launch_cluster_variant<MODE, true, true>(a, grid, st);
         else launch_cluster_variant<MODE, true, false>(a, grid, st);
     } else {

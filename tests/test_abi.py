@@ -49,18 +49,20 @@ def test_layout_helpers_and_version(hip_lib):
     qs = 33 * 1024 * 4  # column sums of Q + 32 slice partials
     table = 4096 * 16 * 4  # schedule table of the persistent small-N path
     sync = 128  # the cluster path's launch status word (its own 128-byte line), last in the workspace
-    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table
+    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table + sync
     assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs + table + sync
     assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == 2 * state + qs + table + sync
     assert hip_lib.ccvm_status_offset(1, 1000, 1000) == 3 * state + qs + table
     assert hip_lib.ccvm_status_offset(2, 1000, 1000) == 2 * state + qs + table
-    assert hip_lib.ccvm_status_offset(0, 1000, 1000) == ctypes.c_size_t(-1).value
+    assert hip_lib.ccvm_status_offset(0, 1000, 1000) == 2 * state + qs + table
+    assert hip_lib.ccvm_status_offset(3, 1000, 1000) == ctypes.c_size_t(-1).value
     # 256 < N <= 512: + the cluster path's two exchange buffers of 8-byte {value, tag} packets
     state5, qs5 = 1024 * 512 * 4, 33 * 512 * 4
     xchg = 2 * 32 * 32 * 512 * 8
     assert hip_lib.ccvm_workspace_bytes(2, 1000, 500) == 2 * state5 + qs5 + table + xchg + sync
     assert hip_lib.ccvm_workspace_bytes(1, 1000, 500) == 3 * state5 + qs5 + table + xchg + sync
     assert hip_lib.ccvm_status_offset(2, 1000, 500) == 2 * state5 + qs5 + table + xchg
+    assert hip_lib.ccvm_workspace_bytes(0, 1000, 500) == 2 * state5 + qs5 + table + 2 * xchg + sync  # DL: c and s planes
     assert hip_lib.ccvm_workspace_bytes(3, 1000, 1000) == 32 * 1024 * 4
     assert hip_lib.ccvm_workspace_bytes(4, 1000, 1000) == 2 * state
     assert hip_lib.ccvm_workspace_bytes(5, 1000, 1000) == qs

@@ -1,6 +1,6 @@
 """GPU tests of the column-cluster persistent kernel (ccvm_amd/csrc/ccvm_cluster.h): 256 < N <= 512,
-MF / Langevin / pumped Langevin and their Adam variants, whole chunks of steps in one launch with the
-cluster's workgroups exchanging the GEMM input through sc1 stores / loads and one counter per step.
+DL / MF / Langevin / pumped Langevin and the Adam variants, whole chunks of steps in one launch with the
+cluster's workgroups exchanging the GEMM input as {value, tag} packets through sc1 stores / loads.
 
 Every word of every trajectory is compared with the oracle (fused noise through oracle/noise_ref.py),
 over enough steps that a single stale exchange read would be amplified into a visible difference, on
@@ -33,7 +33,9 @@ def _run_engine(kind, n, b, t, adam, seed, row_offset, chunks=None, replay_gener
     p = dict(EXAMPLE_PARAMS[kind])
     noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=row_offset)
     prob = engine.DeviceProblem(q, v)
-    if kind == "mf":
+    if kind == "dl":
+        traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)
+    elif kind == "mf":
         traj = engine.Trajectories(prob, b, "mf", t, dict(p, g=0.01), (0.0, 1.0), noise, adam=adam)
     else:
         traj = engine.Trajectories(prob, b, "langevin", t, dict(p, use_pump=kind == "pl"), (0.0, 1.0), noise, adam=adam)
@@ -49,7 +51,11 @@ def _run_oracle(kind, n, b, t, adam, seed, row_offset):
 
     q, v, _ = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
-    ref_noise = FusedNoise(seed, row_offset, single=True)
+    ref_noise = FusedNoise(seed, row_offset, single=kind != "dl")
+    if kind == "dl":
+        c, s = oracle.dl_loop(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05, (0.0, 1.0),
+                              True, ref_noise)
+        return [("c", c), ("s", s)]
     if kind == "mf":
         mu, mu_tilde, sigma = oracle.mf_loop(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], 0.01,
                                              (0.0, 1.0), True, adam, ref_noise)
@@ -73,6 +79,9 @@ def _run_oracle(kind, n, b, t, adam, seed, row_offset):
     ("pl", 449, 32, 16, None), ("mf", 512, 256, 12, "first_moment_only"), ("pl", 512, 1, 12, None),
     # more workgroups than the chip holds at once: clusters run in dispatch order
     ("pl", 300, 5000, 8, None), ("mf", 500, 3000, 6, None),
+    # DL: two exchanged planes (c, s), 2 K / 128 chunks per phase
+    ("dl", 500, 1000, 40, None), ("dl", 257, 33, 30, None), ("dl", 320, 100, 24, None), ("dl", 384, 70, 20, None),
+    ("dl", 385, 64, 20, None), ("dl", 449, 129, 16, None), ("dl", 512, 1, 12, None), ("dl", 300, 5000, 8, None),
 ])
 def test_cluster_kernel_matches_oracle(cluster, kind, n, b, t, adam):
     hp = _ADAMS[adam]
@@ -104,12 +113,12 @@ def test_cluster_kernel_is_what_ran(cluster):
     assert not torch.equal(a, b_) and float((a - b_).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("kind", ["mf", "pl"])
+@pytest.mark.parametrize("kind", ["mf", "pl", "dl"])
 def test_cluster_chunking_and_sharding_are_exact(cluster, kind):
     """Chunked launches (evolution sampling, replay staging) and batch shards reproduce the one-launch,
     unsharded run bit for bit."""
     n, b, t = 300, 96, 30
-    adam = _ADAMS["add_assign"]
+    adam = None if kind == "dl" else _ADAMS["add_assign"]
     whole = _run_engine(kind, n, b, t, adam, 99, 0)
     parts = _run_engine(kind, n, b, t, adam, 99, 0, chunks=[1, 7, 2, 20])
     for name in whole.state:
@@ -120,16 +129,17 @@ def test_cluster_chunking_and_sharding_are_exact(cluster, kind):
         assert torch.equal(whole.compact(name), torch.cat([lo.compact(name), hi.compact(name)])), name
 
 
-@pytest.mark.parametrize("kind,post", [("mf", None), ("langevin", "adam"), ("pl", "grad-descent")])
+@pytest.mark.parametrize("kind,post", [("mf", None), ("langevin", "adam"), ("pl", "grad-descent"), ("dl", None),
+                                       ("dl", "adam")])
 def test_cluster_replay_mode_through_the_public_api(cluster, kind, post):
     """Replay noise (torch's CPU stream in the reference's order) through Solver.__call__ and the fused
     finalize, against the oracle's solve_* on the same seed."""
-    from ccvm_amd.solvers import LangevinSolver, MFSolver, PumpedLangevinSolver
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
     from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
     from oracle import ccvm_oracle as oracle
 
     n, b, t = 300, 70, 60
-    cls = {"mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
+    cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
     solver = cls(device="cpu", batch_size=b)
     solver.noise_mode = "replay"
     inst = synthetic_instance(n)
@@ -142,7 +152,10 @@ def test_cluster_replay_mode_through_the_public_api(cluster, kind, post):
     q, v, f = inst.q_matrix, inst.v_vector, float(inst.scaled_by)
     common = dict(scaled_by=f, optimal_value=1.0, post_processor=post)
     torch.manual_seed(31)
-    if kind == "mf":
+    if kind == "dl":
+        ref = oracle.solve_dl(q, v, b, t, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], g=0.05, S=1,
+                              **common)
+    elif kind == "mf":
         ref = oracle.solve_mf(q, v, b, t, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], g=0.01, **common)
     elif kind == "langevin":
         ref = oracle.solve_langevin(q, v, b, t, p["dt"], p["sigma"], p["feedback_scale"], p["S"], **common)
@@ -190,10 +203,10 @@ def test_status_word_is_checked_at_synchronisation_points(cluster):
         traj.score("c", 0.5, 1.0)
     dl = engine.Trajectories(traj.p, 8, "dl", 3, {"pump": 2.0, "dt": 0.001, "noise_ratio": 2.0, "feedback_scale": 1.0,
                                                    "g": 0.05}, (0.0, 1.0), engine.NoiseSpec(mode="fused", seed=1))
-    assert dl._status is None                        # DL has no cluster path: no status word
+    assert dl._status is not None                    # every solver's workspace carries the status word
 
 
-@pytest.mark.parametrize("kind,adam", [("langevin", None), ("mf", "second_moment")])
+@pytest.mark.parametrize("kind,adam", [("langevin", None), ("mf", "second_moment"), ("dl", None)])
 def test_cluster_soak_is_deterministic(cluster, kind, adam):
     """20 000 steps at the BASELINE config-3 shape, twice (one in 4096-step launches, one in ragged chunks):
     bit-identical and finite.  The exchange is the only cross-workgroup traffic in the engine: a single
