@@ -41,6 +41,7 @@ WORKLOADS = {
     # name: (solver kind, N, batch per GPU)
     "dl_n1000_b1000": ("dl", 1000, 1000),
     "dl_n100_b1000": ("dl", 100, 1000),
+    "dl_n500_b1000": ("dl", 500, 1000),      # not a BASELINE configuration: the DL solver at config 3's size
     "mf_n500_b1000": ("mf", 500, 1000),
     "langevin_n500_b1000": ("langevin", 500, 1000),
     "pl_n2000_b512": ("pl", 2000, 512),

@@ -164,9 +164,10 @@ static int run_case(int N, int B) {
             }
             REQUIRE(st.rows == B && st.nonfinite == 0 && st.best_objective_value == best);
             for (int k = 0; k < 7; ++k) REQUIRE(st.within[k] == want[k]);
-            // the run's status word (MF / Langevin workspaces): zeroed by the caller, still 0 after the run
+            // the run's status word (solver workspaces): zeroed by the caller, still 0 after the run
             const size_t off = ccvm_status_offset(2, B, N);
-            REQUIRE(off != (size_t)-1 && off + 4 <= wl.n * 4 && ccvm_status_offset(0, B, N) == (size_t)-1);
+            REQUIRE(off != (size_t)-1 && off + 4 <= wl.n * 4 && ccvm_status_offset(0, B, N) != (size_t)-1 &&
+                    ccvm_status_offset(3, B, N) == (size_t)-1);
             unsigned status = 7;
             hipMemcpy(&status, reinterpret_cast<char*>(wl.p) + off, 4, hipMemcpyDeviceToHost);
             REQUIRE(status == 0);
