@@ -241,12 +241,8 @@ bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.
 int cluster_count(int B) { return (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS); }
 // the launch status word (its own 128-byte line), last in the workspace
 size_t cluster_sync_bytes(int) { return 128; }
-// Default: only while every cluster is resident at once (<= 256 workgroups, one per CU: B <= 1024 at
-// N = 500).  There the launch-free time loop wins 10-13 % over the tile kernel (7.05 vs 8.15 us per step,
-// Langevin N = 500, B = 1000); with more clusters than CUs they run in rounds and the tile kernel's larger
-// tiles are the better use of the chip.
-// the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h, CCVM_CL_LL), one per
-// element of the clusters' rows; nothing at the sizes the cluster kernel does not serve
+// the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h), one per element of
+// the clusters' rows; nothing at the sizes the cluster kernel does not serve
 // (planes: DL exchanges c and s, the one-stream solvers one array)
 size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
@@ -255,7 +251,11 @@ size_t cluster_exchange_bytes(int B, int N, int planes) {
 bool want_cluster(int B, int N, const Tuning& tun, int planes = 1) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
-    if (tun.cluster < 0 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
+    // Default policy (us per step, N = 500, cluster vs tile kernel): B = 1000: Langevin 4.95 vs 8.15, MF 5.39 vs 8.31,
+    // DL 10.1 vs 13.1.  With more clusters than CUs they run in rounds of 256 workgroups: B = 2000 / 4000: Langevin
+    // 9.97 / 20.0 vs 11.5 / 21.1, MF 10.8 vs 13.0 -- still ahead; DL 20.2 / 40.5 vs 19.8 / 38.8 -- the tile kernel's
+    // larger tiles win, so DL takes the cluster path only while every cluster is resident at once.
+    if (tun.cluster < 0 && planes == 2 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:

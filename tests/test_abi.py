@@ -96,7 +96,8 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 500, 0): "ccvm::cluster_kernel<0, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 300, 0): "ccvm::cluster_kernel<0, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
-        (2, 4000, 500, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 500 x 512",
+        (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 1024 x 512 threads (125 clusters of 8 workgroups)",
+        (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",
         (1, 1000, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 160 x 512",
         (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",
     }
