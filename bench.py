@@ -100,8 +100,9 @@ def profiled_counters(workload):
     out = {"source": os.path.relpath(files[-1], ROOT), "measured_by_this_run": False,
            "kernel": doc.get("kernel"), "command": doc.get("command")}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        out["traffic_bytes_per_launch"] = 1024.0 * (2.0 * c["FETCH_SIZE"]["mean_per_dispatch"]
-                                                    + c["WRITE_SIZE"]["mean_per_dispatch"])
+        # per time step: a persistent kernel's profiled dispatches run another number of steps than this run's
+        out["traffic_bytes_per_step"] = 1024.0 * (2.0 * c["FETCH_SIZE"]["mean_per_dispatch"]
+                                                  + c["WRITE_SIZE"]["mean_per_dispatch"]) / doc.get("steps_per_dispatch", 1.0)
         out["dispatches"] = c["FETCH_SIZE"]["dispatches"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # MFMA_BUSY is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (its
@@ -385,7 +386,8 @@ def main():
         prof = profiled_counters(args.workload)
         if prof is not None:
             out["roofline"]["profiled"] = prof
-            out["roofline"]["traffic"] = prof.get("traffic_bytes_per_launch")
+            per_step = prof.get("traffic_bytes_per_step")
+            out["roofline"]["traffic"] = None if per_step is None else per_step * steps_per_launch
             out["roofline"]["traffic_source"] = (f"{prof['source']}: separate rocprofv3 --pmc passes of this command "
                                                  f"({prof.get('dispatches')} dispatches), NOT measured by this run")
         if world == 1 and args.workload == "dl_n1000_b1000":

@@ -1,0 +1,17 @@
+#!/bin/bash
+# The round's un-profiled bench lines on the GPU box (developer tool): gpurun_out/<tag>_bench*.json
+#   usage: tools/bench_round.sh <round tag, e.g. r02>      (then tools/collect_profiles.sh <tag>)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r02}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
+python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_like.json 2>> $O/${TAG}_bench.err || exit 1
+python3 bench.py --workload pl_n2000_b512 --post adam > $O/${TAG}_bench_pl_adam.json 2>> $O/${TAG}_bench.err || exit 1
+for w in dl_n100_b1000 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000; do
+  python3 bench.py --workload $w > $O/${TAG}_bench_$w.json 2>> $O/${TAG}_bench.err || exit 1
+done
+CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 1000 --warmup 100 --no-cpu-baseline > $O/${TAG}_bench_gpus2_share.json 2>> $O/${TAG}_bench.err || exit 1
+echo BENCH_DONE

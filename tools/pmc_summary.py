@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--command", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--skip", type=int, default=0, help="skip the first dispatches of the kernel (warm-up)")
+    ap.add_argument("--steps-per-dispatch", type=float, default=1.0,
+                    help="time steps a dispatch of this kernel runs, mean over the recorded dispatches (persistent kernels)")
     args = ap.parse_args()
     counters = {}
     for d in args.dirs:
@@ -47,6 +49,7 @@ def main():
         "command": args.command,
         "note": "gfx950: FETCH_SIZE counts half of a wide coalesced read (MI355X_MICROARCH.md, HBM): HBM-side bytes "
                 "per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB",
+        "steps_per_dispatch": args.steps_per_dispatch,
         "counters": dict(sorted(counters.items())),
     }
     with open(args.out, "w") as fh:
