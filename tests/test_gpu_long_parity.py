@@ -29,6 +29,8 @@ CASES = [
     ("config3_langevin_n500_b1000_adam", "langevin", 500, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
     ("config4_dl_n1000_b1000_headline", "dl", 1000, 1000, 1000, None, None, 3e-4, 1e-5),
     ("config5_pl_n2000_b512_adam_pp", "pl", 2000, 512, 200, "adam", None, 3e-4, 1e-5),
+    # not a BASELINE configuration: the DL solver at config 3's size (the cluster kernel's two-plane mode)
+    ("extra_dl_n500_b1000", "dl", 500, 1000, 500, None, None, 3e-4, 1e-5),
 ]
 
 
