@@ -105,8 +105,8 @@ struct ClusterArgs {
 // 2 no noise, 8 no exchange (no loads, no tag checks, no publish), 32 no LDS operand reads, 64 s_memtime stamps:
 // a.dbg[block][0..7] MFMA wave 0: waiting at B_0, first operand read + chunks, update + publish, waiting at the inner
 // barriers (total; at B_1, B_2, B_3 and later), the publish stores;
-// [8..12] fetch wave 4: waiting at B_0, staging + inner barriers, load issue, waiting at the last barrier,
-// tag check + staging of the next phase's first chunks; [13] retry rounds.
+// fetch wave 4: [8] waiting at B_0, [9] staging, loads and the inner barriers, [12] tag check + staging of the next
+// phase's first chunks, [13] retry rounds.
 #ifndef CCVM_CLUSTER_ABL
 #define CCVM_CLUSTER_ABL 0
 #endif
