@@ -238,7 +238,9 @@ size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float);
 bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 512, one-stream solvers ---------
-int cluster_count(int B) { return (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS); }
+// batch rows per cluster: two row sets of 16, three above K = 512 (ccvm_cluster.h: NSETS)
+int cluster_rows(int N) { return round_up(N, 128) > CL_LDS_K ? 3 * CL_ROWS : 2 * CL_ROWS; }
+int cluster_count(int B, int N) { return (B + cluster_rows(N) - 1) / cluster_rows(N); }
 // the launch status word (its own 128-byte line), last in the workspace
 size_t cluster_sync_bytes(int) { return 128; }
 // the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h), one per element of
@@ -246,16 +248,28 @@ size_t cluster_sync_bytes(int) { return 128; }
 // (planes: DL exchanges c and s, the one-stream solvers one array)
 size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
-    return 2 * (size_t)cluster_count(B) * 2 * CL_ROWS * planes * round_up(N, 128) * CL_XE;
+    return 2 * (size_t)cluster_count(B, N) * cluster_rows(N) * planes * round_up(N, 128) * CL_XE;
 }
-bool want_cluster(int B, int N, const Tuning& tun, int planes = 1) {
+// mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
+bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
+    const int planes = mode == MODE_DL ? 2 : 1;
+    // K = 640 / 768: DL and Langevin / pumped Langevin without Adam only (register budget, ccvm_cluster.h)
+    if (round_up(N, 128) > CL_LDS_K && !cluster_wide_ok(mode, adam)) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
     // Default policy (us per step, N = 500, cluster vs tile kernel): B = 1000: Langevin 4.95 vs 8.15, MF 5.39 vs 8.31,
     // DL 10.1 vs 13.1.  With more clusters than CUs they run in rounds of 256 workgroups: B = 2000 / 4000: Langevin
     // 9.97 / 20.0 vs 11.5 / 21.1, MF 10.8 vs 13.0 -- still ahead; DL 20.2 / 40.5 vs 19.8 / 38.8 -- the tile kernel's
     // larger tiles win, so DL takes the cluster path only while every cluster is resident at once.
-    if (tun.cluster < 0 && planes == 2 && (cluster_count(B) + 7) / 8 * 8 * G > 256) return false;
+    // Above K = 512 (three row sets of 16 per cluster, Q's k >= 512 in registers; Langevin / DL): N = 576 / 640,
+    // B = 1000: 9.5 / 9.6 and 18.8 / 18.7 vs 12.3 / 13.0 and 22 / 23.2; N = 768 (12 members: two clusters per XCD, so
+    // B <= 768 is what fits at once): B = 768: 10.6 / 21.8 vs 15.5 / 27.8, but B = 512: 10.6 / 21.8 vs 9.6 / 16.0 --
+    // a cluster's time per step does not shrink with a smaller batch, the tile grid's does.  So: only while the grid
+    // is resident, and from B = 640 up.
+    const bool wide = round_up(N, 128) > CL_LDS_K;
+    const bool resident = (cluster_count(B, N) + 7) / 8 * 8 * G <= 256;
+    if (tun.cluster < 0 && (planes == 2 || wide) && !resident) return false;
+    if (tun.cluster < 0 && wide && B < 640) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:
@@ -272,7 +286,7 @@ int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* q
     ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + xb);
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld;
-    ca.nclusters = cluster_count(B);
+    ca.nclusters = cluster_count(B, N);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
     return CCVM_OK;
 }
@@ -361,10 +375,10 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
-    if (!want_persist(N, tun) && want_cluster(B, N, tun, solver == 0 ? 2 : 1)) {
+    if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
         const int G = (N + CL_COLS - 1) / CL_COLS;
         std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups), up to %d steps per launch",
-                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B) + 7) / 8 * 8 * G, cluster_count(B), G,
+                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B, N) + 7) / 8 * 8 * G, cluster_count(B, N), G,
                       TABLE_STEPS);
         return CCVM_OK;
     }
@@ -461,7 +475,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         }
         return CCVM_OK;
     }
-    if (nsteps > 0 && want_cluster(B, N, tun, 2)) {
+    if (nsteps > 0 && want_cluster(B, N, tun, MODE_DL, false)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
@@ -642,7 +656,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         return CCVM_OK;
     }
 
-    if (want_cluster(B, N, tun)) {
+    if (want_cluster(B, N, tun, MODE_MF, use_adam)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         const float* qsum;
         if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum, p->qsum))) return rc;
@@ -843,7 +857,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         }
         return CCVM_OK;
     }
-    if (want_cluster(B, N, tun)) {
+    if (want_cluster(B, N, tun, MODE_LANGEVIN, use_adam)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         ClusterArgs ca;
         if (cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st))

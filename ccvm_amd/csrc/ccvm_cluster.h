@@ -67,7 +67,8 @@ namespace ccvm {
 constexpr int CL_COLS = 64;     // output columns per workgroup (cluster member)
 constexpr int CL_ROWS = 16;     // rows per row set (one 16x16x4 tile height); two sets per cluster
 constexpr int CL_KC = 128;      // K chunk staged through LDS per barrier
-constexpr int CL_MIN_N = 257, CL_MAX_N = 512;
+constexpr int CL_MIN_N = 257, CL_MAX_N = 768;
+constexpr int CL_LDS_K = 512;   // k < 512 of a member's panel lives in LDS, the rest (K = 640, 768) in the MFMA waves' registers
 constexpr int CL_THREADS = 512; // 4 MFMA waves + 4 fetch waves
 constexpr unsigned CL_SPIN_LIMIT = 1u << 19;  // fetch retries, ~2 us each: ~1 s
 constexpr unsigned CL_XE = 8;   // bytes per exchanged element: {value, tag}
@@ -132,15 +133,20 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 
-// KCH = K / 128 (3 or 4): K = ld = N rounded up to 128.
+// KCH = K / 128 (3 .. 6): K = ld = N rounded up to 128.  K <= 512: two row sets of 16 per cluster; K = 640 / 768: three
+// (a cluster has 9-12 members there: with 48 rows each, B = 1000 = 21 clusters still fit the chip at once), and the
+// panel's k >= 512 are B fragments in the MFMA waves' registers (32 / 64 VGPRs), loaded once per launch.
 // REPLAY is a template parameter, not a run-time branch: with the replay loads in the same code as the fused
 // noise hipcc guards the registers they share with s_waitcnt vmcnt(0) in BOTH paths.
 template <int MODE, bool ADAM, int KCH, bool REPLAY>
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant");
-    static_assert(KCH == 3 || KCH == 4, "K = 384 or 512");
+    static_assert(KCH >= 3 && KCH <= 6, "K = 384 ... 768");
     constexpr int K = KCH * CL_KC;
+    constexpr int NSETS = (KCH > 4) ? 3 : 2;       // row sets of 16 per cluster (ccvm_abi.hip: cluster_rows)
+    constexpr int CROWS = NSETS * CL_ROWS;
+    constexpr int KL = (KCH > 4) ? 4 : KCH;        // panel chunks in LDS; chunks KL .. KCH-1 in registers
     // DL contracts two input planes (c, then s) against the same panel: 2 KCH chunks per phase, two accumulator sets
     constexpr int NPL = (MODE == MODE_DL) ? 2 : 1;
     constexpr int NC = NPL * KCH;
@@ -171,19 +177,19 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     if (cluster >= a.nclusters) return;  // a whole cluster out of range: nobody waits for it
     const int N = a.N, ld = a.ld;
     const int col0 = member * CL_COLS;
-    const int crow0 = cluster * 2 * CL_ROWS;       // first batch row of the cluster
-    const int xrow0 = crow0 * NPL;                 // its first row in the exchange buffers: + 32 plane + 16 set + row
-    const int nphases = 2 * a.nsteps;              // phase P: step P / 2 of the launch, row set P % 2
+    const int crow0 = cluster * CROWS;             // first batch row of the cluster
+    const int xrow0 = crow0 * NPL;                 // its first row in the exchange buffers: + CROWS plane + 16 set + row
+    const int nphases = NSETS * a.nsteps;          // phase P: step P / NSETS of the launch, row set P % NSETS
     if (tid == 0) lds[DEAD] = 0.0f;
 
     // ---- Q panel, resident for the whole launch: qp[c][k] = Q[k][col0 + c] --------------------------
     {
         const int c = tid & 63, kk = tid >> 6;
 #pragma unroll 8
-        for (int k = kk; k < K; k += CL_THREADS / 64) qp[c * QS + kpos(k)] = a.Q[(size_t)k * ld + col0 + c];
+        for (int k = kk; k < KL * CL_KC; k += CL_THREADS / 64) qp[c * QS + kpos(k)] = a.Q[(size_t)k * ld + col0 + c];
     }
     // buffer descriptors of the two exchange buffers (wave-uniform: kernel arguments only)
-    const size_t xbytes = (size_t)(a.nclusters * 2 * CL_ROWS * NPL) * ld * CL_XE;
+    const size_t xbytes = (size_t)(a.nclusters * CROWS * NPL) * ld * CL_XE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.xb0, 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.xb1, 0, (int)xbytes, 0x00020000);
     constexpr int SC1 = 16;  // aux bits of the buffer builtins: sc1
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     for (int h = 0; h < 2; ++h)
                         w[cc][j][h] = __builtin_amdgcn_raw_buffer_load_b128(
                             par ? rs1 : rs0, ld_off,
-                            ((2 * CL_ROWS * (cc / KCH) + CL_ROWS * s + 8 * j) * ld + CL_KC * (cc % KCH) + 2 * h) * CL_XE, SC1);
+                            ((CROWS * (cc / KCH) + CL_ROWS * s + 8 * j) * ld + CL_KC * (cc % KCH) + 2 * h) * CL_XE, SC1);
         };
         auto arrived = [&](unsigned want, auto k_tag) {
             constexpr int C0 = 2 * decltype(k_tag)::value, C1 = (C0 + 2 < NC) ? C0 + 2 : NC;
@@ -306,19 +312,24 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         await_pair(0, 0, (unsigned)a.step0 + 1u, std::integral_constant<int, 0>{});
         stage(0, 0);
         stage(1, 1);
-        // Pair k of the NEXT phase's input is requested behind barrier B_(L0 + k): its peers stored it at the end of
-        // their previous phase, >= L0 chunks ago, and its registers are free (this phase's chunks 2 k, 2 k + 1 were
-        // staged behind B_(2 k - 2), B_(2 k - 1)).
+        // Pair k of the NEXT phase's input is requested behind barrier B_max(L0 + k, 2 k - 1): its peers stored it at
+        // the end of their previous phase, >= L0 chunks ago, and its registers are free -- this phase's chunks 2 k and
+        // 2 k + 1 are staged behind B_(2 k - 2) and B_(2 k - 1), the latter earlier in the same interval.
         constexpr int L0 = (NC == 3) ? 1 : 2;
+        auto pair_behind = [](int c) {  // the pair requested behind B_c, or -1
+            for (int k = 0; k < NPAIR; ++k)
+                if (((L0 + k > 2 * k - 1) ? L0 + k : 2 * k - 1) == c) return k;
+            return -1;
+        };
         if constexpr (CCVM_CLUSTER_ABL & 64) t_last = cl_stamp();
         bool dead = false;
         // one phase; B0 = buffer of its chunk 0 (compile time)
         auto phase = [&](int P, auto b0_tag) {
             constexpr int B0 = decltype(b0_tag)::value;
-            const int cs = P & 1, cpar = (P >> 1) & 1;          // this phase's set and exchange buffer
-            const unsigned cwant = (unsigned)(a.step0 + (P >> 1)) + 1u;
+            const int cs = P % NSETS, cj = P / NSETS, cpar = cj & 1;  // this phase's set, input number, exchange buffer
+            const unsigned cwant = (unsigned)(a.step0 + cj) + 1u;
             const bool next = P + 1 < nphases;
-            const int ns = (P + 1) & 1, nj = (P + 1) >> 1;      // the next phase's set and input number
+            const int ns = (P + 1) % NSETS, nj = (P + 1) / NSETS;      // the next phase's set and input number
             const unsigned nwant = (unsigned)(a.step0 + nj) + 1u;
             unroll_indices([&](auto c_tag) {
                 constexpr int c = decltype(c_tag)::value;
@@ -333,11 +344,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     if constexpr (c % 2 == 0) await_pair(cs, cpar, cwant, std::integral_constant<int, (c + 2) / 2>{});
                     stage(c + 2, (B0 + c + 2) % 3);
                 }
-                if constexpr (c >= L0 && c - L0 < NPAIR) {
+                if constexpr (constexpr int kp = pair_behind(c); kp >= 0) {
                     // unconditional (behind the last phase it fetches packets nobody looks at): with a branch around
                     // the loads the wait counts of the tag checks that follow must assume the shorter path and
                     // would wait for these very loads
-                    load_pair(ns, nj & 1, std::integral_constant<int, c - L0>{});
+                    load_pair(ns, nj & 1, std::integral_constant<int, kp>{});
                 }
                 if constexpr (c == NC - 1) {
                     mark(hseg[1]);
@@ -377,23 +388,23 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
 
     // ---- this lane's elements: set s, i = 0..3 -> batch row crow0 + 16 s + 4 g + i, column col ------
-    int brow[2][4];
-    bool ok[2][4];
-    size_t gidx[2][4];
-    float s0[2][4], s1[2][4], mt[2][4], wc[2][4], am[2][4], av[2][4];
+    int brow[NSETS][4];
+    bool ok[NSETS][4];
+    float s0[NSETS][4], s1[NSETS][4], mt[NSETS][4], wc[NSETS][4], am[NSETS][4], av[NSETS][4];
+    // (a cluster's last rows can lie beyond the padded arrays when it owns 48: every access is guarded by ok)
+    auto gidx = [&](int s, int i) { return (size_t)brow[s][i] * ld + col; };
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NSETS; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             brow[s][i] = crow0 + CL_ROWS * s + 4 * g + i;
             ok[s][i] = col_ok && brow[s][i] < a.B;
-            gidx[s][i] = (size_t)brow[s][i] * ld + col;  // inside the padded arrays for every lane
-            s0[s][i] = a.x0[gidx[s][i]];
-            s1[s][i] = (MODE != MODE_LANGEVIN) ? a.x1[gidx[s][i]] : 0.0f;
+            s0[s][i] = ok[s][i] ? a.x0[gidx(s, i)] : 0.0f;
+            s1[s][i] = (MODE != MODE_LANGEVIN && ok[s][i]) ? a.x1[gidx(s, i)] : 0.0f;
             mt[s][i] = wc[s][i] = am[s][i] = av[s][i] = 0.0f;
             if constexpr (ADAM) {
-                am[s][i] = a.am[gidx[s][i]];
-                av[s][i] = a.ad.use_v ? a.av[gidx[s][i]] : 0.0f;
+                am[s][i] = ok[s][i] ? a.am[gidx(s, i)] : 0.0f;
+                av[s][i] = (a.ad.use_v && ok[s][i]) ? a.av[gidx(s, i)] : 0.0f;
             }
         }
 
@@ -445,13 +456,13 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         for (int i = 0; i < 4; ++i) {
             const u32x2c v = {__builtin_bit_cast(unsigned, ok[s][i] ? x[i] : 0.0f), tag};
             __builtin_amdgcn_raw_buffer_store_b64(v, par ? rs1 : rs0, pub_off,
-                                                  (2 * CL_ROWS * plane + CL_ROWS * s + i) * ld * CL_XE, SC1);
+                                                  (CROWS * plane + CL_ROWS * s + i) * ld * CL_XE, SC1);
         }
     };
 
-    // ---- first inputs: x(step0) of both sets ---------------------------------------------------------
+    // ---- first inputs: x(step0) of every set ---------------------------------------------------------
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSETS; ++s) {
         if constexpr (MODE == MODE_MF) {
             stream_normals(s, a.step0, 0, wc[s]);  // mf_solver.py:551-554 for the first step of the launch
 #pragma unroll
@@ -477,10 +488,34 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             dst[4 * q] = v[0]; dst[4 * q + 1] = v[1]; dst[4 * q + 2] = v[2]; dst[4 * q + 3] = v[3];
         }
     };
-    read_ops(bq[0], b_rd);
+    // the panel's chunks KL .. KCH-1 (k >= 512): this lane's B fragments, for the whole launch
+    float breg[(KCH > KL) ? KCH - KL : 1][32];
+    if constexpr (KCH > KL) {
+#pragma unroll
+        for (int j = 0; j < KCH - KL; ++j)
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+                breg[j][m] = a.Q[(size_t)(CL_KC * (KL + j) + 32 * g + m) * ld + col];
+    }
+    // The first chunk's B operands are read during the previous phase's last chunk (the panel never changes), into the
+    // half of the double buffer that phase's last chunk does not compute from -- possible when the chunks of an
+    // iteration are even in number (the halves' roles are compile-time constants); else every phase reads them
+    // itself, next to its first A operands.
+    constexpr bool XPHASE = (NSETS * NC) % 2 == 0;
+    if constexpr (XPHASE) read_ops(bq[0], b_rd);
 
+    // schedule rows through the scalar cache into SGPRs (constant address space: the table is written by an earlier
+    // kernel and never here): as vector loads the current and the next row held 16-32 VGPRs for the whole iteration
     struct Row { float w[TABLE_WORDS]; };
-    Row rnext = *reinterpret_cast<const Row*>(a.table);
+    typedef const __attribute__((address_space(4))) float* table_ptr;
+    const table_ptr table = (table_ptr)(size_t)a.table;
+    auto load_row = [&](int i) {
+        Row r;
+#pragma unroll
+        for (int k = 0; k < TABLE_WORDS; ++k) r.w[k] = table[(size_t)i * TABLE_WORDS + k];
+        return r;
+    };
+    Row rnext = load_row(0);
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int b0 = 0;  // buffer of chunk 0 of the current phase
     if constexpr (CCVM_CLUSTER_ABL & 64) t_last = cl_stamp();
@@ -489,10 +524,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         const int step = a.step0 + it;
         const Row rcur = rnext;
         const float* trow = rcur.w;
-        rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
+        rnext = load_row(min(it + 1, a.nsteps - 1));
         const bool has_next = it + 1 < a.nsteps;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NSETS; ++s) {
             __syncthreads();  // B_0: the fetch waves have staged this phase's chunks 0 and 1
             if (lds[DEAD] != 0.0f) return;
             mark(seg[0]);
@@ -506,14 +541,21 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             for (int pl = 0; pl < NPL; ++pl) acc[pl][0] = acc[pl][1] = f32x4c{0.0f, 0.0f, 0.0f, 0.0f};
             float aq[2][32];
             __builtin_amdgcn_sched_barrier(0);
-            read_ops(aq[(NC * s) & 1], ab[0]);  // chunk 0: the one exposed LDS latency
+            // operand double buffer: chunk n of the iteration (n = NC s + c) computes from [n & 1] (s is a constant
+            // after unrolling); without the cross-phase read every phase starts at [0]
+            const int cb0 = XPHASE ? (NC * s) & 1 : 0;
+            read_ops(aq[cb0], ab[0]);  // chunk 0: the one exposed LDS latency
+            if constexpr (!XPHASE) read_ops(bq[0], b_rd);
             __builtin_amdgcn_sched_barrier(0);
             unroll_indices([&](auto c_tag) {
                 constexpr int c = decltype(c_tag)::value;  // chunk c % KCH of plane c / KCH
                 constexpr int pl = c / KCH;
-                // operand double buffer: chunk n of the iteration (n = NC s + c) computes from [n & 1] (s is a
-                // constant after unrolling; 2 NC flips per iteration bring the first chunk back to [0])
-                const int cb = (NC * s + c) & 1, nb = cb ^ 1;
+                constexpr int pc = c % KCH;             // panel chunk: from LDS (pc < KL) or registers
+                constexpr int npc = (c + 1) % KCH;      // the next chunk's
+                // B operands to read during this chunk: the next chunk's if they live in LDS and (it belongs to this
+                // phase or the cross-phase read is on)
+                constexpr bool RD_B = npc < KL && (c + 1 < NC || XPHASE);
+                const int cb = (cb0 + c) & 1, nb = cb ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 32; ++m) {
@@ -522,8 +564,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     // below: hipcc otherwise sinks every read to its use and waits for it there
                     if constexpr (!(CCVM_CLUSTER_ABL & 32)) {
                         if (m % 4 == 0) {  // one b128 per operand and four MFMAs
-                            const f32x4c vb = *reinterpret_cast<const f32x4c*>(b_rd + 32 * ((c + 1) % KCH) + m);
-                            bq[nb][m] = vb[0]; bq[nb][m + 1] = vb[1]; bq[nb][m + 2] = vb[2]; bq[nb][m + 3] = vb[3];
+                            if constexpr (RD_B) {
+                                const f32x4c vb = *reinterpret_cast<const f32x4c*>(b_rd + 32 * npc + m);
+                                bq[nb][m] = vb[0]; bq[nb][m + 1] = vb[1]; bq[nb][m + 2] = vb[2]; bq[nb][m + 3] = vb[3];
+                            }
                             if constexpr (c + 1 < NC) {
                                 const f32x4c va = *reinterpret_cast<const f32x4c*>(ab[(c + 1) % 3] + m);
                                 aq[nb][m] = va[0]; aq[nb][m + 1] = va[1]; aq[nb][m + 2] = va[2]; aq[nb][m + 3] = va[3];
@@ -533,18 +577,21 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                         bq[nb][m] = bq[cb][m];
                         aq[nb][m] = aq[cb][m];
                     }
+                    const float bop = (pc < KL) ? bq[cb][m] : breg[(pc < KL) ? 0 : pc - KL][m];
                     if constexpr (CCVM_CLUSTER_ABL & 1) {
-                        acc[pl][0][m & 3] += aq[cb][m] * bq[cb][m];  // keeps the operands live
+                        acc[pl][0][m & 3] += aq[cb][m] * bop;  // keeps the operands live
                     } else {
-                        acc[pl][m & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bq[cb][m], acc[pl][m & 1], 0, 0, 0);
+                        acc[pl][m & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bop, acc[pl][m & 1], 0, 0, 0);
                     }
                 }
-                constexpr int NRD = (c + 1 < NC) ? 2 : 1;  // next chunk's operand reads per four MFMAs
+                constexpr int NRD = (c + 1 < NC ? 1 : 0) + (RD_B ? 1 : 0);  // next chunk's operand reads per four MFMAs
+                if constexpr (NRD > 0) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // the next chunk's b128 reads
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // 3 MFMAs
+                    for (int m = 0; m < 8; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // the next chunk's b128 reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // 3 MFMAs
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (c + 1 < NC) {
@@ -645,22 +692,25 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
     // ---- write the state back (owner-only data: plain stores) ---------------------------------------
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NSETS; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!ok[s][i]) continue;
-            a.x0[gidx[s][i]] = s0[s][i];
-            if constexpr (MODE == MODE_DL) a.x1[gidx[s][i]] = s1[s][i];
+            a.x0[gidx(s, i)] = s0[s][i];
+            if constexpr (MODE == MODE_DL) a.x1[gidx(s, i)] = s1[s][i];
             if constexpr (MODE == MODE_MF) {
-                a.x1[gidx[s][i]] = s1[s][i];
-                if (a.xt) a.xt[gidx[s][i]] = mt[s][i];
+                a.x1[gidx(s, i)] = s1[s][i];
+                if (a.xt) a.xt[gidx(s, i)] = mt[s][i];
             }
             if constexpr (ADAM) {
-                a.am[gidx[s][i]] = am[s][i];
-                if (a.ad.use_v) a.av[gidx[s][i]] = av[s][i];
+                a.am[gidx(s, i)] = am[s][i];
+                if (a.ad.use_v) a.av[gidx(s, i)] = av[s][i];
             }
         }
 }
+
+// K > 512 is served for these solver variants only (register budget of the MFMA waves)
+constexpr bool cluster_wide_ok(int mode, bool adam) { return !adam && (mode == MODE_DL || mode == MODE_LANGEVIN); }
 
 void cluster_launch_dl(const ClusterArgs& a, hipStream_t st);
 void cluster_launch_mf(const ClusterArgs& a, bool adam, hipStream_t st);
@@ -668,8 +718,15 @@ void cluster_launch_lv(const ClusterArgs& a, bool adam, hipStream_t st);
 
 template <int MODE, bool ADAM, bool REPLAY>
 void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
-    if (a.ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+    const int kch = a.ld / CL_KC;
+    if (kch == 3) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+    else if (kch == 4) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+    // K = 640 / 768 (cluster_wide_ok): three row sets + 32 / 64 registers of Q per MFMA wave fit the 256-register
+    // budget for DL and for Langevin / pumped Langevin without Adam; MF and the Adam variants would spill
+    if constexpr (cluster_wide_ok(MODE, ADAM)) {
+        if (kch == 5) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 5, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        else if (kch == 6) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 6, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+    }
 }
 
 template <int MODE>

@@ -99,6 +99,12 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 1024 x 512 threads (125 clusters of 8 workgroups)",
         (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",
         (1, 1000, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 160 x 512",
+        (2, 1000, 600, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
+        (2, 1000, 600, 1): "ccvm::step_kernel<2, true, 0, 1, false, 0> grid 160 x 512",
+        (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
+        (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
+        (0, 1000, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 192 x 512",
+        (2, 512, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 192 x 512",
         (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",
     }
     for (solver, b, n, adam), text in want.items():

@@ -35,7 +35,8 @@ int main(int argc, char** argv) {
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
     a.status = sync;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
-    a.nclusters = (B + 31) / 32; a.G = (N + 63) / 64;
+    const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512
+    a.nclusters = (B + crows - 1) / crows; a.G = (N + 63) / 64;
     const int grid = (a.nclusters + 7) / 8 * 8 * a.G;
     unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 16 * 8); hipMemset(dbg, 0, (size_t)grid * 16 * 8);
     a.dbg = dbg;
@@ -45,8 +46,12 @@ int main(int argc, char** argv) {
         hipMemset(xb0, 0, state * 16); hipMemset(xb1, 0, state * 16);  // LL exchange: no stale tags
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        if (ld == 512) hipLaunchKernelGGL((cluster_kernel<MODE, false, 4, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a);
-        else hipLaunchKernelGGL((cluster_kernel<MODE, false, 3, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a);
+        switch (ld / 128) {
+            case 3: hipLaunchKernelGGL((cluster_kernel<MODE, false, 3, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a); break;
+            case 4: hipLaunchKernelGGL((cluster_kernel<MODE, false, 4, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a); break;
+            case 5: hipLaunchKernelGGL((cluster_kernel<MODE, false, 5, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a); break;
+            default: hipLaunchKernelGGL((cluster_kernel<MODE, false, 6, false>), dim3(grid), dim3(CL_THREADS), 0, 0, a); break;
+        }
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
@@ -62,7 +67,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 16; ++k) {
             if (!names[k][0]) continue;
             std::vector<double> v;
-            for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 16 + k] / (2.0 * steps));
+            for (int w = 0; w < grid; ++w) v.push_back((double)hd[(size_t)w * 16 + k] / ((ld > 512 ? 3.0 : 2.0) * steps));
             std::sort(v.begin(), v.end());
             printf("%-38s: min %8.1f  median %8.1f  max %8.1f ticks/phase\n", names[k], v.front(), v[v.size() / 2], v.back());
         }
