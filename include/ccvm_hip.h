@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 5
+#define CCVM_ABI_VERSION 6
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
