@@ -254,14 +254,13 @@ size_t cluster_exchange_bytes(int B, int N, int planes) {
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
     const int planes = mode == MODE_DL ? 2 : 1;
-    // K = 640 / 768: DL and Langevin / pumped Langevin without Adam only (register budget, ccvm_cluster.h)
     if (round_up(N, 128) > CL_LDS_K && !cluster_wide_ok(mode, adam)) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
     // Default policy (us per step, N = 500, cluster vs tile kernel): B = 1000: Langevin 4.95 vs 8.15, MF 5.39 vs 8.31,
     // DL 10.1 vs 13.1.  With more clusters than CUs they run in rounds of 256 workgroups: B = 2000 / 4000: Langevin
     // 9.97 / 20.0 vs 11.5 / 21.1, MF 10.8 vs 13.0 -- still ahead; DL 20.2 / 40.5 vs 19.8 / 38.8 -- the tile kernel's
     // larger tiles win, so DL takes the cluster path only while every cluster is resident at once.
-    // Above K = 512 (three row sets of 16 per cluster, Q's k >= 512 in registers; Langevin / DL): N = 576 / 640,
+    // Above K = 512 (three row sets of 16 per cluster, Q's k >= 512 in registers; Langevin and DL here): N = 576 / 640,
     // B = 1000: 9.5 / 9.6 and 18.8 / 18.7 vs 12.3 / 13.0 and 22 / 23.2; N = 768 (12 members: two clusters per XCD, so
     // B <= 768 is what fits at once): B = 768: 10.6 / 21.8 vs 15.5 / 27.8, but B = 512: 10.6 / 21.8 vs 9.6 / 16.0 --
     // a cluster's time per step does not shrink with a smaller batch, the tile grid's does.  So: only while the grid

@@ -120,6 +120,12 @@ struct ClusterArgs {
 #ifndef CCVM_CL_STAGE_ASM
 #define CCVM_CL_STAGE_ASM 0
 #endif
+// MFMAs per operand-prefetch unit: 32 = a whole chunk ahead (2 x 64 operand registers), 16 = half a chunk (2 x 32
+// registers; 512 cycles of MFMAs still cover the LDS latency: N = 500 Langevin 5.00 -> 4.91 us / step, N = 640 9.55 ->
+// 9.30, DL 18.8 -> 18.5, and 64 registers freed)
+#ifndef CCVM_CL_UNIT
+#define CCVM_CL_UNIT 16
+#endif
 
 __device__ __forceinline__ unsigned long long cl_stamp() {
     unsigned long long t;
@@ -480,10 +486,13 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     // operand read addresses: A row c16, B column 16 wave + c16, k segment g; operand m of a chunk at [m]
     const float* const a_rd = abuf + rowpos(c16) * AS + 32 * g;
     const float* const b_rd = qp + (16 * wave + c16) * QS + 128 * g;  // chunk c's B operands start at + 32 c
-    float bq[2][32];  // B operands of a chunk (double-buffered across chunks); the first chunk's now
-    auto read_ops = [&](float (&dst)[32], const float* src) {  // 32 operands of one chunk
+    // operands are read one UNIT (UM MFMAs' worth: a chunk or half a chunk) ahead, double-buffered
+    constexpr int UM = CCVM_CL_UNIT, UPC = 32 / UM, NU = NC * UPC;
+    static_assert(UM == 32 || UM == 16, "operand unit: a chunk or half a chunk");
+    float bq[2][UM];  // B operands of a unit; the first unit's now
+    auto read_ops = [&](float (&dst)[UM], const float* src) {  // the UM operands of one unit
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < UM / 4; ++q) {
             const f32x4c v = *reinterpret_cast<const f32x4c*>(src + 4 * q);
             dst[4 * q] = v[0]; dst[4 * q + 1] = v[1]; dst[4 * q + 2] = v[2]; dst[4 * q + 3] = v[3];
         }
@@ -497,11 +506,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             for (int m = 0; m < 32; ++m)
                 breg[j][m] = a.Q[(size_t)(CL_KC * (KL + j) + 32 * g + m) * ld + col];
     }
-    // The first chunk's B operands are read during the previous phase's last chunk (the panel never changes), into the
-    // half of the double buffer that phase's last chunk does not compute from -- possible when the chunks of an
-    // iteration are even in number (the halves' roles are compile-time constants); else every phase reads them
-    // itself, next to its first A operands.
-    constexpr bool XPHASE = (NSETS * NC) % 2 == 0;
+    // The first unit's B operands are read during the previous phase's last unit (the panel never changes), into the
+    // half of the double buffer that unit does not compute from -- possible when the units of an iteration are even
+    // in number (the halves' roles are compile-time constants); else every phase reads them itself, next to its first
+    // A operands.
+    constexpr bool XPHASE = (NSETS * NU) % 2 == 0;
     if constexpr (XPHASE) read_ops(bq[0], b_rd);
 
     // schedule rows through the scalar cache into SGPRs (constant address space: the table is written by an earlier
@@ -539,37 +548,38 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             f32x4c acc[NPL][2];
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) acc[pl][0] = acc[pl][1] = f32x4c{0.0f, 0.0f, 0.0f, 0.0f};
-            float aq[2][32];
+            float aq[2][UM];
             __builtin_amdgcn_sched_barrier(0);
-            // operand double buffer: chunk n of the iteration (n = NC s + c) computes from [n & 1] (s is a constant
+            // operand double buffer: unit n of the iteration (n = NU s + u) computes from [n & 1] (s is a constant
             // after unrolling); without the cross-phase read every phase starts at [0]
-            const int cb0 = XPHASE ? (NC * s) & 1 : 0;
-            read_ops(aq[cb0], ab[0]);  // chunk 0: the one exposed LDS latency
+            const int ub0 = XPHASE ? (NU * s) & 1 : 0;
+            read_ops(aq[ub0], ab[0]);  // unit 0: the one exposed LDS latency
             if constexpr (!XPHASE) read_ops(bq[0], b_rd);
             __builtin_amdgcn_sched_barrier(0);
-            unroll_indices([&](auto c_tag) {
-                constexpr int c = decltype(c_tag)::value;  // chunk c % KCH of plane c / KCH
+            unroll_indices([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                constexpr int c = u / UPC, h = u % UPC;      // chunk c % KCH of plane c / KCH, its unit h
                 constexpr int pl = c / KCH;
-                constexpr int pc = c % KCH;             // panel chunk: from LDS (pc < KL) or registers
-                constexpr int npc = (c + 1) % KCH;      // the next chunk's
-                // B operands to read during this chunk: the next chunk's if they live in LDS and (it belongs to this
-                // phase or the cross-phase read is on)
-                constexpr bool RD_B = npc < KL && (c + 1 < NC || XPHASE);
-                const int cb = (cb0 + c) & 1, nb = cb ^ 1;
+                constexpr int pc = c % KCH;                  // panel chunk: from LDS (pc < KL) or registers
+                constexpr int nc = (u + 1) / UPC, nh = (u + 1) % UPC;  // the next unit's chunk and position
+                constexpr int npc = nc % KCH;
+                // operands to read during this unit: the next unit's A (if it belongs to this phase) and B (if it lives
+                // in LDS and belongs to this phase or the cross-phase read is on)
+                constexpr bool RD_A = u + 1 < NU;
+                constexpr bool RD_B = npc < KL && (u + 1 < NU || XPHASE);
+                const int cb = (ub0 + u) & 1, nb = cb ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < 32; ++m) {
-                    // next chunk's operands in the issue shadow of this chunk's MFMAs (after the last chunk:
-                    // the B operands of the next phase's first chunk -- the panel never changes); order pinned
-                    // below: hipcc otherwise sinks every read to its use and waits for it there
+                for (int m = 0; m < UM; ++m) {
+                    // order pinned below: hipcc otherwise sinks every read to its use and waits for it there
                     if constexpr (!(CCVM_CLUSTER_ABL & 32)) {
                         if (m % 4 == 0) {  // one b128 per operand and four MFMAs
                             if constexpr (RD_B) {
-                                const f32x4c vb = *reinterpret_cast<const f32x4c*>(b_rd + 32 * npc + m);
+                                const f32x4c vb = *reinterpret_cast<const f32x4c*>(b_rd + 32 * npc + UM * nh + m);
                                 bq[nb][m] = vb[0]; bq[nb][m + 1] = vb[1]; bq[nb][m + 2] = vb[2]; bq[nb][m + 3] = vb[3];
                             }
-                            if constexpr (c + 1 < NC) {
-                                const f32x4c va = *reinterpret_cast<const f32x4c*>(ab[(c + 1) % 3] + m);
+                            if constexpr (RD_A) {
+                                const f32x4c va = *reinterpret_cast<const f32x4c*>(ab[nc % 3] + UM * nh + m);
                                 aq[nb][m] = va[0]; aq[nb][m + 1] = va[1]; aq[nb][m + 2] = va[2]; aq[nb][m + 3] = va[3];
                             }
                         }
@@ -577,24 +587,24 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                         bq[nb][m] = bq[cb][m];
                         aq[nb][m] = aq[cb][m];
                     }
-                    const float bop = (pc < KL) ? bq[cb][m] : breg[(pc < KL) ? 0 : pc - KL][m];
+                    const float bop = (pc < KL) ? bq[cb][m] : breg[(pc < KL) ? 0 : pc - KL][UM * h + m];
                     if constexpr (CCVM_CLUSTER_ABL & 1) {
                         acc[pl][0][m & 3] += aq[cb][m] * bop;  // keeps the operands live
                     } else {
                         acc[pl][m & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cb][m], bop, acc[pl][m & 1], 0, 0, 0);
                     }
                 }
-                constexpr int NRD = (c + 1 < NC ? 1 : 0) + (RD_B ? 1 : 0);  // next chunk's operand reads per four MFMAs
+                constexpr int NRD = (RD_A ? 1 : 0) + (RD_B ? 1 : 0);  // the next unit's operand reads per four MFMAs
                 if constexpr (NRD > 0) {
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) {
+                    for (int m = 0; m < UM / 4; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // the next chunk's b128 reads
+                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // the next unit's b128 reads
                         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // 3 MFMAs
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (c + 1 < NC) {
+                if constexpr (h == UPC - 1 && c + 1 < NC) {
                     mark(seg[1]);
                     __syncthreads();  // B_(c+1): chunk c's buffer may be refilled; chunk c + 2 is staged
                     if constexpr (CCVM_CLUSTER_ABL & 64) {
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                         seg[(c < 2) ? 4 + c : 6] += t_last - before;
                     }
                 }
-            }, std::make_integer_sequence<int, NC>{});
+            }, std::make_integer_sequence<int, NU>{});
             mark(seg[1]);
             // ---- this step's / the next step's normals -------------------------------------------
             float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nz1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -709,8 +719,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
 }
 
-// K > 512 is served for these solver variants only (register budget of the MFMA waves)
-constexpr bool cluster_wide_ok(int mode, bool adam) { return !adam && (mode == MODE_DL || mode == MODE_LANGEVIN); }
+// K > 512 is served for every solver variant: with half-chunk operand units the MFMA waves' registers suffice (the
+// tightest, MF + Adam at K = 768: 255 of 256)
+constexpr bool cluster_wide_ok(int, bool) { return true; }
 
 void cluster_launch_dl(const ClusterArgs& a, hipStream_t st);
 void cluster_launch_mf(const ClusterArgs& a, bool adam, hipStream_t st);
@@ -721,8 +732,7 @@ void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
     const int kch = a.ld / CL_KC;
     if (kch == 3) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
     else if (kch == 4) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
-    // K = 640 / 768 (cluster_wide_ok): three row sets + 32 / 64 registers of Q per MFMA wave fit the 256-register
-    // budget for DL and for Langevin / pumped Langevin without Adam; MF and the Adam variants would spill
+    // K = 640 / 768: three row sets + 32 / 64 registers of Q per MFMA wave
     if constexpr (cluster_wide_ok(MODE, ADAM)) {
         if (kch == 5) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 5, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
         else if (kch == 6) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 6, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);

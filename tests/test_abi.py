@@ -98,9 +98,10 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (0, 1000, 300, 0): "ccvm::cluster_kernel<0, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
         (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 1024 x 512 threads (125 clusters of 8 workgroups)",
         (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",
-        (1, 1000, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 160 x 512",
+        (1, 1000, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
-        (2, 1000, 600, 1): "ccvm::step_kernel<2, true, 0, 1, false, 0> grid 160 x 512",
+        (2, 1000, 600, 1): "ccvm::cluster_kernel<2, true, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
+        (1, 1200, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 190 x 512",
         (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
         (0, 1000, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 192 x 512",

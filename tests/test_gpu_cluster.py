@@ -79,12 +79,12 @@ def _run_oracle(kind, n, b, t, adam, seed, row_offset):
     ("pl", 449, 32, 16, None), ("mf", 512, 256, 12, "first_moment_only"), ("pl", 512, 1, 12, None),
     # more workgroups than the chip holds at once: clusters run in dispatch order
     ("pl", 300, 5000, 8, None), ("mf", 500, 3000, 6, None),
-    # K = 640 / 768: three row sets per cluster, Q's k >= 512 in registers (DL and Langevin / PL without Adam; MF and the
-    # Adam variants stay on the tile kernel there: the last two cases)
+    # K = 640 / 768: three row sets per cluster, Q's k >= 512 in registers
     ("langevin", 513, 100, 20, None), ("pl", 576, 1000, 24, None), ("langevin", 640, 47, 16, None),
     ("pl", 641, 96, 16, None), ("langevin", 700, 1000, 20, None), ("pl", 768, 130, 12, None),
     ("dl", 513, 49, 16, None), ("dl", 640, 1000, 20, None), ("dl", 704, 100, 12, None), ("dl", 768, 1000, 16, None),
-    ("mf", 640, 64, 8, None), ("langevin", 640, 64, 8, "second_moment"),
+    ("mf", 640, 1000, 16, None), ("langevin", 640, 64, 12, "second_moment"), ("mf", 768, 100, 12, "add_assign"),
+    ("mf", 513, 33, 12, "first_moment_only"), ("pl", 700, 768, 10, "second_moment"),
     # DL: two exchanged planes (c, s), 2 K / 128 chunks per phase
     ("dl", 500, 1000, 40, None), ("dl", 257, 33, 30, None), ("dl", 320, 100, 24, None), ("dl", 384, 70, 20, None),
     ("dl", 385, 64, 20, None), ("dl", 449, 129, 16, None), ("dl", 512, 1, 12, None), ("dl", 300, 5000, 8, None),
