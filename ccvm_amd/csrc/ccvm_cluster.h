@@ -103,7 +103,8 @@ struct ClusterArgs {
 };
 
 // Ablation bits for tools/cluster_ablate.hip (0 in the product; timing only, results are wrong): 1 no MFMA,
-// 2 no noise, 8 no exchange (no loads, no tag checks, no publish), 32 no LDS operand reads, 64 s_memtime stamps:
+// 2 no noise, 4 no tag checks, 8 no exchange (no loads, no tag checks, no publish), 16 no publish stores (with 4),
+// 32 no LDS operand reads, 64 s_memtime stamps:
 // a.dbg[block][0..7] MFMA wave 0: waiting at B_0, first operand read + chunks, update + publish, waiting at the inner
 // barriers (total; at B_1, B_2, B_3 and later), the publish stores;
 // fetch wave 4: [8] waiting at B_0, [9] staging, loads and the inner barriers, [12] tag check + staging of the next
@@ -123,6 +124,9 @@ struct ClusterArgs {
 // MFMAs per operand-prefetch unit: 32 = a whole chunk ahead (2 x 64 operand registers), 16 = half a chunk (2 x 32
 // registers; 512 cycles of MFMAs still cover the LDS latency: N = 500 Langevin 5.00 -> 4.91 us / step, N = 640 9.55 ->
 // 9.30, DL 18.8 -> 18.5, and 64 registers freed)
+#ifndef CCVM_CL_STAMP_TID
+#define CCVM_CL_STAMP_TID 256  // the fetch wave whose stamps are reported (first lane of wave 4 .. 7)
+#endif
 #ifndef CCVM_CL_UNIT
 #define CCVM_CL_UNIT 16
 #endif
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         };
         // wait (bounded) until pair k of input `want` of set s is complete in w
         auto await_pair = [&](int s, int par, unsigned want, auto k_tag) {
-            if constexpr (NO_XCHG) return;
+            if constexpr (NO_XCHG || (CCVM_CLUSTER_ABL & 4)) return;
             // the first check stands alone: straight-line code whose wait counts leave the younger loads (the
             // input's other pairs) in flight; the merged counts of a loop header would wait for everything
             if (__builtin_expect(arrived(want, k_tag), 1)) return;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             if (dead || ++P >= nphases) break;
         }
         if constexpr (CCVM_CLUSTER_ABL & 64) {
-            if (tid == 256)
+            if (tid == CCVM_CL_STAMP_TID)
                 for (int k = 0; k < 6; ++k) a.dbg[(size_t)blockIdx.x * 16 + 8 + k] = hseg[k];
         }
         return;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     // whole 128-byte lines.  Never waited for.
     const unsigned pub_off = (unsigned)(((size_t)(xrow0 + 4 * g) * ld + col) * CL_XE);
     auto publish = [&](int s, int par, const float (&x)[4], unsigned tag, int plane = 0) {
-        if constexpr (NO_XCHG) return;
+        if constexpr (NO_XCHG || (CCVM_CLUSTER_ABL & 16)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32x2c v = {__builtin_bit_cast(unsigned, ok[s][i] ? x[i] : 0.0f), tag};
@@ -533,12 +537,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         const int step = a.step0 + it;
         const Row rcur = rnext;
         const float* trow = rcur.w;
-        rnext = load_row(min(it + 1, a.nsteps - 1));
         const bool has_next = it + 1 < a.nsteps;
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             __syncthreads();  // B_0: the fetch waves have staged this phase's chunks 0 and 1
-            if (lds[DEAD] != 0.0f) return;
+            if (lds[DEAD] != 0.0f) return;  // (looking at the flag only behind the chunks measured 2 % SLOWER)
             mark(seg[0]);
             // chunk c of this phase sits in buffer (b0 + c) % 3
             const float* const ab[3] = {a_rd + b0 * ABUF, a_rd + ((b0 + 1) % 3) * ABUF, a_rd + ((b0 + 2) % 3) * ABUF};
@@ -615,6 +618,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                 }
             }, std::make_integer_sequence<int, NU>{});
             mark(seg[1]);
+            // the next step's schedule row: requested here, ahead of ~1000 cycles of VALU work without a single LDS
+            // wait -- scalar loads share lgkmcnt with LDS and return out of order, so requested at the top of the
+            // iteration the barrier's s_waitcnt lgkmcnt(0) sat out the scalar cache's latency (~600 cycles per step)
+            if (s == NSETS - 1) rnext = load_row(min(it + 1, a.nsteps - 1));
             // ---- this step's / the next step's normals -------------------------------------------
             float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nz1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (MODE == MODE_DL) {
@@ -699,6 +706,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     if constexpr (CCVM_CLUSTER_ABL & 64) {
         if (tid == 0)
             for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 16 + k] = seg[k];
+        // the other MFMA waves' wait at B_0 (slots 10, 11, 14) and wave 3's noise + update (15)
+        if (lane == 0 && wave > 0) a.dbg[(size_t)blockIdx.x * 16 + (wave == 1 ? 10 : wave == 2 ? 11 : 14)] = seg[0];
+        if (lane == 0 && wave == 3) a.dbg[(size_t)blockIdx.x * 16 + 15] = seg[2];
     }
     // ---- write the state back (owner-only data: plain stores) ---------------------------------------
 #pragma unroll

@@ -62,8 +62,9 @@ int main(int argc, char** argv) {
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
         const char* names[16] = {"MFMA wave: wait at B_0", "MFMA wave: first read + chunks", "MFMA wave: noise + update", "MFMA wave: wait at inner barriers",
                                  "MFMA wave:   at B_1", "MFMA wave:   at B_2", "MFMA wave:   at B_3..", "MFMA wave: publish stores",
-                                 "fetch wave: wait at B_0", "fetch wave: staging, loads, inner barriers", "",
-                                 "", "fetch wave: tag check + stage next", "fetch wave: RETRY ROUNDS per phase", "", ""};
+                                 "fetch wave: wait at B_0", "fetch wave: staging, loads, inner barriers", "MFMA wave 1: wait at B_0",
+                                 "MFMA wave 2: wait at B_0", "fetch wave: tag check + stage next", "fetch wave: RETRY ROUNDS per phase",
+                                 "MFMA wave 3: wait at B_0", "MFMA wave 3: noise + update"};
         for (int k = 0; k < 16; ++k) {
             if (!names[k][0]) continue;
             std::vector<double> v;
