@@ -135,16 +135,17 @@ def test_cluster_chunking_and_sharding_are_exact(cluster, kind, n):
         assert torch.equal(whole.compact(name), torch.cat([lo.compact(name), hi.compact(name)])), name
 
 
-@pytest.mark.parametrize("kind,post", [("mf", None), ("langevin", "adam"), ("pl", "grad-descent"), ("dl", None),
-                                       ("dl", "adam")])
-def test_cluster_replay_mode_through_the_public_api(cluster, kind, post):
+@pytest.mark.parametrize("kind,post,n", [("mf", None, 300), ("langevin", "adam", 300), ("pl", "grad-descent", 300),
+                                         ("dl", None, 300), ("dl", "adam", 300), ("mf", "adam", 600), ("pl", None, 640),
+                                         ("dl", None, 700)])
+def test_cluster_replay_mode_through_the_public_api(cluster, kind, post, n):
     """Replay noise (torch's CPU stream in the reference's order) through Solver.__call__ and the fused
     finalize, against the oracle's solve_* on the same seed."""
     from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
     from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
     from oracle import ccvm_oracle as oracle
 
-    n, b, t = 300, 70, 60
+    b, t = 70, 60
     cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind]
     solver = cls(device="cpu", batch_size=b)
     solver.noise_mode = "replay"
