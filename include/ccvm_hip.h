@@ -144,14 +144,14 @@ int ccvm_unpack(const float* src, int src_ld,
 
 /* ---- the hot path: nsteps fused Euler-Maruyama steps ------------------------- */
 /* Bytes of caller-provided scratch a call needs (ping-pong state, the MF measured-amplitude
- * buffers, column sums of Q, schedule table; for 256 < N <= 512 the column-cluster path's exchange
+ * buffers, column sums of Q, schedule table; for 256 < N <= 768 the column-cluster path's exchange
  * buffers of 8-byte {value, tag} packets; a status word).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
  * 2 ccvm_langevin_run, 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);
 /* Byte offset, inside the workspace of ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2),
  * of a 4-byte status word; (size_t)-1 for the other entries.  The caller zeroes it once (a fresh workspace) and may
  * read it after synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of the column-cluster
- * persistent path (256 < N <= 512) gave up because its workgroups could not become resident (another
+ * persistent path (256 < N <= 768) gave up because its workgroups could not become resident (another
  * process holding the GPU for ~1 s) -- the state arrays are then invalid.  Run calls never clear it. */
 size_t ccvm_status_offset(int solver, int B, int N);
 /* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
