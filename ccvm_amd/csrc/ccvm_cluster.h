@@ -541,7 +541,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             __syncthreads();  // B_0: the fetch waves have staged this phase's chunks 0 and 1
-            if (lds[DEAD] != 0.0f) return;  // (looking at the flag only behind the chunks measured 2 % SLOWER)
+            // (looking at the flag only behind the chunks, or making the ring addresses below before the barrier, each
+            // measured 2 % SLOWER: the MFMA waves gain nothing from starting earlier than the fetch waves' staging)
+            if (lds[DEAD] != 0.0f) return;
             mark(seg[0]);
             // chunk c of this phase sits in buffer (b0 + c) % 3
             const float* const ab[3] = {a_rd + b0 * ABUF, a_rd + ((b0 + 1) % 3) * ABUF, a_rd + ((b0 + 2) % 3) * ABUF};
