@@ -250,6 +250,10 @@ size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
     return 2 * (size_t)cluster_count(B, N) * cluster_rows(N) * planes * round_up(N, 128) * CL_XE;
 }
+// every cluster inside one XCD and all of them on the chip at once: ceil(clusters / 8) x members <= 32 CUs
+bool cluster_resident_pinned(int B, int N) {
+    return (cluster_count(B, N) + 7) / 8 * ((N + CL_COLS - 1) / CL_COLS) <= 32;
+}
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
@@ -265,8 +269,11 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // B <= 768 is what fits at once): B = 768: 10.6 / 21.8 vs 15.5 / 27.8, but B = 512: 10.6 / 21.8 vs 9.6 / 16.0 --
     // a cluster's time per step does not shrink with a smaller batch, the tile grid's does.  So: only while the grid
     // is resident, and from B = 640 up.
+    // With 11-12 members only two clusters fit an XCD's 32 CUs; spread over the XCDs (ClusterArgs::spread: the exchange
+    // crosses the fabric, +10-14 % per step) 21 clusters x 12 = 252 workgroups still fit the chip: N = 768, B = 1000:
+    // 10.8 / 21.8 vs 15.6 / 28.0.
     const bool wide = round_up(N, 128) > CL_LDS_K;
-    const bool resident = (cluster_count(B, N) + 7) / 8 * 8 * G <= 256;
+    const bool resident = cluster_resident_pinned(B, N) || (wide && cluster_count(B, N) * G <= 256);
     if (tun.cluster < 0 && (planes == 2 || wide) && !resident) return false;
     if (tun.cluster < 0 && wide && B < 640) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
@@ -287,6 +294,8 @@ int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* q
     ca.B = B; ca.N = N; ca.ld = ld;
     ca.nclusters = cluster_count(B, N);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
+    // K > 512 and the XCD-pinned placement does not fit the chip at once while the plain one does: spread
+    ca.spread = round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N) && ca.nclusters * ca.G <= 256;
     return CCVM_OK;
 }
 
@@ -375,10 +384,11 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
-        const int G = (N + CL_COLS - 1) / CL_COLS;
-        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups), up to %d steps per launch",
-                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, (cluster_count(B, N) + 7) / 8 * 8 * G, cluster_count(B, N), G,
-                      TABLE_STEPS);
+        const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
+        const bool spread = ccvm_ld(N) > CL_LDS_K && !cluster_resident_pinned(B, N) && count * G <= 256;
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
+                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
+                      spread ? ", spread over the XCDs" : "", TABLE_STEPS);
         return CCVM_OK;
     }
     if (want_persist(N, tun)) {

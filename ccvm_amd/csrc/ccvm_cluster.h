@@ -95,6 +95,7 @@ struct ClusterArgs {
     int replay;
     int B, N, ld;
     int nclusters, G;
+    int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;             // MF: clamp of the measured amplitude
@@ -181,9 +182,13 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = a.G;
+    // Placement.  Default: blocks b, b + 8, ... share an XCD, so a cluster (consecutive indices of one XCD) keeps its
+    // exchange in one L2.  a.spread: consecutive blocks form a cluster, i.e. its members sit on all XCDs and the
+    // exchange crosses the fabric (sc1 = agent scope: still coherent) -- for member counts that do not pack into an
+    // XCD's 32 CUs (11-12 members: 2 clusters of 12 use 24 CUs per XCD, 21 clusters need 252 of the chip's 256).
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int cluster = (idx / G) * 8 + xcd;
-    const int member = idx % G;
+    const int cluster = a.spread ? blockIdx.x / G : (idx / G) * 8 + xcd;
+    const int member = a.spread ? blockIdx.x % G : idx % G;
     if (cluster >= a.nclusters) return;  // a whole cluster out of range: nobody waits for it
     const int N = a.N, ld = a.ld;
     const int col0 = member * CL_COLS;
@@ -325,7 +330,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         // Pair k of the NEXT phase's input is requested behind barrier B_max(L0 + k, 2 k - 1): its peers stored it at
         // the end of their previous phase, >= L0 chunks ago, and its registers are free -- this phase's chunks 2 k and
         // 2 k + 1 are staged behind B_(2 k - 2) and B_(2 k - 1), the latter earlier in the same interval.
-        constexpr int L0 = (NC == 3) ? 1 : 2;
+        // (three row sets: the input was stored a whole phase earlier and is requested from the phase's start: N = 640
+        // 9.55 -> 8.86 us / step against L0 = 2, and what makes clusters spread over the XCDs pay: N = 768 12.1 -> 10.8)
+        constexpr int L0 = (NSETS == 3) ? 0 : (NC == 3) ? 1 : 2;
         auto pair_behind = [](int c) {  // the pair requested behind B_c, or -1
             for (int k = 0; k < NPAIR; ++k)
                 if (((L0 + k > 2 * k - 1) ? L0 + k : 2 * k - 1) == c) return k;
@@ -753,7 +760,7 @@ void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
 
 template <int MODE>
 void launch_cluster(const ClusterArgs& a, bool adam, hipStream_t st) {
-    const int grid = ((a.nclusters + 7) / 8) * 8 * a.G;
+    const int grid = a.spread ? a.nclusters * a.G : ((a.nclusters + 7) / 8) * 8 * a.G;
     if constexpr (MODE == MODE_DL) {
         if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
         else launch_cluster_variant<MODE, false, false>(a, grid, st);

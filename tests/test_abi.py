@@ -101,10 +101,13 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (1, 1000, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 1): "ccvm::cluster_kernel<2, true, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
-        (1, 1200, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 190 x 512",
+        (1, 1200, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 250 x 512 threads (25 clusters of 10 workgroups, spread over the XCDs)",
+        (1, 1300, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 205 x 512",
         (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
-        (0, 1000, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 192 x 512",
+        (0, 1000, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 252 x 512 threads (21 clusters of 12 workgroups, spread over the XCDs)",
+        (2, 1000, 700, 1): "ccvm::cluster_kernel<2, true, 6, false> grid 231 x 512 threads (21 clusters of 11 workgroups, spread over the XCDs)",
+        (0, 1100, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 210 x 512",
         (2, 512, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 192 x 512",
         (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",
     }

@@ -84,6 +84,8 @@ def _run_oracle(kind, n, b, t, adam, seed, row_offset):
     ("pl", 641, 96, 16, None), ("langevin", 700, 1000, 20, None), ("pl", 768, 130, 12, None),
     ("dl", 513, 49, 16, None), ("dl", 640, 1000, 20, None), ("dl", 704, 100, 12, None), ("dl", 768, 1000, 16, None),
     ("mf", 640, 1000, 16, None), ("langevin", 640, 64, 12, "second_moment"), ("mf", 768, 100, 12, "add_assign"),
+    # 11-12 members, more clusters than fit XCD by XCD: spread over the XCDs (B = 1000: 21 clusters x 12 = 252)
+    ("langevin", 768, 1000, 24, None), ("dl", 700, 1000, 16, None), ("mf", 768, 1000, 12, "second_moment"),
     ("mf", 513, 33, 12, "first_moment_only"), ("pl", 700, 768, 10, "second_moment"),
     # DL: two exchanged planes (c, s), 2 K / 128 chunks per phase
     ("dl", 500, 1000, 40, None), ("dl", 257, 33, 30, None), ("dl", 320, 100, 24, None), ("dl", 384, 70, 20, None),
@@ -119,11 +121,12 @@ def test_cluster_kernel_is_what_ran(cluster):
     assert not torch.equal(a, b_) and float((a - b_).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("kind,n", [("mf", 300), ("pl", 300), ("dl", 300), ("pl", 700), ("dl", 600)])
-def test_cluster_chunking_and_sharding_are_exact(cluster, kind, n):
+@pytest.mark.parametrize("kind,n,b", [("mf", 300, 96), ("pl", 300, 96), ("dl", 300, 96), ("pl", 700, 96), ("dl", 600, 96),
+                                      ("pl", 768, 1000)])
+def test_cluster_chunking_and_sharding_are_exact(cluster, kind, n, b):
     """Chunked launches (evolution sampling, replay staging) and batch shards reproduce the one-launch,
-    unsharded run bit for bit."""
-    b, t = 96, 30
+    unsharded run bit for bit (the last case: the whole batch runs spread over the XCDs, its shards XCD by XCD)."""
+    t = 30
     adam = None if (kind == "dl" or n > 512) else _ADAMS["add_assign"]
     whole = _run_engine(kind, n, b, t, adam, 99, 0)
     parts = _run_engine(kind, n, b, t, adam, 99, 0, chunks=[1, 7, 2, 20])
@@ -214,7 +217,7 @@ def test_status_word_is_checked_at_synchronisation_points(cluster):
 
 
 @pytest.mark.parametrize("kind,adam,n", [("langevin", None, 500), ("mf", "second_moment", 500), ("dl", None, 500),
-                                         ("langevin", None, 768), ("dl", None, 640)])
+                                         ("langevin", None, 768), ("dl", None, 640), ("pl", None, 700)])
 def test_cluster_soak_is_deterministic(cluster, kind, adam, n):
     """20 000 steps at the BASELINE config-3 shape (and at K = 640 / 768), twice (one in 4096-step launches, one in
     ragged chunks): bit-identical and finite.  The exchange is the only cross-workgroup traffic in the engine: a single

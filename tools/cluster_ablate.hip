@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
     const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512
     a.nclusters = (B + crows - 1) / crows; a.G = (N + 63) / 64;
-    const int grid = (a.nclusters + 7) / 8 * 8 * a.G;
+    a.spread = getenv("CL_SPREAD") ? atoi(getenv("CL_SPREAD")) : 0;
+    const int grid = a.spread ? a.nclusters * a.G : (a.nclusters + 7) / 8 * 8 * a.G;
     unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 16 * 8); hipMemset(dbg, 0, (size_t)grid * 16 * 8);
     a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
