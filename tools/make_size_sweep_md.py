@@ -1,0 +1,43 @@
+"""profiles/rNN_size_sweep.md from gpurun_out/size_sweep_{auto,tile}.txt (developer tool; tools/size_sweep.sh)."""
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def parse(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(\w+):(\d+):(\d+)\s+RU=\w+\s+([\d.]+) us/step", line)
+        if m:
+            out[(m.group(1), int(m.group(2)), int(m.group(3)))] = float(m.group(4))
+    return out
+
+
+auto, tile = parse("gpurun_out/size_sweep_auto.txt"), parse("gpurun_out/size_sweep_tile.txt")
+flops = {"dl": 4, "mf": 2, "langevin": 2, "pl": 2}
+
+
+def path(n):
+    if n <= 256:
+        return "persistent row-owner"
+    if n <= 512:
+        return "column-cluster persistent"
+    if n <= 640:
+        return "column-cluster persistent (3 row sets, k >= 512 in registers)"
+    if n <= 768:
+        return "column-cluster persistent (3 row sets, spread over the XCDs)"
+    return "per-step tile kernel"
+
+
+print(f"# Round {tag[1:].lstrip('0')}: per-step time and fraction of the fp32 MFMA peak across problem sizes (B = 1000, 1x MI355X)\n")
+print("`tools/size_sweep.sh` = `python3 tools/time_small.py kind:N:1000 ...` (4096-step chunks of the engine, best of 5, no "
+      "profiler) with the default kernel policy and, for 256 < N <= 768, with `CCVM_AMD_KERNEL=nocluster` (last column). "
+      "Algorithmic flops per step: DL 4 N^2 B, MF / Langevin / PL 2 N^2 B; peak 157.3 TFLOP/s.\n")
+print("| solver | N | B | kernel path | us/step | TFLOP/s | frac of 157.3 | tile kernel at this size (us/step, frac) |")
+print("|---|---|---|---|---|---|---|---|")
+for (k, n, b), t in sorted(auto.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+    tf = flops[k] * n * n * b / (t * 1e-6) / 1e12
+    tl = tile.get((k, n, b))
+    extra = "" if tl is None else f"{tl:.2f}, {flops[k] * n * n * b / (tl * 1e-6) / 1e12 / 157.3:.2f}"
+    print(f"| {k} | {n} | {b} | {path(n)} | {t:.2f} | {tf:.1f} | {tf / 157.3:.2f} | {extra} |")
