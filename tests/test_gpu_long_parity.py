@@ -31,6 +31,10 @@ CASES = [
     ("config5_pl_n2000_b512_adam_pp", "pl", 2000, 512, 200, "adam", None, 3e-4, 1e-5),
     # not a BASELINE configuration: the DL solver at config 3's size (the cluster kernel's two-plane mode)
     ("extra_dl_n500_b1000", "dl", 500, 1000, 500, None, None, 3e-4, 1e-5),
+    # the cluster kernel's K = 640 (three row sets, Q's k >= 512 in registers) and K = 768 (spread over the XCDs) variants
+    ("extra_mf_n640_b1000_adam", "mf", 640, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
+    ("extra_pl_n768_b1000", "pl", 768, 1000, 400, None, None, 3e-4, 1e-5),
+    ("extra_dl_n700_b1000", "dl", 700, 1000, 400, None, None, 3e-4, 1e-5),
 ]
 
 
