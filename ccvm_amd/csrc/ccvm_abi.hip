@@ -272,10 +272,23 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // With 11-12 members only two clusters fit an XCD's 32 CUs; spread over the XCDs (ClusterArgs::spread: the exchange
     // crosses the fabric, +10-14 % per step) 21 clusters x 12 = 252 workgroups still fit the chip: N = 768, B = 1000:
     // 10.8 / 21.8 vs 15.6 / 28.0.
+    // Larger batches above K = 512 run in rounds of 8 x floor(32 / G) clusters against the tile kernel's waves of 256
+    // workgroups (N = 640, Langevin: 8.9 us per round vs 12.1 per wave; B = 1500: 2 rounds 18.2 vs 1 wave 13.1; B = 2000:
+    // 2 rounds 18.0 vs 2 waves 24.3, MF 19.2 vs 28.5, DL 36.3 vs 44.9; B = 4000: 4 rounds 36.0 vs 3 waves 36.3; N = 768,
+    // B = 2000: 3 rounds 31.8 vs 2 waves 27.9): the cluster path is taken when rounds < 1.3 x waves.
     const bool wide = round_up(N, 128) > CL_LDS_K;
-    const bool resident = cluster_resident_pinned(B, N) || (wide && cluster_count(B, N) * G <= 256);
-    if (tun.cluster < 0 && (planes == 2 || wide) && !resident) return false;
-    if (tun.cluster < 0 && wide && B < 640) return false;
+    const int count = cluster_count(B, N);
+    const bool resident = cluster_resident_pinned(B, N) || (wide && count * G <= 256);
+    if (tun.cluster < 0 && planes == 2 && !wide && !resident) return false;
+    if (tun.cluster < 0 && wide) {
+        if (B < 640) return false;
+        if (!resident) {
+            const int per_round = 8 * (32 / G);
+            const int rounds = (count + per_round - 1) / per_round;
+            const int waves = (((B + BM - 1) / BM) * ((N + BN - 1) / BN) + 255) / 256;
+            if (10 * rounds >= 13 * waves) return false;
+        }
+    }
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:

@@ -84,6 +84,8 @@ def _run_oracle(kind, n, b, t, adam, seed, row_offset):
     ("pl", 641, 96, 16, None), ("langevin", 700, 1000, 20, None), ("pl", 768, 130, 12, None),
     ("dl", 513, 49, 16, None), ("dl", 640, 1000, 20, None), ("dl", 704, 100, 12, None), ("dl", 768, 1000, 16, None),
     ("mf", 640, 1000, 16, None), ("langevin", 640, 64, 12, "second_moment"), ("mf", 768, 100, 12, "add_assign"),
+    # K = 640 in rounds of 24 clusters
+    ("pl", 600, 2000, 6, None), ("dl", 640, 2100, 5, None),
     # 11-12 members, more clusters than fit XCD by XCD: spread over the XCDs (B = 1000: 21 clusters x 12 = 252)
     ("langevin", 768, 1000, 24, None), ("dl", 700, 1000, 16, None), ("mf", 768, 1000, 12, "second_moment"),
     ("mf", 513, 33, 12, "first_moment_only"), ("pl", 700, 768, 10, "second_moment"),
