@@ -1,5 +1,5 @@
-// Column-cluster persistent kernel for the mid-size regime (256 < N <= 512): a whole chunk of time
-// steps in ONE launch for the one-stream solvers (MF, Langevin / pumped Langevin, Adam variants).
+// Column-cluster persistent kernel for the mid-size regime (256 < N <= 768): a whole chunk of time
+// steps in ONE launch, every solver (DL, MF, Langevin / pumped Langevin) and Adam variant.
 //
 // Why: at N = 500, B = 1000 a per-step launch of the tile kernel takes 8.2 us for 3.1 us of MFMA work
 // (tools/ablate_mid.hip): the kernel boundary (~1.8 us), the first tiles' fill, the store drain and a
@@ -7,21 +7,22 @@
 // persistent row-owner kernel (ccvm_persist.h) cannot take over: above N = 256 a workgroup can hold
 // neither Q's fragments in registers nor all of Q in LDS.
 //
-// Here a CLUSTER of G = ceil(N / 64) workgroups owns 32 batch rows for the whole launch.  Member m
-// keeps the Q panel of its 64 output columns resident in LDS (K x 64 floats, <= 128 KB, loaded once
-// per launch), owns the elements (row, its 64 columns) in registers, and per step needs the cluster's
-// full GEMM input rows (32 x K), of which the other members produce 7/8.
+// Here a CLUSTER of G = ceil(N / 64) workgroups owns 32 batch rows (48 above K = 512) for the whole
+// launch.  Member m keeps the Q panel of its 64 output columns resident (k < 512 in LDS: <= 128 KB; k >= 512,
+// for K = 640 / 768, as B fragments in the MFMA waves' registers; loaded once per launch), owns the
+// elements (row, its 64 columns) in registers, and per step needs the cluster's full GEMM input rows
+// (rows x K; DL: two planes, c and s), of which the other members produce (G - 1) / G.
 //
 // Exchange: flag in data.  Every exchanged element is an 8-byte packet {value, tag} (tag = global step
 // number of the GEMM it feeds + 1; buffers zeroed before the call), written by ONE lane with ONE 8-byte
-// sc1 (write-through) store and read as half of a 16-byte sc1 load: a reader that finds the expected tag
-// has the value stored with it (gfx950 inter-workgroup rules, MI355X_MICROARCH.md, visibility: sc1
-// stores / sc1 loads, no cached copies in between).  No drain, no counter, no poll: the hand-off chain
-// is store -> load instead of store -> drain -> counter -> poll -> load (round 2's first version:
-// three memory round trips, ~2.7 us, longer than a phase).  Ping-pong buffers (input of even / odd steps);
-// a member publishes input j + 1 only after it has consumed input j from every member, so nobody
-// overwrites input j (with j + 2) while anybody still reads it, and every stale tag a reader can meet is
-// SMALLER than the one it waits for (min over the tags == expected  <=>  everything arrived).
+// sc1 (write-through, agent scope) store and read as half of a 16-byte sc1 load: a reader that finds the
+// expected tag has the value stored with it (gfx950 inter-workgroup rules, MI355X_MICROARCH.md,
+// visibility).  No drain, no counter, no poll: the hand-off chain is store -> load instead of
+// store -> drain -> counter -> poll -> load (round 2's first version: three memory round trips, ~2.7 us,
+// longer than a phase).  Ping-pong buffers (input of even / odd steps); a member publishes input j + 1
+// only after it has consumed input j from every member, so nobody overwrites input j (with j + 2) while
+// anybody still reads it, and every stale tag a reader can meet is SMALLER than the one it waits for
+// (min over the tags == expected  <=>  everything arrived).
 //
 // Roles.  512 threads: waves 0-3 (one per SIMD) do nothing but MFMAs, LDS operand reads, the update and
 // the publish stores; waves 4-7 (their SIMD siblings) fetch the exchanged rows, check the tags (bounded
@@ -29,26 +30,30 @@
 // one-role version: issuing the exchange loads (64 B/clk per CU through the texture path: 32-64 KB per
 // phase) blocked the issuing wave for 400-1100 cycles per phase, the staging and its barrier another
 // ~700, all of it with the matrix pipe idle; a sibling wave's VMEM / LDS issue and its waiting cost the
-// MFMA wave nothing (only its VALU instructions do: tools/coissue.hip), so the fetch wave hides all of
-// it except ~60 VALU instructions per phase.
-// Latency hiding: the 32 rows are TWO independent row sets of 16 (v_mfma_f32_16x16x4_f32 tiles);
-// phases alternate between the sets, so a set's new input has a whole phase of the other set to travel.
+// MFMA wave nothing (only its VALU instructions do: tools/coissue.hip; they are kept to a v_min3_u32 per
+// 16 bytes and the staging moves).
+// Latency hiding: the rows are two (K <= 512) or three independent row sets of 16 (v_mfma_f32_16x16x4_f32
+// tiles); PHASES cycle through the sets, so a set's new input has the other sets' phases to travel.
 //
-// Operand ring: A chunks of 128 k through three LDS buffers, chunk n of the launch (KCH per phase) in
-// buffer n % 3.  Barrier B_c precedes chunk c of a phase.  Fetch waves: after B_0 .. B_(KCH-3) stage
-// chunks 2 .. KCH-1 of this phase, after B_(KCH-2) issue the next phase's loads (its peers stored them at
-// the end of their previous phase, KCH - 1 chunks ago), after B_(KCH-1) check the tags and stage the next
-// phase's chunks 0 and 1 (their buffers: chunks KCH-3 / KCH-2 of this phase, done) while the MFMA waves run
-// the last chunk and the update.  So chunk c + 1 is always complete when chunk c starts (its operands
-// are read in the issue shadow of chunk c's MFMAs).
+// Operand ring: A chunks of 128 k through three LDS buffers, chunk n of the launch in buffer n % 3; a
+// phase has NC = K / 128 chunks (DL: 2 K / 128: plane c, then plane s, against the same panel).  Barrier
+// B_c precedes chunk c.  Fetch waves: behind B_c they stage chunk c + 2 (its buffer held chunk c - 1), so
+// chunk c + 1 is always complete when chunk c starts (the MFMA waves read operands half a chunk ahead, in
+// the issue shadow of the MFMAs); they request the next phase's input in PAIRS of chunks (8 loads per
+// wave: never more between two barriers than a chunk of MFMAs covers), pair k behind B_max(L0 + k, 2 k - 1),
+// and behind the last barrier check pair 0 and stage the next phase's chunks 0 and 1 while the MFMA waves
+// run the last chunk and the update.
 //
-// Deadlock freedom does not need the whole grid resident: workgroups are dispatched in order, a
-// cluster's members are consecutive in their XCD's dispatch order (blocks b, b + 8, ... share an XCD:
-// speed only), so at most one cluster per XCD is ever partially resident and every complete cluster
-// runs to the end of the launch without waiting for anything unplaced.  Every spin is bounded all the
-// same: on a timeout the workgroup sets the launch's status word and leaves (the host raises).
+// Placement and deadlock freedom: blocks b, b + 8, ... share an XCD, a cluster is G consecutive indices of
+// one XCD (its exchange stays in that XCD's L2); with 11-12 members, when the clusters do not pack XCD by
+// XCD but fit the chip, G consecutive blocks (members on all XCDs, exchange over the fabric).  Residency
+// of the whole grid is not needed: workgroups are dispatched in order, so at most one cluster per XCD is
+// ever partially resident and every complete cluster runs to the end of the launch without waiting for
+// anything unplaced (larger batches run in rounds).  Every spin is bounded all the same: on a timeout the
+// fetch wave sets the launch's status word and an LDS flag, the workgroup leaves behind its next barrier
+// (the host raises).
 //
-// Per MFMA wave: 16 of the member's 64 columns, both row sets, full K.  MFMA t of a chunk takes
+// Per MFMA wave: 16 of the member's 64 columns, every row set, full K.  MFMA t of a chunk takes
 // k = 128 c + 32 g + t for lane group g, so a lane's 32 operands of a chunk are contiguous: 8
 // ds_read_b128 per operand and chunk.  Conflict-free LDS image for ds_read_b128 (MI355X_MICROARCH.md,
 // LDS: four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32; bank row = 16 slots
