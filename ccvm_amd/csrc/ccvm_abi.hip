@@ -102,6 +102,7 @@ struct Tuning {
     bool xcd = true;
     int xcd_xc = 0;      // 0: choose by L2 footprint
     int persist_ru = 0;  // 0: choose by batch size
+    int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
 };
 
 Tuning read_tuning() {
@@ -117,6 +118,10 @@ Tuning read_tuning() {
     if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
         if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
+    // CCVM_AMD_FAULT=cluster_drop: the cluster path launches without its last 8 workgroups, so the last member of
+    // up to 8 clusters never runs and their peers' bounded waits must give up (status word, ~1 s): the error path
+    // of tests/test_gpu_cluster.py -- never set in production
+    if (const char* e = std::getenv("CCVM_AMD_FAULT")) t.cluster_drop = !std::strcmp(e, "cluster_drop") ? 8 : 0;
     return t;
 }
 
@@ -295,8 +300,9 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
 // [exchange buffer 0][exchange buffer 1][status word].  Zeroes the exchange buffers (once per call: the tags are
 // global step numbers, unique across the launches of a call).
 int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
-                 const ccvm_noise* nz, float* table, void* area, hipStream_t st, int planes = 1) {
+                 const ccvm_noise* nz, float* table, void* area, hipStream_t st, const Tuning& tun, int planes = 1) {
     std::memset(&ca, 0, sizeof(ca));
+    ca.drop = tun.cluster_drop;
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
     const size_t xb = cluster_exchange_bytes(B, N, planes);
     ca.xb0 = static_cast<float*>(area);
@@ -502,7 +508,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
-        if (cluster_base(ca, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, 2))
+        if (cluster_base(ca, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 2))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = c; ca.x1 = s;
         ca.in_scale = a.in_scale; ca.in_shift = a.in_shift;
@@ -686,7 +692,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
         const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
-        if (cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st))
+        if (cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st, tun))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = mu; ca.x1 = sigma; ca.xt = mu_tilde_out;
         ca.in_scale = (float)(ul / S_eff); ca.in_shift = (float)up; ca.S = (float)S_eff; ca.s_cols = s_cols;
@@ -882,7 +888,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (want_cluster(B, N, tun, MODE_LANGEVIN, use_adam)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         ClusterArgs ca;
-        if (cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st))
+        if (cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = c;
         ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.s_cols = s_cols;

@@ -75,7 +75,9 @@ constexpr int CL_KC = 128;      // K chunk staged through LDS per barrier
 constexpr int CL_MIN_N = 257, CL_MAX_N = 768;
 constexpr int CL_LDS_K = 512;   // k < 512 of a member's panel lives in LDS, the rest (K = 640, 768) in the MFMA waves' registers
 constexpr int CL_THREADS = 512; // 4 MFMA waves + 4 fetch waves
-constexpr unsigned CL_SPIN_LIMIT = 1u << 19;  // fetch retries, ~2 us each: ~1 s
+constexpr unsigned CL_SPIN_LIMIT = 1u << 22;  // fetch retries, ~0.3 us each (measured: 2^19 gave up after 0.16 s): ~1.2 s.
+                                              // In rounds a partially placed cluster waits for a whole launch of another one
+                                              // (4096 steps x <= 22 us = 90 ms): the limit must stay well above that.
 constexpr unsigned CL_XE = 8;   // bytes per exchanged element: {value, tag}
 
 struct ClusterArgs {
@@ -101,6 +103,7 @@ struct ClusterArgs {
     int B, N, ld;
     int nclusters, G;
     int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
+    int drop;            // fault injection (tests only): this many workgroups are left out of the launch
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;             // MF: clamp of the measured amplitude
@@ -765,7 +768,7 @@ void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
 
 template <int MODE>
 void launch_cluster(const ClusterArgs& a, bool adam, hipStream_t st) {
-    const int grid = a.spread ? a.nclusters * a.G : ((a.nclusters + 7) / 8) * 8 * a.G;
+    const int grid = (a.spread ? a.nclusters * a.G : ((a.nclusters + 7) / 8) * 8 * a.G) - a.drop;
     if constexpr (MODE == MODE_DL) {
         if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
         else launch_cluster_variant<MODE, false, false>(a, grid, st);

@@ -218,6 +218,22 @@ def test_status_word_is_checked_at_synchronisation_points(cluster):
     assert dl._status is not None                    # every solver's workspace carries the status word
 
 
+def test_bounded_waits_give_up_instead_of_hanging(monkeypatch):
+    """Fault injection (CCVM_AMD_FAULT=cluster_drop: the launch omits its last 8 workgroups, so the last member of
+    the last clusters never publishes): the peers' fetch waves exhaust their bounded retries (~1 s), the workgroups
+    leave, the launch ENDS, and the engine raises at its next synchronisation point; the next run is unaffected."""
+    from ccvm_amd import _lib
+
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    traj = _run_engine("langevin", 500, 1000, 3, None, 21, 0)
+    with pytest.raises(_lib.EngineError, match="cluster kernel timed out"):
+        traj.compact("c")
+    monkeypatch.delenv("CCVM_AMD_FAULT")
+    good = _run_engine("langevin", 500, 1000, 3, None, 21, 0)
+    assert bool(torch.isfinite(good.compact("c")).all())
+
+
 @pytest.mark.parametrize("kind,adam,n", [("langevin", None, 500), ("mf", "second_moment", 500), ("dl", None, 500),
                                          ("langevin", None, 768), ("dl", None, 640), ("pl", None, 700)])
 def test_cluster_soak_is_deterministic(cluster, kind, adam, n):

@@ -38,7 +38,9 @@ int main(int argc, char** argv) {
     const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512
     a.nclusters = (B + crows - 1) / crows; a.G = (N + 63) / 64;
     a.spread = getenv("CL_SPREAD") ? atoi(getenv("CL_SPREAD")) : 0;
-    const int grid = a.spread ? a.nclusters * a.G : (a.nclusters + 7) / 8 * 8 * a.G;
+    // CL_DROP=1: launch without the last 8 workgroups (the last member of the last 8 clusters never runs): exercises the
+    // bounded waits' give-up path -- expect "(SPIN LIMIT HIT)" after ~1-2 s per launch, not a hang
+    const int grid = (a.spread ? a.nclusters * a.G : (a.nclusters + 7) / 8 * 8 * a.G) - (getenv("CL_DROP") ? 8 : 0);
     unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 16 * 8); hipMemset(dbg, 0, (size_t)grid * 16 * 8);
     a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
