@@ -40,10 +40,13 @@ class EngineUnavailable(RuntimeError):
     """The HIP engine cannot be used (library not built / no MI355X visible)."""
 
 
+RUN_WS_PADDED = 1  # ccvm_noise.flags: the workspace's scratch arrays still have zero padding (see ccvm_hip.h)
+
+
 class Noise(Structure):
     _fields_ = [
         ("mode", c_int32),
-        ("reserved", c_int32),
+        ("flags", c_int32),
         ("seed", c_uint64),
         ("row_offset", c_int64),
         ("w0", c_void_p),

@@ -466,7 +466,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     const size_t state = (size_t)ccvm_rows(B) * ld;
     float* bufc[2] = {c, static_cast<float*>(ws)};
     float* bufs[2] = {s, static_cast<float*>(ws) + state};
-    if (nsteps > 0) {
+    if (nsteps > 0 && !(nz->flags & CCVM_RUN_WS_PADDED)) {
         // keep the padding of the scratch buffers zero (rows >= B, cols >= N are never written)
         if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
@@ -717,7 +717,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
 
     float* mt[2] = {static_cast<float*>(ws), static_cast<float*>(ws) + state};
     float* carry = static_cast<float*>(ws) + 2 * state;  // this step's normals (fused mode)
-    if (hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
+    if (!(nz->flags & CCVM_RUN_WS_PADDED) && hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     // measured amplitude of the first step of this chunk (mf_solver.py:551-554)
@@ -807,7 +807,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     // workspace: [c' = exchange buffer 0][exchange buffer 1][column sums of Q][schedule table][cluster sync]
     const size_t state = (size_t)ccvm_rows(B) * ld;
     float* buf[2] = {c, static_cast<float*>(ws)};
-    if (hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
+    if (!(nz->flags & CCVM_RUN_WS_PADDED) && hipMemsetAsync(ws, 0, 2 * state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;

@@ -367,6 +367,7 @@ class Trajectories:
             self.ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=self.device)
             off = self.lib.ccvm_status_offset(self._SOLVER_ID[kind], self.b, self.n)
             self._status = self.ws[off:off + 4] if off != ctypes.c_size_t(-1).value else None
+            self._ws_padded = False  # set by the first completed run call (ccvm_hip.h: CCVM_RUN_WS_PADDED)
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
 
     def _set_saturation(self, cp, S):
@@ -397,6 +398,8 @@ class Trajectories:
 
     def _run(self, step0, k, nz):
         lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
+        if self._ws_padded:  # this object zero-filled the workspace and only its own run calls have used it since
+            nz.flags |= _lib.RUN_WS_PADDED
         tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
         if self.kind == "dl":
             rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,
@@ -409,6 +412,7 @@ class Trajectories:
             rc = lib.ccvm_langevin_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), *common,
                                        ctypes.byref(self.cparams), ctypes.byref(self.adam), *tail)
         _lib.check(rc, f"ccvm_{self.kind}_run")
+        self._ws_padded = True
 
     # ------------------------------------------------------------------ #
     def clamp(self, name, lo, hi):

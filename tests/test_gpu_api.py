@@ -371,3 +371,26 @@ def test_staged_problem_cache_never_serves_stale_data():
     assert torch.allclose(e2, want, rtol=1e-5, atol=1e-5) and not torch.allclose(e1, e2)
     q2 = q.clone()                                                  # equal values, different object
     assert engine.device_problem(q2, v) is not engine.device_problem(q, v)
+
+
+def test_workspace_padded_flag_skips_the_memset_without_changing_results():
+    """CCVM_RUN_WS_PADDED (ccvm_noise.flags): chunked calls that skip re-zeroing the scratch arrays give the same
+    trajectories bit for bit as one call, on every kernel path, and the engine sets the flag from its second call on."""
+    from ccvm_amd import _lib, engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    for kind, n, b in (("dl", 300, 40), ("dl", 1000, 64), ("mf", 600, 1300), ("langevin", 900, 50), ("dl", 100, 30)):
+        q, v, _ = scaled_qv(n, kind if kind != "langevin" else "langevin")
+        p = dict(EXAMPLE_PARAMS[kind], g=0.05 if kind == "dl" else 0.01)
+        out = []
+        for chunks in ([12], [1, 5, 6]):
+            prob = engine.DeviceProblem(q, v)
+            traj = engine.Trajectories(prob, b, kind, 12, p, (0.0, 1.0), engine.NoiseSpec(mode="fused", seed=9))
+            assert traj._ws_padded is False
+            for k in chunks:
+                traj.advance(k)
+            assert traj._ws_padded is True
+            out.append({name: traj.compact(name).cpu() for name in traj.state})
+        for name in out[0]:
+            assert torch.equal(out[0][name], out[1][name]), (kind, n, name)
+    assert _lib.RUN_WS_PADDED == 1
