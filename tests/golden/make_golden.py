@@ -241,39 +241,54 @@ def asgd_cases():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
-def larger_n_cases():
-    """The reference on a problem larger than its shipped files (N = 96, dense synthetic, written to a
+def larger_n_cases(n=96, batch=24, iterations=25):
+    """The reference on a problem larger than its shipped files (N = 96 / 300 / 600, dense synthetic, written to a
     temporary .in file the reference parses itself): pins the oracle beyond N = 20 -- other einsum
-    blocking, several K chunks / column groups of the engine's small-N kernel."""
+    blocking, several K chunks / column groups of the engine's small-N kernel (96), the column-cluster
+    kernel (300: K = 384; 600: K = 640, three row sets)."""
     import tempfile
 
-    n = 96
-    g = torch.Generator().manual_seed(96)
+    g = torch.Generator().manual_seed(n)
     a = torch.randn(n, n, generator=g) * 5
     q_file = ((a + a.T) / 2 ** 0.5).double().numpy()   # maximisation form, as stored in .in files
     v_file = (torch.randn(n, generator=g) * 17).double().numpy()
     with tempfile.TemporaryDirectory() as tmp:
-        path = os.path.join(tmp, "synthetic096-100-96.in")
+        path = os.path.join(tmp, f"synthetic{n:03d}-100-{n}.in")
         with open(path, "w") as fh:
-            fh.write("\t".join([str(n), "1.0", "1.0", "True", "0.0", "0.0", "96", "0"]) + "\n")
+            fh.write("\t".join([str(n), "1.0", "1.0", "True", "0.0", "0.0", str(n), "0"]) + "\n")
             fh.write("\t".join(repr(float(x)) for x in v_file) + "\n")
             for row in q_file:
                 fh.write("\t".join(repr(float(x)) for x in row) + "\n")
         inst = ProblemInstance(instance_type="test", file_path=path, device="cpu")
-        store = {"q_matrix": inst.q_matrix.numpy().copy(), "v_vector": inst.v_vector.numpy().copy()}
         manifest = {"cases": {}, "instance": {"problem_size": n, "optimal_sol": inst.optimal_sol,
                                               "best_sol": inst.best_sol, "name": inst.name}}
+        if n <= 96:
+            store = {"q_matrix": inst.q_matrix.numpy().copy(), "v_vector": inst.v_vector.numpy().copy()}
+        else:  # 1.4 MB at N = 600: not stored, regenerated from the seed by tests/golden_util.py and checked
+            store = {}
+            qd, vd = inst.q_matrix.double(), inst.v_vector.double()
+            assert torch.equal(inst.q_matrix, torch.from_numpy(-q_file).float())
+            assert torch.equal(inst.v_vector, torch.from_numpy(-v_file).float())
+            manifest["instance"]["generated"] = {
+                "seed": n,
+                "recipe": "g = torch.Generator().manual_seed(seed); a = torch.randn(n, n, generator=g) * 5; "
+                          "q_file = ((a + a.T) / 2 ** 0.5).double(); v_file = (torch.randn(n, generator=g) * 17).double(); "
+                          "q_matrix = (-q_file).float(); v_vector = (-v_file).float()   (what the reference's parser "
+                          "returns for the .in file make_golden.py wrote; the arrays themselves are not stored: 1.4 MB "
+                          "at N = 600)",
+                "q_checksum": [float(qd.sum()), float(qd.abs().sum()), float(qd[0, 1]), float(qd[-1, -2])],
+                "v_checksum": [float(vd.sum()), float(vd.abs().sum())]}
         rel = os.path.relpath(path, REFERENCE)
         for kind in SOLVERS:
             for adam in (None, "adamA") if kind != "dl" else (None,):
-                name = f"{kind}_T25" + (f"_{adam}" if adam else "")
-                arrays, meta = run_case(kind, rel, 25, adam=adam, batch=24)
+                name = f"{kind}_T{iterations}" + (f"_{adam}" if adam else "")
+                arrays, meta = run_case(kind, rel, iterations, adam=adam, batch=batch)
                 for k, v in arrays.items():
                     store[f"{name}/{k}"] = v
                 manifest["cases"][name] = meta
-                print("N=96", name, meta["best_objective_value"])
-    np.savez_compressed(os.path.join(OUT, "synthetic096.npz"), **store)
-    with open(os.path.join(OUT, "synthetic096.json"), "w") as fh:
+                print(f"N={n}", name, meta["best_objective_value"])
+    np.savez_compressed(os.path.join(OUT, f"synthetic{n:03d}.npz"), **store)
+    with open(os.path.join(OUT, f"synthetic{n:03d}.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
@@ -281,6 +296,10 @@ def main():
     torch.set_num_threads(1)  # fixtures independent of intra-op partitioning
     if "--only-larger-n" in sys.argv:
         larger_n_cases()
+        return
+    if "--only-cluster-n" in sys.argv:  # the sizes the column-cluster kernel serves
+        larger_n_cases(300, batch=12, iterations=20)
+        larger_n_cases(600, batch=12, iterations=16)
         return
     if "--only-asgd" in sys.argv:
         asgd_cases()

@@ -6,7 +6,9 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TAGS = ("test020", "tuningH020", "synthetic096")  # synthetic096: the reference on an N = 96 dense instance
+# synthetic096 / 300 / 600: the reference on dense synthetic instances (300, 600: the column-cluster kernel's sizes; their
+# Q and V are regenerated from the recorded seed instead of stored, and checked against the recorded checksums)
+TAGS = ("test020", "tuningH020", "synthetic096", "synthetic300", "synthetic600")
 
 
 class Golden:
@@ -18,10 +20,30 @@ class Golden:
         self.instance = self.manifest["instance"]
         self.cases = self.manifest["cases"]
 
+    def _generated(self):
+        """(q_matrix, v_vector) of a synthetic instance from its recorded seed (see the manifest's recipe)."""
+        gen = self.instance["generated"]
+        n = self.instance["problem_size"]
+        g = torch.Generator().manual_seed(gen["seed"])
+        a = torch.randn(n, n, generator=g) * 5
+        q = (-((a + a.T) / 2 ** 0.5).double()).float()
+        v = (-(torch.randn(n, generator=g) * 17).double()).float()
+        qd, vd = q.double(), v.double()
+        got = [float(qd.sum()), float(qd.abs().sum()), float(qd[0, 1]), float(qd[-1, -2]), float(vd.sum()),
+               float(vd.abs().sum())]
+        want = gen["q_checksum"] + gen["v_checksum"]  # (sums: up to the summation order)
+        assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(got, want)), \
+            f"{self.tag}: torch's CPU generator no longer reproduces the instance the fixture was made from"
+        return q, v
+
     def q(self):
+        if "q_matrix" not in self.arrays.files:
+            return self._generated()[0]
         return torch.from_numpy(self.arrays["q_matrix"].copy())
 
     def v(self):
+        if "v_vector" not in self.arrays.files:
+            return self._generated()[1]
         return torch.from_numpy(self.arrays["v_vector"].copy())
 
     def scaled(self, kind):

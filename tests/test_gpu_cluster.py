@@ -258,3 +258,36 @@ def test_trajectories_do_not_interact_at_full_size(cluster):
     lo = _run_engine("pl", n, 500, t, None, 11, 0).compact("c")
     hi = _run_engine("pl", n, 500, t, None, 11, 500).compact("c")
     assert torch.equal(whole, torch.cat([lo, hi]))
+
+
+def _reference_cases():
+    from golden_util import golden
+
+    return [(tag, name) for tag in ("synthetic300", "synthetic600") for name in golden(tag).cases]
+
+
+@pytest.mark.parametrize("tag,case", _reference_cases())
+def test_cluster_kernel_matches_the_reference_itself(cluster, tag, case):
+    """The reference's OWN output (tests/golden/synthetic300 / synthetic600: every solver and Adam variant on dense
+    N = 300 / 600 instances, made by make_golden.py --only-cluster-n from the reference in the build container)
+    against the cluster kernel through the public API in replay mode: K = 384 with two row sets, K = 640 with three
+    and the panel's k >= 512 in registers."""
+    import math
+
+    from golden_util import check_noise_checksum, golden
+    from test_gpu_parity import ATOL_OBJ, ATOL_X, _run_case
+
+    g = golden(tag)
+    meta = g.cases[case]
+    n = g.instance["problem_size"]
+    check_noise_checksum(meta, n, meta["batch"])
+    sol = _run_case(g, meta)
+    gate = math.sqrt(max(n, 20) / 20.0)
+    for field in g.fields(case):
+        want = g.out(case, field)
+        got = sol.objective_values if field == "objective_values" else sol.variables[field]
+        scale = max(1.0, float(want.abs().max()) / (150.0 if field == "objective_values" else 1.0))
+        tol = (ATOL_OBJ if field == "objective_values" else ATOL_X) * gate * scale
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol, f"{tag}/{case}/{field}: max abs err {err:.3e} > {tol:.1e}"
+    assert abs(sol.best_objective_value - meta["best_objective_value"]) <= 1e-5 * abs(meta["best_objective_value"]) + 1e-4
