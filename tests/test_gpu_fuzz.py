@@ -1,7 +1,7 @@
 """Seeded random sweep of the engine against the oracle (fused generator): awkward problem sizes
 (around every tile / shape boundary), tiny and ragged batches, odd shard offsets, random chunking,
 every solver and Adam variant, fused and replayed noise, non-default bounds / g / pump ramp.  One
-process, 96 cases by default (CCVM_FUZZ_SEED / CCVM_FUZZ_COUNT select another sweep), each finishes
+process, 128 cases by default (CCVM_FUZZ_SEED / CCVM_FUZZ_COUNT select another sweep), each finishes
 in well under a second."""
 import math
 import os
@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SIZES = [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 96, 100, 127, 128, 129, 144, 200, 255, 256,
-         257, 300, 383, 385, 511, 513, 640]
+         257, 300, 383, 385, 449, 511, 513, 576, 640, 641, 700, 768]
 BATCHES = [1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 100, 257, 1000]
 ADAMS = [None,
          {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False},
@@ -22,7 +22,7 @@ ADAMS = [None,
 ATOL_X = 5e-4
 
 
-def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "96")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
+def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "128")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
     rng = random.Random(seed)
     out = []
     for _ in range(count):
@@ -38,19 +38,25 @@ def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "96")), seed=int(os.envir
         g = rng.choice([None, None, 0.1, 0.002])      # __call__(g=...) of DL / MF
         ramp = rng.random() < 0.7                     # pump_rate_flag
         vec_s = kind != "dl" and rng.random() < 0.35  # per-variable saturation (1-D tensor S)
+        force_cluster = rng.random() < 0.4           # CCVM_AMD_KERNEL=cluster: the cluster kernel wherever it exists
         out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, bounds, g, ramp,
-                    vec_s))
+                    vec_s, force_cluster))
     return out
 
 
-@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp,vec_s", _cases())
-def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s):
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp,vec_s,force_cluster", _cases())
+def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s,
+                                             force_cluster, monkeypatch):
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
     from oracle import ccvm_oracle as oracle
     from oracle.noise_ref import FusedNoise
 
     adam = ADAMS[adam_i]
+    if force_cluster:
+        monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+    else:
+        monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     q, v, _ = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
     if vec_s:
