@@ -9,12 +9,14 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/ccvm_hip.h"
 #include "ccvm_cluster.h"
 #include "ccvm_kernels.h"
 #include "ccvm_persist_launch.h"
 #include "ccvm_schedule.h"
+#include "ccvm_slab.h"
 
 using namespace ccvm;
 
@@ -103,6 +105,9 @@ struct Tuning {
     int xcd_xc = 0;      // 0: choose by L2 footprint
     int persist_ru = 0;  // 0: choose by batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
+    int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
+    int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
+    ChipGeometry chip{0, 0};  // 0: ask the device
 };
 
 Tuning read_tuning() {
@@ -111,6 +116,16 @@ Tuning read_tuning() {
         t.force_tile = !std::strcmp(e, "tile");
         if (!std::strcmp(e, "cluster")) t.cluster = 1;
         if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = 0;
+        if (!std::strcmp(e, "slab")) t.slab = 1;
+        if (!std::strcmp(e, "noslab") || t.force_tile) t.slab = 0;
+    }
+    if (const char* e = std::getenv("CCVM_AMD_SLAB_CGRP")) t.slab_cgrp = std::atoi(e);
+    if (const char* e = std::getenv("CCVM_AMD_SLAB_RG")) t.slab_rg = std::atoi(e);
+    // CCVM_AMD_GEOMETRY=cus,xcds: the launch policy plans for this chip instead of the device's (tests of the policy
+    // functions, and a way to keep a solve inside a CU-masked or partitioned share of the chip)
+    if (const char* e = std::getenv("CCVM_AMD_GEOMETRY")) {
+        int cus = 0, xcds = 0;
+        if (std::sscanf(e, "%d,%d", &cus, &xcds) == 2 && cus > 0 && xcds > 0) t.chip = ChipGeometry{cus, xcds};
     }
     if (const char* e = std::getenv("CCVM_AMD_KS"))
         if (e[0] == '1' || e[0] == '2') t.ks = e[0] - '0';
@@ -125,12 +140,41 @@ Tuning read_tuning() {
     return t;
 }
 
+// The chip as the launch policies see it: CU and XCD counts, asked ONCE per device (hipDeviceAttributeMultiprocessorCount,
+// hipDeviceAttributeNumberOfXccs; immutable device properties behind a mutex, no other global state).  Without a
+// device (ccvm_describe_launch on a host without a GPU) the nominal MI355X in SPX mode.  CCVM_AMD_GEOMETRY overrides.
+constexpr ChipGeometry NOMINAL_CHIP{256, 8};
+ChipGeometry device_geometry() {
+    static std::mutex mu;
+    static ChipGeometry cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return NOMINAL_CHIP;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache[dev].cus == 0) {
+        int cus = 0, xcds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            return NOMINAL_CHIP;
+        }
+        if (hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || xcds <= 0) {
+            (void)hipGetLastError();
+            xcds = 1;  // unknown: one L2 domain (placement is a speed matter only)
+        }
+        cache[dev] = ChipGeometry{cus, xcds};
+    }
+    return cache[dev];
+}
+ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : device_geometry(); }
+
 // Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
 // a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).
 int choose_ks(int B, int N, const Tuning& tun) {
     if (tun.ks) return tun.ks;
     const int tiles = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
-    return tiles <= 128 ? 2 : 1;
+    return tiles <= chip_of(tun).cus / 2 ? 2 : 1;
 }
 
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
@@ -142,7 +186,7 @@ void set_grid(StepArgs& a, const Tuning& tun) {
     a.ncb = (a.N + BN / ks - 1) / (BN / ks);
     a.xr = a.xc = 0;
     const int total = a.nrb * a.ncb;
-    if (total % 8 == 0 && tun.xcd) {
+    if (total % 8 == 0 && tun.xcd && chip_of(tun).xcds == 8) {  // (a bijection either way: speed only)
         const int per = total / 8;
         long best = -1;
         for (int xc = 1; xc <= a.ncb; ++xc) {
@@ -255,13 +299,28 @@ size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
     return 2 * (size_t)cluster_count(B, N) * cluster_rows(N) * planes * round_up(N, 128) * CL_XE;
 }
-// every cluster inside one XCD and all of them on the chip at once: ceil(clusters / 8) x members <= 32 CUs
-bool cluster_resident_pinned(int B, int N) {
-    return (cluster_count(B, N) + 7) / 8 * ((N + CL_COLS - 1) / CL_COLS) <= 32;
+// the exchange area of a workspace serves whichever persistent path a call takes
+size_t exchange_bytes(int B, int N, int planes) {
+    return std::max(cluster_exchange_bytes(B, N, planes), slab_exchange_bytes(B, N, planes));
+}
+// every cluster inside one XCD and all of them on the chip at once: ceil(clusters / XCDs) x members <= CUs per XCD
+bool cluster_resident_pinned(int B, int N, const ChipGeometry& chip) {
+    return (cluster_count(B, N) + chip.xcds - 1) / chip.xcds * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus / chip.xcds;
+}
+// K > 512 and the XCD-pinned placement does not fit the chip at once while the plain one does: spread
+bool cluster_spread(int B, int N, const ChipGeometry& chip) {
+    return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip) &&
+           cluster_count(B, N) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
 }
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
+    // The kernel's block -> (cluster, member) map is written for 8 XCDs (blocks b and b + 8 share one), and its
+    // measured policy below for 32 CUs in each: any other geometry (CPX / DPX partitions, CU masks: CCVM_AMD_GEOMETRY,
+    // a different part) takes the per-step tile kernel, which assumes nothing about the chip.
+    const ChipGeometry chip = chip_of(tun);
+    if (chip.xcds != 8 || chip.cus < 8 * (CL_MIN_N / CL_COLS + 1)) return false;
+    const int cus_per_xcd = chip.cus / chip.xcds;
     const int planes = mode == MODE_DL ? 2 : 1;
     if (round_up(N, 128) > CL_LDS_K && !cluster_wide_ok(mode, adam)) return false;
     const int G = (N + CL_COLS - 1) / CL_COLS;
@@ -283,14 +342,16 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // B = 2000: 3 rounds 31.8 vs 2 waves 27.9): the cluster path is taken when rounds < 1.3 x waves.
     const bool wide = round_up(N, 128) > CL_LDS_K;
     const int count = cluster_count(B, N);
-    const bool resident = cluster_resident_pinned(B, N) || (wide && count * G <= 256);
+    const bool spread_fits = wide && count * G <= chip.cus;
+    if (G > cus_per_xcd && !spread_fits) return false;  // a cluster must fit an XCD, or the whole grid the chip
+    const bool resident = cluster_resident_pinned(B, N, chip) || spread_fits;
     if (tun.cluster < 0 && planes == 2 && !wide && !resident) return false;
     if (tun.cluster < 0 && wide) {
         if (B < 640) return false;
         if (!resident) {
-            const int per_round = 8 * (32 / G);
+            const int per_round = chip.xcds * (cus_per_xcd / G);
             const int rounds = (count + per_round - 1) / per_round;
-            const int waves = (((B + BM - 1) / BM) * ((N + BN - 1) / BN) + 255) / 256;
+            const int waves = (((B + BM - 1) / BM) * ((N + BN - 1) / BN) + chip.cus - 1) / chip.cus;
             if (10 * rounds >= 13 * waves) return false;
         }
     }
@@ -308,13 +369,48 @@ int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* q
     ca.xb0 = static_cast<float*>(area);
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
     if (hipMemsetAsync(area, 0, xb, st) != hipSuccess) return CCVM_E_HIP;
-    ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + xb);
+    ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld;
     ca.nclusters = cluster_count(B, N);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
-    // K > 512 and the XCD-pinned placement does not fit the chip at once while the plain one does: spread
-    ca.spread = round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N) && ca.nclusters * ca.G <= 256;
+    ca.spread = cluster_spread(B, N, chip_of(tun));
+    return CCVM_OK;
+}
+
+// Largest batch the slab path takes by default (CCVM_AMD_KERNEL=slab / noslab force either)
+int slab_default_max_batch(int N, int mode) {
+    (void)N; (void)mode;
+    return 0;  // (set from measurements)
+}
+// ---- column-slab persistent path (ccvm_slab.h): small batches above N = 256 --------------------------------
+// Default policy: the slab path wherever its plan exists and the batch is smaller than what fills the other paths'
+// tiles.  Measured (us per step, slab vs what ran before; profiles/r03_small_batch.md):
+SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
+    SlabPlan none{};
+    if (!tun.slab) return none;
+    const int planes = mode == MODE_DL ? 2 : 1;
+    const SlabPlan p = slab_plan(B, N, planes, chip_of(tun), tun.slab_cgrp, tun.slab_rg);
+    if (!p.ok) return none;
+    if ((size_t)p.nclusters * planes * p.rg * round_up(N, 128) * 4 * SL_XE >= ((size_t)1 << 31)) return none;
+    if (tun.slab < 0 && B > slab_default_max_batch(N, mode)) return none;
+    return p;
+}
+// the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]
+int slab_base(SlabArgs& sa, const SlabPlan& p, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
+              const ccvm_noise* nz, float* table, void* area, hipStream_t st, const Tuning& tun, int planes) {
+    std::memset(&sa, 0, sizeof(sa));
+    sa.drop = tun.cluster_drop;
+    sa.Q = Q; sa.V = V; sa.qsum = qsum; sa.table = table;
+    const size_t half = (size_t)p.nclusters * planes * p.rg * ld * 4 * SL_XE;  // <= exchange_bytes / 2
+    sa.xb0 = static_cast<float*>(area);
+    sa.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + half);
+    if (hipMemsetAsync(area, 0, 2 * half, st) != hipSuccess) return CCVM_E_HIP;
+    sa.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
+    sa.seed = nz->seed; sa.row_offset = nz->row_offset; sa.replay = nz->mode == CCVM_NOISE_REPLAY;
+    sa.B = B; sa.N = N; sa.ld = ld;
+    sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.spread = p.spread;
+    sa.nxcd = chip_of(tun).xcds;
     return CCVM_OK;
 }
 
@@ -361,11 +457,11 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
     switch (solver) {
         // DL: c', s', the schedule table of the persistent paths, the cluster path's exchange buffers and status word
-        case 0: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 2) + cluster_sync_bytes(B);
+        case 0: return 2 * state + qs + table_bytes() + exchange_bytes(B, N, 2) + cluster_sync_bytes(B);
         // MF: measured-amplitude ping-pong + noise carry; Langevin: c' (+ one spare state); both: the cluster
         // path's exchange buffers, status word and counters
-        case 1: return 3 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
-        case 2: return 2 * state + qs + table_bytes() + cluster_exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
+        case 1: return 3 * state + qs + table_bytes() + exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
+        case 2: return 2 * state + qs + table_bytes() + exchange_bytes(B, N, 1) + cluster_sync_bytes(B);
         case 3: return (ld / 32) * rows * sizeof(float); // energy: column-strip partials
         case 4: return state + ld * ld * sizeof(float);  // post-processors: x' + 1/2(Q+Q')
         case 5: return qs;                               // ccvm_feedback
@@ -402,9 +498,16 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
+    if (const SlabPlan sp = want_persist(N, tun) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
+        const int nx = chip_of(tun).xcds;
+        std::snprintf(buf, buf_len, "ccvm::slab_kernel<%d, %d, %d> grid %d x 256 threads (%d clusters of %d workgroups x %d columns, %d rows each, K = %d%s), up to %d steps per launch",
+                      solver, sp.cgrp, sp.nq, sp.spread ? sp.nclusters * sp.G : (sp.nclusters + nx - 1) / nx * nx * sp.G,
+                      sp.nclusters, sp.G, 4 * sp.cgrp, 4 * sp.rg, sp.K, sp.spread ? ", spread over the XCDs" : "", TABLE_STEPS);
+        return CCVM_OK;
+    }
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
         const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
-        const bool spread = ccvm_ld(N) > CL_LDS_K && !cluster_resident_pinned(B, N) && count * G <= 256;
+        const bool spread = cluster_spread(B, N, chip_of(tun));
         std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
                       solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
                       spread ? ", spread over the XCDs" : "", TABLE_STEPS);
@@ -500,6 +603,31 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 pa.w1 = nz->w1 + (size_t)done * N * B;
             }
             if ((rc = launch_persist<MODE_DL, false>(pa, st, fn))) return rc;
+        }
+        return CCVM_OK;
+    }
+    if (const SlabPlan sp = (nsteps > 0 && !want_persist(N, tun)) ? want_slab(B, N, tun, MODE_DL) : SlabPlan{}; sp.ok) {
+        // small batch: whole chunks in one launch each, Q resident in the members' registers (ccvm_slab.h)
+        char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        SlabArgs sa;
+        if (slab_base(sa, sp, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 2))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        sa.x0 = c; sa.x1 = s;
+        sa.in_scale = a.in_scale; sa.in_shift = a.in_shift;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
+                       step0 + done, k};
+            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            sa.step0 = step0 + done;
+            sa.nsteps = k;
+            if (sa.replay) {
+                sa.w0 = nz->w0 + (size_t)done * N * B;
+                sa.w1 = nz->w1 + (size_t)done * N * B;
+            }
+            slab_launch_dl(sa, sp, st);
+            CCVM_CHECK_LAUNCH(fn);
         }
         return CCVM_OK;
     }
@@ -680,6 +808,37 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             if (replay) pa.w0 = nz->w0 + (size_t)done * N * B;
             rc = use_adam ? launch_persist<MODE_MF, true>(pa, st, fn) : launch_persist<MODE_MF, false>(pa, st, fn);
             if (rc) return rc;
+        }
+        return CCVM_OK;
+    }
+
+    if (const SlabPlan sp = want_slab(B, N, tun, MODE_MF); sp.ok) {
+        // small batch: whole chunks in one launch each, Q resident in the members' registers (ccvm_slab.h)
+        const float* qsum;
+        if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum, p->qsum))) return rc;
+        char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        SlabArgs sa;
+        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        if (slab_base(sa, sp, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 1))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        sa.x0 = mu; sa.x1 = sigma; sa.xt = mu_tilde_out;
+        sa.in_scale = (float)(ul / S_eff); sa.in_shift = (float)up; sa.S = (float)S_eff; sa.s_cols = s_cols;
+        PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
+        AdamSched asc;
+        persist_adam(pa_ad, asc, adam, use_adam);
+        sa.adam = use_adam; sa.ad = pa_ad.ad; sa.am = pa_ad.am; sa.av = pa_ad.av;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
+            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            sa.step0 = step0 + done;
+            sa.nsteps = k;
+            sa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
+            if (replay) sa.w0 = nz->w0 + (size_t)done * N * B;
+            slab_launch_mf(sa, sp, st);
+            CCVM_CHECK_LAUNCH(fn);
         }
         return CCVM_OK;
     }
@@ -882,6 +1041,31 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             rc = use_adam ? launch_persist<MODE_LANGEVIN, true>(pa, st, fn)
                           : launch_persist<MODE_LANGEVIN, false>(pa, st, fn);
             if (rc) return rc;
+        }
+        return CCVM_OK;
+    }
+    if (const SlabPlan sp = want_slab(B, N, tun, MODE_LANGEVIN); sp.ok) {
+        // small batch: whole chunks in one launch each, Q resident in the members' registers (ccvm_slab.h)
+        SlabArgs sa;
+        if (slab_base(sa, sp, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 1))
+            return fail(CCVM_E_HIP, "%s: memset failed", fn);
+        sa.x0 = c;
+        sa.in_scale = a.in_scale; sa.in_shift = a.in_shift; sa.s_cols = s_cols;
+        PersistArgs pa_ad;  // the Adam constants in the persistent kernels' form
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
+        AdamSched asc;
+        persist_adam(pa_ad, asc, adam, use_adam);
+        sa.adam = use_adam; sa.ad = pa_ad.ad; sa.am = pa_ad.am; sa.av = pa_ad.av;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
+                       step0 + done, k, asc};
+            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            sa.step0 = step0 + done;
+            sa.nsteps = k;
+            if (sa.replay) sa.w0 = nz->w0 + (size_t)done * N * B;
+            slab_launch_lv(sa, sp, st);
+            CCVM_CHECK_LAUNCH(fn);
         }
         return CCVM_OK;
     }
