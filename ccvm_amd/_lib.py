@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -41,6 +41,7 @@ class EngineUnavailable(RuntimeError):
 
 
 RUN_WS_PADDED = 1  # ccvm_noise.flags: the workspace's scratch arrays still have zero padding (see ccvm_hip.h)
+RUN_NO_EXCHANGE = 2  # ccvm_noise.flags: no kernel whose workgroups wait for each other (cluster / slab)
 
 
 class Noise(Structure):

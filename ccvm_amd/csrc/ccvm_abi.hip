@@ -39,6 +39,10 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int check_layout(const char* fn, int B, int N, int ld) {
@@ -88,9 +92,13 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 // launch loop never touches environ (getenv is a linear scan, and not safe against a concurrent
 // setenv from another host thread).
 //   CCVM_AMD_KERNEL=tile      force the per-step tile kernel where a persistent kernel would apply
-//   CCVM_AMD_KERNEL=cluster   the column-cluster persistent kernel wherever it applies (256 < N <= 512,
-//                             MF / Langevin), also for batches whose clusters run in several rounds;
-//                             =nocluster keeps those sizes on the per-step tile kernel
+//   CCVM_AMD_KERNEL=cluster   the column-cluster persistent kernel wherever it applies (256 < N <= 768), also for
+//                             batches whose clusters run in several rounds, and never the slab kernel;
+//                             =nocluster: neither of the two kernels whose workgroups exchange data (cluster, slab):
+//                             every size above 256 on the per-step tile kernel
+//   CCVM_AMD_KERNEL=slab      the column-slab small-batch kernel wherever it has a plan; =noslab: never
+//   CCVM_AMD_SLAB_CGRP=1|2|4|8, CCVM_AMD_SLAB_RG=n   force its member width (4 CGRP columns) / row groups per cluster
+//   CCVM_AMD_GEOMETRY=cus,xcds  plan for this chip instead of the device's
 //   CCVM_AMD_KS=1|2           force the tile shape (32 x 128 / 32 x 64 split-K)
 //   CCVM_AMD_XCD=0            linear block -> tile map instead of the XCD rectangles
 //   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
@@ -114,10 +122,10 @@ Tuning read_tuning() {
     Tuning t;
     if (const char* e = std::getenv("CCVM_AMD_KERNEL")) {
         t.force_tile = !std::strcmp(e, "tile");
-        if (!std::strcmp(e, "cluster")) t.cluster = 1;
-        if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = 0;
+        if (!std::strcmp(e, "cluster")) { t.cluster = 1; t.slab = 0; }
+        if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = t.slab = 0;  // no cross-workgroup kernel at all
         if (!std::strcmp(e, "slab")) t.slab = 1;
-        if (!std::strcmp(e, "noslab") || t.force_tile) t.slab = 0;
+        if (!std::strcmp(e, "noslab")) t.slab = 0;
     }
     if (const char* e = std::getenv("CCVM_AMD_SLAB_CGRP")) t.slab_cgrp = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_SLAB_RG")) t.slab_rg = std::atoi(e);
@@ -378,23 +386,30 @@ int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* q
     return CCVM_OK;
 }
 
-// Largest batch the slab path takes by default (CCVM_AMD_KERNEL=slab / noslab force either)
-int slab_default_max_batch(int N, int mode) {
-    (void)N; (void)mode;
-    return 0;  // (set from measurements)
-}
 // ---- column-slab persistent path (ccvm_slab.h): small batches above N = 256 --------------------------------
-// Default policy: the slab path wherever its plan exists and the batch is smaller than what fills the other paths'
-// tiles.  Measured (us per step, slab vs what ran before; profiles/r03_small_batch.md):
+// Default policy: the slab path wherever its plan exists (slab_plan: the batch's clusters fit the chip with <= 128 KB
+// of staged input per member).  Measured, us per step, slab vs what ran before (gpurun_out/slab8.txt,
+// profiles/r03_small_batch.md): DL N = 1000: B <= 32 3.05 vs 18.5, B = 64 5.0 vs 18.8, B = 128 9.5 vs 19.4; Langevin
+// N = 1000: B = 32 2.1 vs 10.7, B = 128 5.7 vs 11.0; N = 500: Langevin B = 32 / 256 1.55 / 3.7 vs 4.8 (cluster kernel),
+// DL B = 128 3.6 vs 9.9; clusters spread over the XCDs (N > 1024): PL N = 2000 B = 8 / 32 5.6 / 13.9 vs 17.5, DL
+// N = 1500 B = 16 10.8 vs 25.2.  CCVM_AMD_KERNEL=slab / noslab force either.
 SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     SlabPlan none{};
     if (!tun.slab) return none;
     const int planes = mode == MODE_DL ? 2 : 1;
     const SlabPlan p = slab_plan(B, N, planes, chip_of(tun), tun.slab_cgrp, tun.slab_rg);
     if (!p.ok) return none;
-    if ((size_t)p.nclusters * planes * p.rg * round_up(N, 128) * 4 * SL_XE >= ((size_t)1 << 31)) return none;
-    if (tun.slab < 0 && B > slab_default_max_batch(N, mode)) return none;
+    if ((size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE >= ((size_t)1 << 31)) return none;
     return p;
+}
+// Both exchange buffers of a slab launch before the call: every packet {0, 0}, the packets of the columns nobody owns
+// (k >= G C: the slab kernel fetches all K columns of a block) {0, 0xFFFFFFFF}, a tag that no step ever awaits and the
+// minimum over a unit's tags ignores.  Once per call: tags are global step numbers.
+__global__ void slab_init_kernel(uint2* xb, size_t packets, int K, int Kx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < packets; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)((i >> 2) % (size_t)K);
+        xb[i] = make_uint2(0u, k >= Kx ? 0xFFFFFFFFu : 0u);
+    }
 }
 // the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]
 int slab_base(SlabArgs& sa, const SlabPlan& p, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
@@ -402,10 +417,13 @@ int slab_base(SlabArgs& sa, const SlabPlan& p, const float* Q, const float* V, c
     std::memset(&sa, 0, sizeof(sa));
     sa.drop = tun.cluster_drop;
     sa.Q = Q; sa.V = V; sa.qsum = qsum; sa.table = table;
-    const size_t half = (size_t)p.nclusters * planes * p.rg * ld * 4 * SL_XE;  // <= exchange_bytes / 2
+    const size_t half = (size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE;  // <= exchange_bytes / 2
     sa.xb0 = static_cast<float*>(area);
     sa.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + half);
-    if (hipMemsetAsync(area, 0, 2 * half, st) != hipSuccess) return CCVM_E_HIP;
+    const size_t packets = 2 * half / SL_XE;
+    hipLaunchKernelGGL(slab_init_kernel, dim3(ew_grid(packets)), dim3(256), 0, st, static_cast<uint2*>(area), packets, p.K,
+                       p.G * 4 * p.cgrp);
+    if (hipGetLastError() != hipSuccess) return CCVM_E_HIP;
     sa.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
     sa.seed = nz->seed; sa.row_offset = nz->row_offset; sa.replay = nz->mode == CCVM_NOISE_REPLAY;
     sa.B = B; sa.N = N; sa.ld = ld;
@@ -437,10 +455,6 @@ void persist_adam(PersistArgs& pa, AdamSched& sc, const ccvm_adam* adam, bool us
     pa.av = adam->v;
 }
 
-inline int ew_grid(size_t total) {
-    size_t g = (total + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
-}
 
 }  // namespace
 
@@ -554,7 +568,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 int nsteps, int T, const ccvm_dl_params* p, const ccvm_noise* nz, void* ws, size_t ws_bytes,
                 void* stream) {
     const char* fn = "ccvm_dl_run";
-    const Tuning tun = read_tuning();
+    Tuning tun = read_tuning();
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
     if (!Q || !V || !c || !s || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -691,7 +706,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
                 int ld, int step0, int nsteps, int T, const ccvm_mf_params* p, const ccvm_adam* adam,
                 const ccvm_noise* nz, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_mf_run";
-    const Tuning tun = read_tuning();
+    Tuning tun = read_tuning();
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
     if (!Q || !V || !mu || !sigma || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -941,7 +957,8 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
                       int T, const ccvm_langevin_params* p, const ccvm_adam* adam, const ccvm_noise* nz,
                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_langevin_run";
-    const Tuning tun = read_tuning();
+    Tuning tun = read_tuning();
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
     if (!Q || !V || !c || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;

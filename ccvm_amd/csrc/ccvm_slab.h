@@ -54,7 +54,6 @@ constexpr int SL_MIN_N = 257, SL_MAX_N = 2048;
 constexpr int SL_MAX_RC = 128;           // RG x C: two rows x one column per lane -> at most 256 owners
 constexpr int SL_MAX_B = 512;            // batches the path is ever considered for (workspace sizing)
 constexpr unsigned SL_SPIN_LIMIT = 1u << 22;
-constexpr int SL_BATCH = 8;              // 16-byte loads per lane and fetch unit (32 KB per workgroup)
 
 struct SlabArgs {
     const float* Q;      // [ld][ld] (the row-scaled copy with a per-variable saturation)
@@ -63,14 +62,15 @@ struct SlabArgs {
     float* x0;           // DL, Langevin: c;  MF: mu   (pitched, in/out; owner-only data)
     float* x1;           // DL: s;  MF: sigma
     float* xt;           // MF: measured amplitude fed to the LAST step of this launch (out, may be NULL)
-    float* xb0;          // exchange buffers: GEMM input of even / odd steps, [cluster][plane][RG][ld][4 rows] packets
-    float* xb1;
+    float* xb0;          // exchange buffers: GEMM input of even / odd steps, [cluster][plane][RG][K][4 rows] packets;
+    float* xb1;          //   before the call: zero, tags of the columns nobody owns (k >= G C) 0xFFFFFFFF (slab_init_kernel)
     float* am;           // Adam moments (in/out)
     float* av;
     const float* table;  // [nsteps][TABLE_WORDS] schedule rows
     const float* w0;     // REPLAY noise for the chunk: [nsteps][N][B]
     const float* w1;
     unsigned* status;    // 0 = ok; set to 1 when a bounded spin gave up
+    unsigned long long* dbg;  // ablation stamps only: [grid][16]
     uint64_t seed;
     int64_t row_offset;
     int step0, nsteps;
@@ -87,10 +87,43 @@ struct SlabArgs {
     AdamConsts ad;
 };
 
+// Ablation bits for tools/slab_ablate.hip (0 in the product; timing only, results are wrong): 1 no MFMA, 2 no noise,
+// 4 no tag checks, 64 s_memtime stamps of wave 0 into a.dbg[block][0..7]: noise, wait for the first unit, rest of the
+// fetch + staging, wait at B1, contraction + reductions, wait at B2, update + publish, retry rounds.
+#ifndef CCVM_SLAB_ABL
+#define CCVM_SLAB_ABL 0
+#endif
+#ifndef CCVM_SL_SLEEP
+#define CCVM_SL_SLEEP 2
+#endif
+#ifndef CCVM_SL_DELAY
+#define CCVM_SL_DELAY 12   // x 64 cycles: what a wave without owners sleeps before its first loads of a step
+#endif
+
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 constexpr int sl_log2(int x) { return x <= 1 ? 0 : 1 + sl_log2(x / 2); }
+
+// Butterfly steps of the wavefront-level reduction (every lane ends with the sum; probed: tools/permlane_probe.hip).
+// Inside a row of 16 lanes: DPP row rotations fused into the add; across rows: gfx950's v_permlane16/32_swap (the
+// second operand goes through an empty asm: given the same SSA value twice hipcc 7.2 assumes both results equal).
+template <int ROR>
+__device__ __forceinline__ float sl_add_ror(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sl_add_swap16(float v) {
+    unsigned x = __float_as_uint(v), y = x;
+    asm volatile("" : "+v"(y));
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sl_add_swap32(float v) {
+    unsigned x = __float_as_uint(v), y = x;
+    asm volatile("" : "+v"(y));
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // CGRP = C / 4 column groups per member (1, 2, 4, 8); NQ = Q registers per lane; K = 64 NQ / CGRP >= N rounded up to C
 template <int MODE, int CGRP, int NQ>
@@ -105,6 +138,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     constexpr int K = SL_NW * KW;
     constexpr int CBSZ = sl_log2(CGRP);
     constexpr int NPL = (MODE == MODE_DL) ? 2 : 1;
+    constexpr int NLD = K / 128;             // 16-byte loads per lane and (plane, row group) block: 2 K loads / 256 lanes
     __shared__ __attribute__((aligned(16))) float lds[SL_XS_FLOATS + SL_RED_FLOATS + 4];
     float* const xs = lds;                       // [plane][rg][K][4 rows]
     float* const red = lds + SL_XS_FLOATS;       // [wave][plane][rg][C][4 rows]
@@ -128,9 +162,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     const int N = a.N, ld = a.ld;
     const int col0 = member * C;
     const int crow0 = cluster * 4 * RG;
-    const int Kx = G * C;                // published columns (N rounded up to C)
     if (tid == 0) lds[DEAD] = 0.0f;
-    for (int i = tid; i < NPL * RG * K * 4; i += SL_THREADS) xs[i] = 0.0f;  // k >= Kx stays zero for the launch
 
     // ---- Q slab, resident in registers for the whole launch -----------------------------------------
     // lane = 4 (kr CGRP + cg) + j: B operand of MFMA q is Q[kw0 + q KRES + kr][col0 + 4 cg + j]
@@ -172,18 +204,28 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     }
 
     // ---- exchange buffers ---------------------------------------------------------------------------
-    const size_t xbytes = (size_t)a.nclusters * NPL * RG * ld * 4 * SL_XE;
+    const size_t xbytes = (size_t)a.nclusters * NPL * RG * K * 4 * SL_XE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.xb0, 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.xb1, 0, (int)xbytes, 0x00020000);
     constexpr int SC1 = 16;  // aux bits of the buffer builtins: sc1
-    const unsigned blk_bytes = (unsigned)ld * 4 * SL_XE;                 // one (plane, row group) block
+    constexpr unsigned blk_bytes = (unsigned)K * 4 * SL_XE;              // one (plane, row group) block
     const unsigned cbase = (unsigned)(cluster * NPL * RG) * blk_bytes;   // this cluster's blocks
-    const int L = 2 * Kx;                                                // 16-byte loads per block
-    const int NB = (L + SL_BATCH * SL_THREADS - 1) / (SL_BATCH * SL_THREADS);  // fetch units per block
-    const int TU = NPL * RG * NB;
+    const int TU = NPL * RG;                                             // fetch units = blocks
+
+    unsigned long long t_last = 0, seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](unsigned long long& acc) {
+        if constexpr (CCVM_SLAB_ABL & 64) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc += t - t_last;
+            t_last = t;
+        }
+    };
 
     // publish this lane's two elements of plane pl with tag `tag` into buffer `par`: one 16-byte store
-    const unsigned pub_off = cbase + (unsigned)(org * ld + col) * 4 * SL_XE + (unsigned)oh * 16;
+    const unsigned pub_off = cbase + (unsigned)(org * K + col) * 4 * SL_XE + (unsigned)oh * 16;
     auto publish = [&](int par, const float (&x)[2], unsigned tag, int pl) {
         if (!owner) return;
         const u32x4s v = {__builtin_bit_cast(unsigned, ok[0] ? x[0] : 0.0f), tag,
@@ -245,29 +287,26 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         return r;
     };
 
-    // ---- fetch units: unit u = block u / NB (plane, row group), piece u % NB of SL_BATCH x 256 loads -----
-    u32x4s wa[SL_BATCH], wb[SL_BATCH];
-    auto issue = [&](int u, int par, u32x4s (&w)[SL_BATCH]) {
-        const int b = u / NB, ib = u - b * NB;
-        const unsigned off = cbase + (unsigned)b * blk_bytes + (unsigned)(ib * SL_BATCH * SL_THREADS + tid) * 16u;
+    // ---- fetch: one unit = one (plane, row group) block = NLD 16-byte loads per lane, staged 1:1 into xs -----------
+    u32x4s wa[NLD], wb[NLD];
+    const unsigned ld_off = cbase + (unsigned)tid * 16u;
+    auto issue = [&](int b, int par, u32x4s (&w)[NLD]) {
 #pragma unroll
-        for (int j = 0; j < SL_BATCH; ++j)
-            w[j] = __builtin_amdgcn_raw_buffer_load_b128(par ? rs1 : rs0, off, j * SL_THREADS * 16, SC1);
+        for (int j = 0; j < NLD; ++j)
+            w[j] = __builtin_amdgcn_raw_buffer_load_b128(par ? rs1 : rs0, ld_off + (unsigned)b * blk_bytes, j * SL_THREADS * 16, SC1);
     };
-    auto arrived = [&](int u, unsigned want, const u32x4s (&w)[SL_BATCH]) {
-        const int ib = u % NB;
-        unsigned lo = want;  // a stale tag is always smaller than the awaited one (ccvm_cluster.h)
+    // every packet of the unit carries the awaited tag (a stale tag is always smaller, the columns nobody owns carry
+    // 0xFFFFFFFF: ccvm_cluster.h, slab_init_kernel)
+    auto arrived = [&](unsigned want, const u32x4s (&w)[NLD]) {
+        unsigned lo = want;
 #pragma unroll
-        for (int j = 0; j < SL_BATCH; ++j) {
-            const bool valid = (ib * SL_BATCH + j) * SL_THREADS + tid < L;
-            const unsigned t = min(w[j][1], w[j][3]);
-            lo = valid ? min(lo, t) : lo;
-        }
+        for (int j = 0; j < NLD; ++j) asm("v_min3_u32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(w[j][1]), "v"(w[j][3]));
         return __builtin_amdgcn_ballot_w64(lo != want) == 0;
     };
     bool dead = false;
-    auto await = [&](int u, int par, unsigned want, u32x4s (&w)[SL_BATCH]) {
-        if (__builtin_expect(arrived(u, want, w), 1)) return;
+    auto await = [&](int b, int par, unsigned want, u32x4s (&w)[NLD]) {
+        if constexpr (CCVM_SLAB_ABL & 4) return;
+        if (__builtin_expect(arrived(want, w), 1)) return;
         unsigned spins = 0;
 #pragma nounroll
         do {
@@ -279,26 +318,39 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 dead = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
-            issue(u, par, w);
-        } while (!arrived(u, want, w));
-    };
-    auto stage = [&](int u, const u32x4s (&w)[SL_BATCH]) {
-        const int b = u / NB, ib = u - b * NB;
-        float* dst = xs + (size_t)b * (K * 4) + (size_t)(ib * SL_BATCH * SL_THREADS + tid) * 2;
+            if constexpr (CCVM_SLAB_ABL & 64) seg[7] += 1;
+            __builtin_amdgcn_s_sleep(CCVM_SL_SLEEP);
+            // only the pieces that have not arrived travel again (a retry of the whole unit is 8 MB per round and
+            // chip at N = 1000): the lanes of an arrived piece load from beyond the buffer (range-checked: zeros, no
+            // traffic) and keep what they have -- no branch around the loads (the wait counts at a join would
+            // serialise the pieces: one round trip EACH)
 #pragma unroll
-        for (int j = 0; j < SL_BATCH; ++j) {
-            if ((ib * SL_BATCH + j) * SL_THREADS + tid < L) {
-                // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0, hipcc 7.2)
-                const unsigned u0 = w[j][0], u1 = w[j][2];
-                const f32x2s v = {__uint_as_float(u0), __uint_as_float(u1)};
-                *reinterpret_cast<f32x2s*>(dst + j * SL_THREADS * 2) = v;
+            for (int j = 0; j < NLD; ++j) {
+                const bool have = min(w[j][1], w[j][3]) == want;
+                const u32x4s nw = __builtin_amdgcn_raw_buffer_load_b128(
+                    par ? rs1 : rs0, have ? 0xFFFFFFF0u : ld_off + (unsigned)b * blk_bytes, j * SL_THREADS * 16, SC1);
+                w[j][0] = have ? w[j][0] : nw[0];
+                w[j][1] = have ? w[j][1] : nw[1];
+                w[j][2] = have ? w[j][2] : nw[2];
+                w[j][3] = have ? w[j][3] : nw[3];
             }
+        } while (!arrived(want, w));
+    };
+    float* const st_dst = xs + tid * 2;
+    auto stage = [&](int b, const u32x4s (&w)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0, hipcc 7.2)
+            const unsigned u0 = w[j][0], u1 = w[j][2];
+            const f32x2s v = {__uint_as_float(u0), __uint_as_float(u1)};
+            *reinterpret_cast<f32x2s*>(st_dst + (size_t)b * (K * 4) + j * SL_THREADS * 2) = v;
         }
     };
 
+    const bool wave_delay = wave * 64 >= EP;  // no owner in this wave
     Row rnext = load_row(0);
     __syncthreads();  // xs is zeroed, DEAD is initialised
+    if constexpr (CCVM_SLAB_ABL & 64) { unsigned long long dummy = 0; mark(dummy); }
 
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
@@ -309,10 +361,14 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         const float* trow = rcur.w;
 
         // ---- phase A: the cluster's GEMM input of this step -> LDS --------------------------------------
-        issue(0, par, wa);
-        // this step's / the next step's normals while the packets travel
+        // This step's / the next step's normals first, THEN the loads: every member publishes at about the same
+        // time, and loads issued right behind the own publish mostly meet the peers' previous packets -- each such
+        // miss costs a whole round trip across the chip (1.0-1.4 retries per step when the loads went first).  The
+        // waves without owners sleep as long as the generator takes.
         float nz[2] = {0.0f, 0.0f}, nz1[2] = {0.0f, 0.0f};
-        if (owner) {
+        if constexpr (CCVM_SLAB_ABL & 2) {
+            nz[0] = nz[1] = nz1[0] = nz1[1] = 0.25f;
+        } else if (owner) {
             if constexpr (MODE == MODE_DL) {
                 pair_normals(step, it, nz, nz1);
             } else if constexpr (MODE == MODE_MF) {
@@ -321,10 +377,14 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 stream_normals(step, it, nz);
             }
         }
+        if (wave_delay) __builtin_amdgcn_s_sleep(CCVM_SL_DELAY);
         rnext = load_row(min(it + 1, a.nsteps - 1));
+        issue(0, par, wa);
+        mark(seg[0]);
         for (int u = 0; u < TU && !dead; u += 2) {
             if (u + 1 < TU) issue(u + 1, par, wb);
             await(u, par, want, wa);
+            if (u == 0) mark(seg[1]);
             stage(u, wa);
             if (u + 2 < TU) issue(u + 2, par, wa);
             if (u + 1 < TU) {
@@ -332,8 +392,10 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 stage(u + 1, wb);
             }
         }
+        mark(seg[2]);
         __syncthreads();  // B1: the input is staged
         if (lds[DEAD] != 0.0f) return;
+        mark(seg[3]);
 
         // ---- phase B: partial sums of this wave's k range, every plane and row group --------------------
         for (int b = 0; b < NPL * RG; ++b) {
@@ -344,18 +406,29 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
             f32x4v acc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-            mfma_chain<CBSZ, CGRP>(af, qf, acc, std::make_integer_sequence<int, NQ>{});
+            if constexpr (CCVM_SLAB_ABL & 1) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc[i & 3][0] += af[i] * qf[i];
+            } else {
+                mfma_chain<CBSZ, CGRP>(af, qf, acc, std::make_integer_sequence<int, NQ>{});
+            }
             f32x4v sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            // wavefront-level reduction over the k residues: lanes that differ in kr only
+            // wavefront-level reduction over the k residues (lanes that differ in kr only; strides 4 CGRP .. 32)
 #pragma unroll
-            for (int s = 4 * CGRP; s < 64; s <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], s, 64);
+            for (int r = 0; r < 4; ++r) {
+                float v = sum[r];
+                if constexpr (CGRP == 1) v = sl_add_ror<4>(v);
+                if constexpr (CGRP <= 2) v = sl_add_ror<8>(v);
+                if constexpr (CGRP <= 4) v = sl_add_swap16(v);
+                v = sl_add_swap32(v);
+                sum[r] = v;
             }
             if (lane < 4 * CGRP)  // kr == 0: lane = column inside the member
                 *reinterpret_cast<f32x4v*>(red + ((size_t)(wave * NPL * RG + b) * C + lane) * 4) = sum;
         }
+        mark(seg[4]);
         __syncthreads();  // B2: the four waves' partial sums are in LDS; xs may be overwritten
+        mark(seg[5]);
 
         // ---- phase C: the owners' update and the next input -------------------------------------------
         if (owner) {
@@ -424,6 +497,11 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 publish(par ^ 1, s0, tag, 0);
             }
         }
+        mark(seg[6]);
+    }
+    if constexpr (CCVM_SLAB_ABL & 64) {
+        if (tid == 0)
+            for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 16 + k] = seg[k];
     }
 
     // ---- write the state back (owner-only data: plain stores) ---------------------------------------
@@ -444,7 +522,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
 }
 
 // ---- host side: the shapes that exist, and the plan for (B, N) -------------------------------------------
-// K = 64 NQ / CGRP in {512, 1024, 1536, 2048}; NQ <= 128 registers per lane
+// K = 64 NQ / CGRP in {512, 768, 1024, 1280, 1536, 2048}; NQ <= 128 registers per lane
 struct SlabPlan {
     int ok;        // 0: the slab path does not serve this shape
     int cgrp, nq;  // template parameters
@@ -461,32 +539,38 @@ struct ChipGeometry {
 };
 
 inline int slab_k_for(int N) {
-    const int ks[4] = {512, 1024, 1536, 2048};
-    for (int i = 0; i < 4; ++i)
+    const int ks[6] = {512, 768, 1024, 1280, 1536, 2048};
+    for (int i = 0; i < 6; ++i)
         if (N <= ks[i]) return ks[i];
     return 0;
 }
 
-// Fewest rows per cluster first (the fetched input per member and step is R K packets), then the narrowest
-// member that still gives every cluster its CUs.  force_cgrp / force_rg (tuning): 0 = choose.
+// Fewest rows per cluster first (the fetched input per member and step is R K packets, the contraction R C K MACs);
+// for that row count a cluster that fits one XCD if there is one (measured, N = 1000, B = 4, us per step: 32 members
+// x 32 columns inside an XCD 1.89; 63 x 16 / 125 x 8 / 250 x 4 spread over the chip 3.3 / 3.3 / 3.0: across the
+// fabric a hand-off round trip is ~3500 cycles against ~1000 inside an L2), else the narrowest member whose
+// clusters fit the chip.  force_cgrp / force_rg (tuning): 0 = choose.
 inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, int force_cgrp = 0, int force_rg = 0) {
     SlabPlan p{};
     if (N < SL_MIN_N || N > SL_MAX_N || B < 1 || B > SL_MAX_B || chip.cus < 8 || chip.xcds < 1) return p;
     const int K = slab_k_for(N);
+    const int cus_per_xcd = chip.cus / chip.xcds;
     for (int rg = 1; rg <= 32; ++rg) {
         if (force_rg && rg != force_rg) continue;
         if (planes * rg * K * 4 > SL_XS_FLOATS) break;
         const int nclusters = (B + 4 * rg - 1) / (4 * rg);
-        for (int cgrp = 1; cgrp <= 8; cgrp *= 2) {
-            if (force_cgrp && cgrp != force_cgrp) continue;
-            const int C = 4 * cgrp, nq = K * cgrp / 64;
-            if (nq > 128 || rg * C > SL_MAX_RC) continue;
-            const int G = (N + C - 1) / C;
-            if ((long)nclusters * G > chip.cus) continue;
-            p.ok = 1; p.cgrp = cgrp; p.nq = nq; p.K = K; p.rg = rg; p.G = G; p.nclusters = nclusters;
-            const int cus_per_xcd = chip.cus / chip.xcds;
-            p.spread = ((nclusters + chip.xcds - 1) / chip.xcds) * G > cus_per_xcd;
-            return p;
+        for (int pinned = 1; pinned >= 0; --pinned) {
+            for (int cgrp = 1; cgrp <= 8; cgrp *= 2) {
+                if (force_cgrp && cgrp != force_cgrp) continue;
+                const int C = 4 * cgrp, nq = K * cgrp / 64;
+                if (nq > 128 || rg * C > SL_MAX_RC) continue;
+                const int G = (N + C - 1) / C;
+                const bool fits_xcd = ((nclusters + chip.xcds - 1) / chip.xcds) * G <= cus_per_xcd;
+                if (pinned ? !fits_xcd : (long)nclusters * G > chip.cus) continue;
+                p.ok = 1; p.cgrp = cgrp; p.nq = nq; p.K = K; p.rg = rg; p.G = G; p.nclusters = nclusters;
+                p.spread = !fits_xcd;
+                return p;
+            }
         }
     }
     return p;
@@ -494,9 +578,8 @@ inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, in
 
 inline size_t slab_exchange_bytes(int B, int N, int planes) {
     if (N < SL_MIN_N || N > SL_MAX_N || B > SL_MAX_B) return 0;
-    // rows of all clusters < B + 4 RG <= B + 128; two buffers
-    const size_t ld = (size_t)((N + 127) / 128 * 128);
-    return 2 * (size_t)(B + 128) * planes * ld * SL_XE;
+    // rows of all clusters < B + 4 RG <= B + 128; two buffers of [rows / 4][K][4 rows] packets per plane
+    return 2 * (size_t)(B + 128) * planes * slab_k_for(N) * SL_XE;
 }
 
 void slab_launch_dl(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
@@ -508,7 +591,11 @@ void launch_slab_nq(const SlabArgs& a, const SlabPlan& p, int grid, hipStream_t 
     const dim3 g(grid), b(SL_THREADS);
     switch (p.K) {
         case 512: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 8 * CGRP>), g, b, 0, st, a); break;
+        case 768: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 12 * CGRP>), g, b, 0, st, a); break;
         case 1024: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 16 * CGRP>), g, b, 0, st, a); break;
+        case 1280:
+            if constexpr (CGRP <= 4) hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP>), g, b, 0, st, a);
+            break;
         case 1536:
             if constexpr (CGRP <= 4) hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP>), g, b, 0, st, a);
             break;

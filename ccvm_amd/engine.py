@@ -369,6 +369,11 @@ class Trajectories:
             self._status = self.ws[off:off + 4] if off != ctypes.c_size_t(-1).value else None
             self._ws_padded = False  # set by the first completed run call (ccvm_hip.h: CCVM_RUN_WS_PADDED)
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
+        # Time-out recovery (see check): the state at the last verified point, taken before the first run call that
+        # may launch a kernel whose workgroups wait for each other; None while nothing unverified has run.
+        self._snap = None
+        self.no_exchange = False   # True after a time-out: the rest of the run stays on the tile kernel
+        self.fallbacks = 0         # time-outs recovered so far
 
     def _set_saturation(self, cp, S):
         """Scalar S; a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs); a 2-D
@@ -390,6 +395,8 @@ class Trajectories:
             raise ValueError("step range outside the run")
         per = self.feeder.steps_per_chunk()
         with torch.cuda.device(self.device):
+            if nsteps > 0 and self._snap is None and not self.no_exchange and self._exchange_kernel():
+                self._snap = self._snapshot()
             while nsteps > 0:
                 k = min(nsteps, per)
                 self._run(self.step, k, self.feeder.chunk(k))
@@ -400,6 +407,8 @@ class Trajectories:
         lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
         if self._ws_padded:  # this object zero-filled the workspace and only its own run calls have used it since
             nz.flags |= _lib.RUN_WS_PADDED
+        if self.no_exchange:
+            nz.flags |= _lib.RUN_NO_EXCHANGE
         tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
         if self.kind == "dl":
             rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,
@@ -439,15 +448,81 @@ class Trajectories:
         with torch.cuda.device(self.device):
             return unpack(self.state[name], self.b, self.n)
 
-    def check(self):
-        """Raise if a kernel of this run reported a failure through the workspace's status word (the
-        column-cluster persistent path gives up a bounded wait when its workgroups cannot become resident,
-        e.g. another process holding the GPU).  Synchronises (4 bytes to the host)."""
-        if self._status is not None and int(self._status.cpu().view(torch.int32).item()) != 0:
+    def _exchange_kernel(self):
+        """Would a run call of this shape launch a kernel whose workgroups wait for each other (column-cluster /
+        column-slab: ccvm_describe_launch under the current tuning environment)?"""
+        buf = ctypes.create_string_buffer(512)
+        rc = self.lib.ccvm_describe_launch(self._SOLVER_ID[self.kind], self.b, self.n, 1 if self.adam.enabled else 0,
+                                           1 if self.s_cols is not None else 0, buf, 512)
+        return rc == 0 and (b"cluster_kernel" in buf.value or b"slab_kernel" in buf.value)
+
+    def _snapshot(self):
+        """Everything a repeat of the coming steps needs: the state arrays (one device-to-device copy each), the
+        step counter and, in replay mode, the host generator's state."""
+        gen = self.feeder.spec.generator
+        rng = None
+        if self.feeder.spec.mode == "replay":
+            rng = gen.get_state() if gen is not None else torch.random.get_rng_state()
+        return {
+            "step": self.step,
+            "state": {k: v.clone() for k, v in self.state.items()},
+            "adam": [None if t is None else t.clone() for t in (self.adam_m, self.adam_v)],
+            "rng": rng,
+        }
+
+    def _restore(self, snap):
+        for k, v in snap["state"].items():
+            self.state[k].copy_(v)
+        for dst, src in zip((self.adam_m, self.adam_v), snap["adam"]):
+            if dst is not None:
+                dst.copy_(src)
+        if snap["rng"] is not None:
+            gen = self.feeder.spec.generator
+            if gen is not None:
+                gen.set_state(snap["rng"])
+            else:
+                torch.random.set_rng_state(snap["rng"])
+        self.step = snap["step"]
+
+    def check(self, rerun=True):
+        """Synchronisation point (4 bytes to the host): did a kernel of this run report a failure through the
+        workspace's status word?  The column-cluster and column-slab persistent kernels give up a bounded wait when
+        their workgroups cannot all become resident (e.g. another process holding the GPU for a second); the state
+        arrays are then invalid.  Recovery: the arrays go back to the last verified point (a snapshot taken before
+        the first unverified run call), the rest of the run stays on kernels whose workgroups do not wait for each
+        other (CCVM_RUN_NO_EXCHANGE: the per-step tile kernel), and with ``rerun`` the steps since the snapshot are
+        repeated there -- same noise, same result up to the summation order -- with a RuntimeWarning instead of an
+        error.  Returns True when a time-out was recovered (with ``rerun=False`` the caller repeats the steps:
+        ``self.step`` is back at the snapshot).  Without a snapshot (the status word was set by something else) it
+        raises."""
+        if self._status is None:
+            return False
+        if int(self._status.cpu().view(torch.int32).item()) == 0:
+            self._snap = None  # verified: the next run call snapshots anew
+            return False
+        snap, self._snap = self._snap, None
+        if snap is None:
             raise _lib.EngineError(
                 f"ccvm_{self.kind}_run: the column-cluster kernel timed out waiting for its workgroups (is another "
                 "process using this GPU?); the trajectories are invalid -- rerun, or set CCVM_AMD_KERNEL=nocluster"
             )
+        import warnings
+
+        reached = self.step
+        with torch.cuda.device(self.device):
+            self._restore(snap)
+            self._status.zero_()
+        self.no_exchange = True
+        self.fallbacks += 1
+        warnings.warn(
+            f"ccvm_{self.kind}_run: a persistent kernel timed out waiting for its workgroups (is another process "
+            f"using this GPU?); steps {snap['step']}..{reached} are repeated on the per-step tile kernel",
+            RuntimeWarning, stacklevel=2)
+        if rerun:
+            self.advance(reached - snap["step"])
+            if int(self._status.cpu().view(torch.int32).item()) != 0:
+                raise _lib.EngineError(f"ccvm_{self.kind}_run: status word set by a kernel that never waits")
+        return True
 
     def view(self, name):
         """The logical (B, N) region of one pitched state array as a strided GPU view (no copy)."""

@@ -24,6 +24,9 @@ from ..post_processor.factory import PostProcessorFactory
 from ..solution import Solution, fractions_from_counts
 from .algorithms import AdamParameters
 
+#: device memory one sampled array's ring may take during evolution sampling
+_SAMPLE_RING_BYTES = 256 * 1024 * 1024
+
 
 class DeviceType(enum.Enum):
     CPU_DEVICE = "cpu"
@@ -283,24 +286,37 @@ class CCVMSolver(ABC):
         if not evolution_step_size:
             traj.advance(iterations)
             return
-        # samples are collected in a device-side buffer (depth, B, N) per sampled array -- a strided
-        # device copy per sample point, no synchronisation -- and moved to the host buffers the
-        # reference exposes (B, N, depth) in ONE copy after the loop
+        # Samples are collected in a device-side ring (<= _SAMPLE_RING_BYTES per sampled array, (depth, B, N): a
+        # strided device copy per sample point, no synchronisation) and flushed to the host buffers the reference
+        # exposes (B, N, depth) whenever the ring is full: one device-to-host copy per flush in ring order, the
+        # permutation happens on the host.  (Dense sampling of a large run -- N = B = 1000, every step of 15000 --
+        # is 60 GB per array: the reference holds it on the host only, and so does this.)
+        # Every flush is a synchronisation point: traj.check verifies the steps since the previous flush (the
+        # persistent cluster / slab kernels can time out on a shared GPU); after a time-out the trajectories are back
+        # at the previous flush and the samples since then are taken again, on the tile kernel.
         points = sample_points(iterations, evolution_step_size)
         first = samples_taken
+        per_sample = traj.b * traj.n * 4
+        depth = max(1, min(len(points), _SAMPLE_RING_BYTES // max(per_sample, 1)))
         ring = {
-            name: torch.zeros((len(points), traj.b, traj.n), dtype=torch.float32, device=traj.device)
+            name: torch.zeros((depth, traj.b, traj.n), dtype=torch.float32, device=traj.device)
             for name in self._SAMPLED
         }
-        done = 0
-        for k, i in enumerate(points):
-            traj.advance(i + 1 - done)
-            done = i + 1
+        base = k = 0
+        while k < len(points):
+            traj.advance(points[k] + 1 - traj.step)
             for name in self._SAMPLED:
-                ring[name][k].copy_(traj.view(name))
-        traj.advance(iterations - done)
-        for name in self._SAMPLED:
-            getattr(self, f"{name}_sample")[:, :, first:first + len(points)] = ring[name].permute(1, 2, 0).cpu()
+                ring[name][k - base].copy_(traj.view(name))
+            k += 1
+            if k - base == depth or k == len(points):
+                if traj.check(rerun=False):  # timed out: traj.step is back at the previous flush
+                    k = base
+                    continue
+                for name in self._SAMPLED:
+                    host = ring[name][: k - base].cpu()  # (depth, B, N), contiguous
+                    getattr(self, f"{name}_sample")[:, :, first + base:first + k] = host.permute(1, 2, 0)
+                base = k
+        traj.advance(iterations - traj.step)
 
     def _begin_sampling(self, instance, batch_size, problem_size, iterations, evolution_step_size,
                         evolution_file):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 6
+#define CCVM_ABI_VERSION 7
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -63,6 +63,11 @@ typedef enum ccvm_noise_mode {
  * else wrote to it since.  The call then skips re-zeroing them (8 MB and ~6 us per call at N = 1000, B = 1000:
  * 2 % of a 20-step call).  Without the flag every call zeroes them itself. */
 #define CCVM_RUN_WS_PADDED 1
+/* CCVM_RUN_NO_EXCHANGE: run this call on kernels whose workgroups do not wait for each other (the per-step tile kernel,
+ * or the row-owner persistent kernel for N <= 256), never on the column-cluster / column-slab persistent kernels.  What
+ * a caller sets to repeat a chunk whose status word reported a time-out (ccvm_status_offset): same noise, same
+ * result up to the summation order of the contraction. */
+#define CCVM_RUN_NO_EXCHANGE 2
 
 typedef struct ccvm_noise {
     int32_t mode;        /* ccvm_noise_mode */

@@ -172,7 +172,7 @@ static int run_case(int N, int B) {
             hipMemcpy(&status, reinterpret_cast<char*>(wl.p) + off, 4, hipMemcpyDeviceToHost);
             REQUIRE(status == 0);
             char what[256];
-            REQUIRE(ccvm_describe_launch(2, B, N, 0, 0, what, sizeof(what)) == CCVM_OK && strstr(what, "_kernel<2, false") != nullptr);
+            REQUIRE(ccvm_describe_launch(2, B, N, 0, 0, what, sizeof(what)) == CCVM_OK && strstr(what, "_kernel<2, ") != nullptr);
         }
         REQUIRE(all_finite(hx) && all_finite(ho));
         for (int b = 0; b < B; ++b)

@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 6
+    assert hip_lib.ccvm_abi_version() == 7
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0

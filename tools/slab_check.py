@@ -41,6 +41,7 @@ for case in cases:
     cgrp = int(parts[3]) if len(parts) > 3 else 0
     rg = int(parts[4]) if len(parts) > 4 else 0
     ref, _, _ = run(kind, n, b, "tile")
+    other = run(kind, n, b, "noslab", timing=True)[2] if os.environ.get("SLAB_COMPARE") else None
     got, desc, best = run(kind, n, b, "slab", cgrp, rg, timing=True)
     errs = []
     for k in ref:
@@ -50,5 +51,6 @@ for case in cases:
         for k in ref:
             print("   ", k, "per-row max err:", [f"{float(x):.1e}" for x in (ref[k] - got[k]).abs().amax(dim=1)[:16]])
     bad = any(not torch.isfinite(got[k]).all() for k in got)
-    print(f"{case:24s} {best / tsteps * 1e6:8.3f} us/step  rel.err vs tile: {' '.join(errs)}{' NONFINITE' if bad else ''}\n"
+    cmp = f" (noslab {other / tsteps * 1e6:7.3f})" if other else ""
+    print(f"{case:24s} {best / tsteps * 1e6:8.3f} us/step{cmp}  rel.err vs tile: {' '.join(errs)}{' NONFINITE' if bad else ''}\n"
           f"    {desc}", flush=True)
