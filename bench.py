@@ -45,6 +45,14 @@ WORKLOADS = {
     "mf_n500_b1000": ("mf", 500, 1000),
     "langevin_n500_b1000": ("langevin", 500, 1000),
     "pl_n2000_b512": ("pl", 2000, 512),
+    # small batches (the reference runs any batch_size through the same einsum, dl_solver.py:145-153): the
+    # column-slab kernel, Q resident in registers chip-wide (ccvm_amd/csrc/ccvm_slab.h)
+    "dl_n1000_b1": ("dl", 1000, 1),
+    "dl_n1000_b8": ("dl", 1000, 8),
+    "dl_n1000_b32": ("dl", 1000, 32),
+    "langevin_n1000_b32": ("langevin", 1000, 32),
+    "mf_n500_b32": ("mf", 500, 32),
+    "pl_n2000_b32": ("pl", 2000, 32),
 }
 SOLVER_ID = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
 SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example scripts' S (workloads.py)
@@ -53,12 +61,39 @@ SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example 
 # --------------------------------------------------------------------------- #
 # launcher (no GPU call may happen in this process before the ranks are started)
 # --------------------------------------------------------------------------- #
-def launch_ranks(n, argv):
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (the launcher must not initialise the GPU before
+    it starts its ranks: torch.cuda.device_count() can fall back to hipGetDeviceCount): the *_VISIBLE_DEVICES
+    lists, else the KFD topology in sysfs (nodes with SIMDs are GPUs).  None when neither says anything."""
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            counts.append(len([x for x in val.split(",") if x.strip() != ""]))
+    if counts:
+        return min(counts)
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(nodes):
+            with open(os.path.join(nodes, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """Start n rank processes of `script` (default: this file) with the torch.distributed environment, wait for
+    them, and return the worst return code.  A rank that dies takes the others down with it (they would wait for
+    it in a collective until the time-out) and the launcher prints ONE diagnostic JSON line instead of leaving the
+    caller without any."""
     import socket
 
     share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
-    visible = torch.cuda.device_count()  # counts devices without creating a HIP context
-    if visible < n and not share:
+    visible = visible_gpu_count()
+    if visible is not None and visible < n and not share:
         raise SystemExit(f"bench.py --gpus {n}: only {visible} GPU(s) visible "
                          "(CCVM_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU over gloo)")
     with socket.socket() as s:
@@ -68,16 +103,30 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
-    worst, deadline = 0, time.time() + float(os.environ.get("CCVM_BENCH_LAUNCH_TIMEOUT", "1500"))
-    for p in procs:
-        try:
-            rc = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exactly the rank this launcher started
-            p.wait()
-            rc = 124
-        worst = max(worst, abs(rc))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=env))
+    deadline = time.time() + float(timeout or os.environ.get("CCVM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    codes = [None] * n
+    failed = None  # (rank, return code) of the first rank that did not exit cleanly
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = (r, codes[r])
+        timed_out = time.time() > deadline
+        if failed is not None or timed_out:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()  # exactly the ranks this launcher started
+                    p.wait()
+                    codes[r] = 124 if timed_out and failed is None else 143
+            break
+        time.sleep(0.05)
+    worst = max(abs(c) for c in codes)
+    if worst != 0:
+        why = (f"rank {failed[0]} exited with return code {failed[1]}" if failed is not None
+               else "time-out: the ranks were killed")
+        print(json.dumps({"error": f"bench.py --gpus {n}: {why}", "return_codes": codes, "n_gpus": n}), flush=True)
     return worst
 
 
@@ -125,13 +174,13 @@ def workload_params(kind):
     return p
 
 
-def make_trajectories(kind, n, b, total_steps, rank, seed=1):
+def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None):
     from ccvm_amd import engine
     from ccvm_amd.workloads import scaled_qv
 
     q, v, _ = scaled_qv(n, kind)
     prob = engine.DeviceProblem(q, v)
-    noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=rank * b)
+    noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=rank * b if row_offset is None else row_offset)
     ekind = {"dl": "dl", "mf": "mf"}.get(kind, "langevin")
     return engine.Trajectories(prob, b, ekind, total_steps, workload_params(kind), (0.0, 1.0), noise), q, v
 
@@ -180,7 +229,10 @@ def cpu_baseline(kind, n, b, total_steps, budget_s=12.0, threads=None):
     steps = done - 2
     return {
         "value": b * steps / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{steps} steps of the same workload (N={n}, batch={b}) with the torch-CPU oracle "
+        "sample": (f"{steps} steps of the same workload (N={n}, batch={b}) " if kind == "dl" else
+                   f"{steps // 5} whole 5-step runs (N={n}, batch={b}: the same per-step work, each run with its own "
+                   f"set-up and a 5-step schedule, not steps {total_steps - steps}.. of the benchmarked run) ")
+                  + f"with the torch-CPU oracle "
                   f"(bit-identical to the reference's CPU path), {dt / steps * 1e3:.1f} ms/step, "
                   f"{torch.get_num_threads()} torch threads on {cpu_model()} ({visible} cores visible to this "
                   f"process), torch {torch.__version__}",
@@ -219,13 +271,44 @@ def tts99_leg():
     }
 
 
+def family_roof(launch, kind, n, b, step_us):
+    """Extra roofline fields for the kernel families whose binding roof is not the fp32 MFMA peak.
+
+    slab_kernel (small batches, Q in registers, ccvm_slab.h): no byte of Q moves, the contraction of a member is
+    R C K MACs (a few hundred cycles); a step is one hand-off of the GEMM input between the cluster's workgroups
+    (own publish -> every peer's packets read: MI355X_MICROARCH.md price list, "handoff-1to1" 0.8-1.1 us idle /
+    "allgather" 2.4-2.9 us for 256 CUs) plus the member's matrix time.  bound "latency": peak = steps/s of that
+    floor, achieved = steps/s measured."""
+    import re
+
+    m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, spread)?",
+                  launch)
+    if not m:
+        return {}
+    cgrp, nq, clusters, members, cols, rows, k, spread = m.groups()
+    planes = 2 if kind == "dl" else 1
+    mfma_us = planes * (int(rows) // 4) * int(nq) * 8 / 2400.0  # 4x4x1 MFMAs of a wave x 8 cycles at 2.4 GHz
+    handoff_us = 2.4 if spread else 0.8                         # allgather over the chip / hand-off inside an XCD
+    floor_us = handoff_us + mfma_us
+    return {
+        "bound": "latency", "achieved": 1e6 / step_us, "peak": 1e6 / floor_us, "unit": "steps/s",
+        "frac": floor_us / step_us,
+        "latency_floor_us": {"handoff": handoff_us, "member_mfma": mfma_us,
+                             "source": "MI355X_MICROARCH.md price list: handoff-1to1 0.8 us (one XCD, idle) / "
+                                       "allgather 2.4 us (256 CUs, 8 KB); v_mfma_f32_4x4x1 8 cycles"},
+        "mfma_frac": 2.0 * planes * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "q_bytes_moved_per_step": 0,
+        "exchange_bytes_per_member_per_step": planes * int(rows) * int(k) * 8,
+    }
+
+
 def describe_launch(kind, b, n):
     import ctypes
 
     from ccvm_amd import _lib
 
-    buf = ctypes.create_string_buffer(256)
-    _lib.check(_lib.load().ccvm_describe_launch(SOLVER_ID[kind], b, n, 0, 0, buf, 256), "ccvm_describe_launch")
+    buf = ctypes.create_string_buffer(512)
+    _lib.check(_lib.load().ccvm_describe_launch(SOLVER_ID[kind], b, n, 0, 0, buf, 512), "ccvm_describe_launch")
     return buf.value.decode()
 
 
@@ -244,6 +327,11 @@ def main():
                     help="run this on-device post-processor on the final variables (after the timed loop, like "
                          "the reference's pp_time) before they are scored: BASELINE config 5 = "
                          "--workload pl_n2000_b512 --post adam")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: this many rows in total, split evenly over the ranks (rank r takes rows "
+                         "[r * ceil(G / N), ...)); BASELINE config 5 at every N = --workload pl_n2000_b512 --post adam "
+                         "--global-batch 4096, config 4 = --global-batch 8000.  Default: the workload's batch PER GPU "
+                         "(weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="torch threads of the cpu_baseline leg")
     args = ap.parse_args()
@@ -275,15 +363,23 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, n, b = WORKLOADS[args.workload]
+    row0 = rank * b
+    if args.global_batch is not None:
+        if args.global_batch < world:
+            raise SystemExit(f"--global-batch {args.global_batch} < {world} ranks")
+        per = -(-args.global_batch // world)
+        row0 = rank * per
+        b = min(per, args.global_batch - row0)
+    global_rows = args.global_batch if args.global_batch is not None else b * world
     total = args.warmup + args.steps
-    traj, q, v = make_trajectories(kind, n, b, total, rank)
+    traj, q, v = make_trajectories(kind, n, b, total, rank, row_offset=row0)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     if args.spinup_ms > 0:
-        scratch, _, _ = make_trajectories(kind, n, b, 1 << 20, rank, seed=2)
+        scratch, _, _ = make_trajectories(kind, n, b, 1 << 20, rank, seed=2, row_offset=row0)
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
             scratch.advance(256)
@@ -323,32 +419,63 @@ def main():
     ranks_seen = 1
     if world > 1:
         obj = obj.to(comm_dev)
+        if args.global_batch is not None:  # the last shard may be shorter: gather equal-length, -inf-padded vectors
+            per = -(-args.global_batch // world)
+            obj = torch.cat([obj, torch.full((per - obj.numel(),), float("inf"), dtype=obj.dtype, device=obj.device)])
         gathered = [torch.empty_like(obj) for _ in range(world)]
         dist.all_gather(gathered, obj)
         obj = torch.cat(gathered)
+        if args.global_batch is not None:
+            obj = obj[torch.isfinite(obj) | torch.isnan(obj)]
         ranks_seen = dist.get_world_size()
     best = float((-obj).max().item())
 
     if rank == 0:
         na = 2 if kind == "dl" else 1
         launch = describe_launch(kind, b, n)
-        steps_per_launch = min(args.steps, 4096) if ("persist_kernel" in launch or "cluster_kernel" in launch) else 1
+        persistent = any(k in launch for k in ("persist_kernel", "cluster_kernel", "slab_kernel"))
+        # a persistent launch runs up to 4096 steps (the schedule table of a run call, ccvm_abi.hip: TABLE_STEPS);
+        # traj.advance(steps) in fused-noise mode is ONE run call = ceil(steps / 4096) launches
+        launches = -(-args.steps // 4096) if persistent else args.steps
+        steps_per_launch = args.steps / launches
         flops_per_step = 2.0 * na * n * n * b
         bytes_per_step = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
         achieved = flops_per_step / (gpu_ms_per_step * 1e-3) / 1e12
+        wall_ms_per_step = elapsed / args.steps * 1e3
         metric = "SDE row-steps/s (Euler-Maruyama steps/s x batch)"
         if args.workload == "dl_n1000_b1000":
             metric += ", DL-CCVM N=1000 batch=1000 per GPU"
+        roofline = {
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            # frac: the kernel (HIP events on the launch stream); frac_wall: the same flops over this line's own
+            # ms_per_step (host wall clock incl. the two synchronisations and post-idle launches)
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "frac_wall": flops_per_step / (wall_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": None,  # HBM bytes need separate rocprofv3 --pmc passes: see "profiled"
+            "algorithmic_bytes": bytes_per_step * steps_per_launch,
+            "algorithmic_flops": flops_per_step * steps_per_launch,
+            "kernel": launch,
+            "steps_per_launch": steps_per_launch,
+            "launches": launches,
+            "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch,
+            "avg_step_us": gpu_ms_per_step * 1e3,
+            "timing": "HIP events on the launch stream around the timed region / launches in it",
+            "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
+                         "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip)",
+            "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
+            "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        }
+        roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3))
         out = {
             "metric": metric,
-            "value": args.steps * b * world / elapsed,
+            "value": args.steps * global_rows / elapsed,
             "unit": "row-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": wall_ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch is not None else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -356,32 +483,18 @@ def main():
             "n_ranks_seen": ranks_seen,
             "config": {
                 "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
-                            f"batch {b} per GPU x {world} GPU, fp32 state, fused Threefry noise, "
-                            f"schedule of a {total}-step run"
+                            + (f"global batch {global_rows} split over {world} GPU ({b} rows on rank 0), "
+                               if args.global_batch is not None else f"batch {b} per GPU x {world} GPU, ")
+                            + f"fp32 state, fused Threefry noise, schedule of a {total}-step run"
                             + (f", {args.post} post-processor on device after the loop" if args.post else ""),
-                "global_batch": b * world,
+                "global_batch": global_rows,
                 "parallelism": f"batch-sharded x{world}, no data-path collective; one all-gather of "
-                               f"{b * world} objective values after the loop "
+                               f"{global_rows} objective values after the loop "
                                f"({'gloo rehearsal on one GPU' if share else 'RCCL' if world > 1 else 'single rank'})",
             },
-            "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None,  # HBM bytes need separate rocprofv3 --pmc passes: see "profiled"
-                "algorithmic_bytes": bytes_per_step * steps_per_launch,
-                "algorithmic_flops": flops_per_step * steps_per_launch,
-                "kernel": launch,
-                "steps_per_launch": steps_per_launch,
-                "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch,
-                "avg_step_us": gpu_ms_per_step * 1e3,
-                "timing": "HIP events on the launch stream around the timed region / launches in it",
-                "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
-                             "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip)",
-                "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
-                "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            },
+            "roofline": roofline,
             "check": {"objective_values_finite": finite, "best_objective_value": best,
-                      "post_processor": args.post, "pp_seconds": pp_seconds},
+                      "post_processor": args.post, "pp_seconds": pp_seconds, "time_outs_recovered": traj.fallbacks},
         }
         prof = profiled_counters(args.workload)
         if prof is not None:

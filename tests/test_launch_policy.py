@@ -1,0 +1,83 @@
+"""The launch policy of the C ABI on the host (ccvm_describe_launch; no GPU): which kernel family a shape takes, for
+the real chip (256 CUs in 8 XCDs) and for other geometries (CCVM_AMD_GEOMETRY=cus,xcds: CPX / DPX partitions, CU
+masks, other parts).  The column-cluster kernel's placement is written for 8 XCDs x 32 CUs: anything else must take
+the per-step tile kernel; the slab kernel plans for whatever geometry it is given."""
+import ctypes
+import re
+
+import pytest
+
+
+def _describe(hip_lib, solver, b, n, adam=0):
+    buf = ctypes.create_string_buffer(512)
+    assert hip_lib.ccvm_describe_launch(solver, b, n, adam, 0, buf, 512) == 0
+    return buf.value.decode()
+
+
+@pytest.fixture
+def clean_env(monkeypatch):
+    for var in ("CCVM_AMD_KERNEL", "CCVM_AMD_GEOMETRY", "CCVM_AMD_SLAB_CGRP", "CCVM_AMD_SLAB_RG", "CCVM_AMD_KS"):
+        monkeypatch.delenv(var, raising=False)
+    return monkeypatch
+
+
+def test_families_on_the_nominal_chip(hip_lib, clean_env):
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    assert "persist_kernel<0" in _describe(hip_lib, 0, 1000, 100)
+    assert "persist_kernel<2" in _describe(hip_lib, 2, 4, 256)            # N <= 256: row owners, any batch
+    assert "cluster_kernel<1" in _describe(hip_lib, 1, 1000, 500)
+    assert "cluster_kernel<0" in _describe(hip_lib, 0, 1000, 768) and "spread" in _describe(hip_lib, 0, 1000, 768)
+    assert "step_kernel<0" in _describe(hip_lib, 0, 1000, 1000)
+    assert "step_kernel<2" in _describe(hip_lib, 2, 512, 2000)
+    d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
+    assert "slab_kernel<0, 8, 128>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
+    assert "spread" not in d
+    d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: a cluster spans XCDs
+    assert "slab_kernel<2" in d and "spread over the XCDs" in d
+    assert "step_kernel" in _describe(hip_lib, 2, 64, 2000)                # no plan: 64 rows x 2048 do not fit
+
+
+@pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])
+def test_other_geometries_never_take_the_cluster_kernel_unless_it_is_8_xcds(hip_lib, clean_env, geometry):
+    clean_env.setenv("CCVM_AMD_GEOMETRY", geometry)
+    cus, xcds = map(int, geometry.split(","))
+    for solver, b, n in ((1, 1000, 500), (2, 1000, 300), (0, 1000, 640), (2, 1000, 768)):
+        d = _describe(hip_lib, solver, b, n)
+        if xcds != 8:
+            assert "step_kernel" in d, (geometry, d)
+        elif "cluster_kernel" in d:
+            grid = int(re.search(r"grid (\d+) x 512", d).group(1))
+            members = int(re.search(r"clusters of (\d+) workgroups", d).group(1))
+            assert members <= cus // xcds or grid <= cus, (geometry, d)
+    clean_env.setenv("CCVM_AMD_KERNEL", "cluster")                         # forcing it does not override the geometry
+    if xcds != 8:
+        assert "step_kernel" in _describe(hip_lib, 2, 1000, 500)
+
+
+@pytest.mark.parametrize("geometry,b,n", [("64,2", 4, 1000), ("64,2", 8, 500), ("32,1", 4, 1000), ("128,4", 16, 1000),
+                                          ("256,8", 128, 1000), ("256,8", 3, 2048), ("304,8", 8, 1200)])
+def test_slab_plans_fit_the_geometry_they_are_given(hip_lib, clean_env, geometry, b, n):
+    clean_env.setenv("CCVM_AMD_GEOMETRY", geometry)
+    cus, xcds = map(int, geometry.split(","))
+    d = _describe(hip_lib, 2, b, n)
+    assert "slab_kernel" in d, d
+    clusters, members, cols, rows, k = map(int, re.search(
+        r"\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)", d).groups())
+    assert clusters * rows >= b and members * cols >= n and k >= n
+    if "spread" in d:
+        assert clusters * members <= cus
+    else:
+        assert -(-clusters // xcds) * members <= cus // xcds
+
+
+def test_no_plan_means_the_tile_kernel(hip_lib, clean_env):
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "16,1")     # 16 CUs cannot hold N = 1000 in 32-column members
+    assert "step_kernel" in _describe(hip_lib, 2, 4, 1000)
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    clean_env.setenv("CCVM_AMD_KERNEL", "noslab")
+    assert "step_kernel" in _describe(hip_lib, 0, 4, 1000)
+    assert "cluster_kernel" in _describe(hip_lib, 2, 32, 500)  # what ran before the slab kernel existed
+    clean_env.setenv("CCVM_AMD_KERNEL", "nocluster")
+    assert "step_kernel" in _describe(hip_lib, 2, 32, 500)
+    clean_env.setenv("CCVM_AMD_KERNEL", "tile")
+    assert "step_kernel" in _describe(hip_lib, 0, 1000, 100)
