@@ -112,6 +112,32 @@ def asgd_arrays():
     return np.load(os.path.join(GOLDEN_DIR, "test020_asgd.npz"))
 
 
+# thick0300 ... thick1000: the reference at real batch sizes where the engine's kernels change shape (make_golden.py
+# --only-thick): objective values of EVERY row, variable arrays for the rows listed in the manifest ("rows_kept")
+THICK_TAGS = ("thick0300", "thick0500", "thick0600", "thick0768", "thick1000")
+
+
+def thick_cases():
+    return [(tag, name) for tag in THICK_TAGS for name in golden(tag).cases]
+
+
+def compare_with_thick(g, case, fields_of, atol_x, atol_obj, label=""):
+    """Compare a result (``fields_of(field)`` -> (batch, ...) tensor) with a thick fixture: objective values of every
+    row, variables on the kept rows.  Gates: atol_x * max(1, |want|max) on variables, atol_obj relative to the
+    magnitude of the objective values."""
+    rows = torch.tensor(g.manifest["rows_kept"])
+    for field in g.fields(case):
+        want = g.out(case, field)
+        got = fields_of(field).cpu()
+        if field == "objective_values":
+            tol = atol_obj * max(1.0, float(want.abs().max()))
+        else:
+            got = got[rows]
+            tol = atol_x * max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= tol, f"{label}{g.tag}/{case}/{field}: max abs err {err:.3e} > {tol:.3e}"
+
+
 _cache = {}
 
 
