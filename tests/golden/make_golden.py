@@ -59,6 +59,12 @@ ADAMS = {
 }
 
 
+def made_with():
+    """Recorded in every manifest: the fixtures are bit-exact only on the configuration that made them (the einsum's
+    blocking depends on the thread count: 3e-7 relative at N = 300 between 1 and 8 threads)."""
+    return {"torch": torch.__version__, "torch_num_threads": torch.get_num_threads()}
+
+
 def run_case(kind, path, iterations, adam=None, post=None, flag=True, batch=B, seed=SEED, bounds=(0.0, 1.0),
              dl_S=None, s_vector=None, g=None):
     """``s_vector``: per-variable saturation (1-D tensor of length N) -- DL takes it in the constructor,
@@ -104,13 +110,13 @@ def anchors():
     # the DL example exactly as shipped: B=1000, T=1500, seed 1234 (SURVEY.md 8c anchor)
     arrays, meta = run_case("dl", INSTANCES["tuningH020"], 1500, batch=1000, seed=1234)
     with open(os.path.join(OUT, "dl_example_anchor.json"), "w") as fh:
-        json.dump(meta, fh, indent=1, sort_keys=True)
+        json.dump(dict(meta, made_with=made_with()), fh, indent=1, sort_keys=True)
     print("anchor", meta["best_objective_value"], meta["solution_performance"])
     # BASELINE.json configs[0]: DLSolver on test020-100-10.in, batch 100, 15000 iterations
     # (example parameters, g = 0.05, seed 1234)
     arrays, meta = run_case("dl", INSTANCES["test020"], 15000, batch=100, seed=1234)
     with open(os.path.join(OUT, "baseline_config1_anchor.json"), "w") as fh:
-        json.dump(meta, fh, indent=1, sort_keys=True)
+        json.dump(dict(meta, made_with=made_with()), fh, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(OUT, "baseline_config1_anchor.npz"), **arrays)
     print("config 1", meta["best_objective_value"], meta["solution_performance"])
 
@@ -148,7 +154,7 @@ def bounds_cases():
             print("g", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_bounds.npz"), **store)
     with open(os.path.join(OUT, "test020_bounds.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def vector_s_cases():
@@ -168,7 +174,7 @@ def vector_s_cases():
             print("vecS", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_vecS.npz"), **store)
     with open(os.path.join(OUT, "test020_vecS.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def full_s_cases():
@@ -204,7 +210,7 @@ def full_s_cases():
                 print("fullS", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, "test020_fullS.npz"), **store)
     with open(os.path.join(OUT, "test020_fullS.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def asgd_cases():
@@ -238,7 +244,7 @@ def asgd_cases():
         c.clone(), q, v, lower_clamp=0.1, upper_clamp=0.9, num_iter_pp=4, step_size=0.05).numpy()
     np.savez_compressed(os.path.join(OUT, "test020_asgd.npz"), **store)
     with open(os.path.join(OUT, "test020_asgd.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def larger_n_cases(n=96, batch=24, iterations=25):
@@ -289,7 +295,7 @@ def larger_n_cases(n=96, batch=24, iterations=25):
                 print(f"N={n}", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, f"synthetic{n:03d}.npz"), **store)
     with open(os.path.join(OUT, f"synthetic{n:03d}.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def thick_cases(n, batch, iterations, kinds=None, seed_offset=7000):
@@ -342,7 +348,7 @@ def thick_cases(n, batch, iterations, kinds=None, seed_offset=7000):
                 print(f"N={n} B={batch}", name, meta["best_objective_value"])
     np.savez_compressed(os.path.join(OUT, f"thick{n:04d}.npz"), **store)
     with open(os.path.join(OUT, f"thick{n:04d}.json"), "w") as fh:
-        json.dump(manifest, fh, indent=1, sort_keys=True)
+        json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
 
 def main():
@@ -416,7 +422,7 @@ def main():
 
         np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **store)
         with open(os.path.join(OUT, f"{tag}.json"), "w") as fh:
-            json.dump(manifest, fh, indent=1, sort_keys=True)
+            json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
     anchors()
     bounds_cases()
