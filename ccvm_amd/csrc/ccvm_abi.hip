@@ -365,19 +365,58 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     }
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
+// ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
+// Before a call both exchange buffers must hold no tag the call will await: every packet {0, 0}; for the slab path the
+// packets of the columns nobody owns (k >= Kx = G C: that kernel fetches all K columns of a block) {0, 0xFFFFFFFF}, a
+// tag that no step awaits and the minimum over a unit's tags ignores.  Tags are global step numbers, so an area left
+// by earlier run calls of the SAME layout whose steps all came before step0 is as good as a fresh one: the 128-byte
+// line behind the area (word 0: the status word) records in words 8 / 9 what the area holds -- a layout id and the
+// largest tag ever stored -- and the init kernel returns at once when that matches (8-25 MB of memset per call
+// otherwise: as much as several steps of a short chunk).  Zero the whole line once (fresh workspace).
+constexpr int XHDR_ID = 8, XHDR_MAXTAG = 9;
+__global__ void exchange_init_kernel(uint2* xb, size_t packets, int K, int Kx, const unsigned* hdr, unsigned id,
+                                     unsigned step0) {
+    if (hdr[XHDR_ID] == id && hdr[XHDR_MAXTAG] <= step0) return;  // (read-only here: the commit kernel writes it)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < packets; i += (size_t)gridDim.x * blockDim.x) {
+        const bool pad = K > 0 && (int)((i >> 2) % (size_t)K) >= Kx;
+        xb[i] = make_uint2(0u, pad ? 0xFFFFFFFFu : 0u);
+    }
+}
+__global__ void exchange_commit_kernel(unsigned* hdr, unsigned id, unsigned max_tag) {
+    hdr[XHDR_ID] = id;
+    hdr[XHDR_MAXTAG] = max_tag;
+}
+unsigned exchange_layout_id(std::initializer_list<int> what) {
+    unsigned h = 2166136261u;  // FNV-1a over the layout's parameters; never 0 (a zeroed line matches nothing)
+    for (int w : what) h = (h ^ (unsigned)w) * 16777619u;
+    return h ? h : 1u;
+}
+int exchange_prepare(void* area, size_t bytes, int K, int Kx, unsigned* hdr, unsigned id, int step0, hipStream_t st) {
+    const size_t packets = bytes / 8;
+    hipLaunchKernelGGL(exchange_init_kernel, dim3(ew_grid(packets)), dim3(256), 0, st, static_cast<uint2*>(area), packets,
+                       K, Kx, hdr, id, (unsigned)step0);
+    return hipGetLastError() == hipSuccess ? CCVM_OK : CCVM_E_HIP;
+}
+int exchange_commit(unsigned* hdr, unsigned id, int step_end, hipStream_t st) {
+    hipLaunchKernelGGL(exchange_commit_kernel, dim3(1), dim3(1), 0, st, hdr, id, (unsigned)step_end);
+    return hipGetLastError() == hipSuccess ? CCVM_OK : CCVM_E_HIP;
+}
+
 // the part of ClusterArgs every solver shares; `area` = what follows the schedule table in the workspace:
 // [exchange buffer 0][exchange buffer 1][status word].  Zeroes the exchange buffers (once per call: the tags are
 // global step numbers, unique across the launches of a call).
-int cluster_base(ClusterArgs& ca, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
-                 const ccvm_noise* nz, float* table, void* area, hipStream_t st, const Tuning& tun, int planes = 1) {
+int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
+                 const ccvm_noise* nz, float* table, void* area, int step0, hipStream_t st, const Tuning& tun,
+                 int planes = 1) {
     std::memset(&ca, 0, sizeof(ca));
     ca.drop = tun.cluster_drop;
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
     const size_t xb = cluster_exchange_bytes(B, N, planes);
     ca.xb0 = static_cast<float*>(area);
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
-    if (hipMemsetAsync(area, 0, xb, st) != hipSuccess) return CCVM_E_HIP;
     ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
+    xid = exchange_layout_id({1, B, N, planes});
+    if (exchange_prepare(area, xb, 0, 0, ca.status, xid, step0, st)) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld;
     ca.nclusters = cluster_count(B, N);
@@ -402,29 +441,19 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     if ((size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE >= ((size_t)1 << 31)) return none;
     return p;
 }
-// Both exchange buffers of a slab launch before the call: every packet {0, 0}, the packets of the columns nobody owns
-// (k >= G C: the slab kernel fetches all K columns of a block) {0, 0xFFFFFFFF}, a tag that no step ever awaits and the
-// minimum over a unit's tags ignores.  Once per call: tags are global step numbers.
-__global__ void slab_init_kernel(uint2* xb, size_t packets, int K, int Kx) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < packets; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)((i >> 2) % (size_t)K);
-        xb[i] = make_uint2(0u, k >= Kx ? 0xFFFFFFFFu : 0u);
-    }
-}
 // the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]
-int slab_base(SlabArgs& sa, const SlabPlan& p, const float* Q, const float* V, const float* qsum, int B, int N, int ld,
-              const ccvm_noise* nz, float* table, void* area, hipStream_t st, const Tuning& tun, int planes) {
+int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, const float* V, const float* qsum, int B, int N,
+              int ld, const ccvm_noise* nz, float* table, void* area, int step0, hipStream_t st, const Tuning& tun,
+              int planes) {
     std::memset(&sa, 0, sizeof(sa));
     sa.drop = tun.cluster_drop;
     sa.Q = Q; sa.V = V; sa.qsum = qsum; sa.table = table;
     const size_t half = (size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE;  // <= exchange_bytes / 2
     sa.xb0 = static_cast<float*>(area);
     sa.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + half);
-    const size_t packets = 2 * half / SL_XE;
-    hipLaunchKernelGGL(slab_init_kernel, dim3(ew_grid(packets)), dim3(256), 0, st, static_cast<uint2*>(area), packets, p.K,
-                       p.G * 4 * p.cgrp);
-    if (hipGetLastError() != hipSuccess) return CCVM_E_HIP;
     sa.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
+    xid = exchange_layout_id({2, B, N, planes, p.cgrp, p.rg, p.K, p.nclusters, p.G});
+    if (exchange_prepare(area, 2 * half, p.K, p.G * 4 * p.cgrp, sa.status, xid, step0, st)) return CCVM_E_HIP;
     sa.seed = nz->seed; sa.row_offset = nz->row_offset; sa.replay = nz->mode == CCVM_NOISE_REPLAY;
     sa.B = B; sa.N = N; sa.ld = ld;
     sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.spread = p.spread;
@@ -626,7 +655,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         SlabArgs sa;
-        if (slab_base(sa, sp, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 2))
+        unsigned xid;
+        if (slab_base(sa, xid, sp, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun, 2))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         sa.x0 = c; sa.x1 = s;
         sa.in_scale = a.in_scale; sa.in_shift = a.in_shift;
@@ -644,6 +674,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             slab_launch_dl(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(sa.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
     if (nsteps > 0 && want_cluster(B, N, tun, MODE_DL, false)) {
@@ -651,7 +682,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
-        if (cluster_base(ca, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 2))
+        unsigned xid;
+        if (cluster_base(ca, xid, Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun, 2))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = c; ca.x1 = s;
         ca.in_scale = a.in_scale; ca.in_shift = a.in_shift;
@@ -669,6 +701,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             cluster_launch_dl(ca, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
     int cur = 0;
@@ -835,8 +868,9 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         SlabArgs sa;
+        unsigned xid;
         const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
-        if (slab_base(sa, sp, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 1))
+        if (slab_base(sa, xid, sp, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun, 1))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         sa.x0 = mu; sa.x1 = sigma; sa.xt = mu_tilde_out;
         sa.in_scale = (float)(ul / S_eff); sa.in_shift = (float)up; sa.S = (float)S_eff; sa.s_cols = s_cols;
@@ -856,6 +890,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             slab_launch_mf(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(sa.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
 
@@ -866,8 +901,9 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
+        unsigned xid;
         const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
-        if (cluster_base(ca, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), st, tun))
+        if (cluster_base(ca, xid, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = mu; ca.x1 = sigma; ca.xt = mu_tilde_out;
         ca.in_scale = (float)(ul / S_eff); ca.in_shift = (float)up; ca.S = (float)S_eff; ca.s_cols = s_cols;
@@ -887,6 +923,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             cluster_launch_mf(ca, use_adam, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
 
@@ -1064,7 +1101,8 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (const SlabPlan sp = want_slab(B, N, tun, MODE_LANGEVIN); sp.ok) {
         // small batch: whole chunks in one launch each, Q resident in the members' registers (ccvm_slab.h)
         SlabArgs sa;
-        if (slab_base(sa, sp, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun, 1))
+        unsigned xid;
+        if (slab_base(sa, xid, sp, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun, 1))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         sa.x0 = c;
         sa.in_scale = a.in_scale; sa.in_shift = a.in_shift; sa.s_cols = s_cols;
@@ -1084,12 +1122,14 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             slab_launch_lv(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(sa.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
     if (want_cluster(B, N, tun, MODE_LANGEVIN, use_adam)) {
         // whole chunks of the trajectory in one launch each, Q panels resident in LDS (ccvm_cluster.h)
         ClusterArgs ca;
-        if (cluster_base(ca, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), st, tun))
+        unsigned xid;
+        if (cluster_base(ca, xid, a.Q, V, a.qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = c;
         ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.s_cols = s_cols;
@@ -1109,6 +1149,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             cluster_launch_lv(ca, use_adam, st);
             CCVM_CHECK_LAUNCH(fn);
         }
+        if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
     if (use_adam) {

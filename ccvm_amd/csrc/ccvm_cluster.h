@@ -506,8 +506,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     const float* const a_rd = abuf + rowpos(c16) * AS + 32 * g;
     const float* const b_rd = qp + (16 * wave + c16) * QS + 128 * g;  // chunk c's B operands start at + 32 c
     // operands are read one UNIT (UM MFMAs' worth: a chunk or half a chunk) ahead, double-buffered
-    constexpr int UM = CCVM_CL_UNIT, UPC = 32 / UM, NU = NC * UPC;
-    static_assert(UM == 32 || UM == 16, "operand unit: a chunk or half a chunk");
+    // (MF + Adam at K = 768 with fused noise, the tightest variant: quarter-chunk units -- 2 x 16 operand registers less,
+    // 256 cycles of MFMAs still cover the LDS latency -- instead of 10 spilled registers)
+    constexpr int UM = (ADAM && MODE == MODE_MF && KCH == 6 && !REPLAY) ? 8 : CCVM_CL_UNIT, UPC = 32 / UM, NU = NC * UPC;
+    static_assert(UM == 32 || UM == 16 || UM == 8, "operand unit: a chunk, half or a quarter of a chunk");
     float bq[2][UM];  // B operands of a unit; the first unit's now
     auto read_ops = [&](float (&dst)[UM], const float* src) {  // the UM operands of one unit
 #pragma unroll

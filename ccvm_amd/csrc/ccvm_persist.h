@@ -81,6 +81,21 @@ __device__ __forceinline__ void mfma_chain(const float* af, const float* qf, f32
     ((acc[K & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[K / KC], qf[K], acc[K & 3], CBSZ, K % KC, 0)), ...);
 }
 
+// the same for k = OFF .. OFF + sizeof...(I) - 1
+template <int CBSZ, int KC, int OFF, int... I>
+__device__ __forceinline__ void mfma_chain_at(const float* af, const float* qf, f32x4v* acc,
+                                              std::integer_sequence<int, I...>) {
+    ((acc[(OFF + I) & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[(OFF + I) / KC], qf[OFF + I], acc[(OFF + I) & 3], CBSZ,
+                                                              (OFF + I) % KC, 0)), ...);
+}
+
+// K tail (measured and left off): the last chunk of 16 k-steps runs only the groups of four that hold
+// a k < N (N = 100: 100 MFMAs per
+// step instead of 112; wave-uniform scalar branches behind the straight-line part)
+#ifndef CCVM_PERSIST_KTAIL
+#define CCVM_PERSIST_KTAIL 0   // measured: DL N = 100 0.967 / 0.980 us per step without, 0.978 / 0.956 with -- no gain, off
+#endif
+
 template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU>
 __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
@@ -256,7 +271,16 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         if constexpr (NOISE_FIRST) make_step_noise();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(CCVM_PERSIST_ABL & 1)) {
-            mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, 16 * NCH>{});
+            if constexpr (CCVM_PERSIST_KTAIL) {
+                constexpr int FULL = 16 * (NCH - 1);
+                mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, FULL + 4>{});
+                const int rem = N - FULL;  // 1 .. 16 k-steps of the last chunk are real
+                if (rem > 4) mfma_chain_at<CBSZ, KC, FULL + 4>(af, qf, acc, std::make_integer_sequence<int, 4>{});
+                if (rem > 8) mfma_chain_at<CBSZ, KC, FULL + 8>(af, qf, acc, std::make_integer_sequence<int, 4>{});
+                if (rem > 12) mfma_chain_at<CBSZ, KC, FULL + 12>(af, qf, acc, std::make_integer_sequence<int, 4>{});
+            } else {
+                mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, 16 * NCH>{});
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < 16 * NCH / KC; ++c) acc[c & 3][0] += af[c] * qf[c];

@@ -157,14 +157,19 @@ int ccvm_unpack(const float* src, int src_ld,
 /* ---- the hot path: nsteps fused Euler-Maruyama steps ------------------------- */
 /* Bytes of caller-provided scratch a call needs (ping-pong state, the MF measured-amplitude
  * buffers, column sums of Q, schedule table; for 256 < N <= 768 the column-cluster path's exchange
- * buffers of 8-byte {value, tag} packets; a status word).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
+ * buffers of 8-byte {value, tag} packets, and the column-slab path's for small batches above N = 256; a status
+ * line).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
  * 2 ccvm_langevin_run, 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);
 /* Byte offset, inside the workspace of ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2),
- * of a 4-byte status word; (size_t)-1 for the other entries.  The caller zeroes it once (a fresh workspace) and may
- * read it after synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of the column-cluster
- * persistent path (256 < N <= 768) gave up because its workgroups could not become resident (another
- * process holding the GPU for ~1 s) -- the state arrays are then invalid.  Run calls never clear it. */
+ * of a 128-byte line whose first 4 bytes are the run's status word; (size_t)-1 for the other entries.  The caller
+ * zeroes the LINE once (a fresh workspace: simplest is to zero the whole workspace) and may read the status word after
+ * synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of a persistent path whose workgroups exchange data
+ * (column-cluster kernel, 256 < N <= 768; column-slab kernel, small batches above N = 256) gave up because its
+ * workgroups could not become resident (another process holding the GPU for ~1 s) -- the state arrays are then
+ * invalid: restore them and repeat the steps with CCVM_RUN_NO_EXCHANGE.  Run calls never clear the status word.  The
+ * rest of the line is the library's: it records what the exchange area in front of it holds, so that a later call
+ * on the same workspace with later steps does not clear the area again. */
 size_t ccvm_status_offset(int solver, int B, int N);
 /* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
