@@ -174,7 +174,7 @@ def workload_params(kind):
     return p
 
 
-def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None):
+def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None, adam=None):
     from ccvm_amd import engine
     from ccvm_amd.workloads import scaled_qv
 
@@ -182,7 +182,7 @@ def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None):
     prob = engine.DeviceProblem(q, v)
     noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=rank * b if row_offset is None else row_offset)
     ekind = {"dl": "dl", "mf": "mf"}.get(kind, "langevin")
-    return engine.Trajectories(prob, b, ekind, total_steps, workload_params(kind), (0.0, 1.0), noise), q, v
+    return engine.Trajectories(prob, b, ekind, total_steps, workload_params(kind), (0.0, 1.0), noise, adam=adam), q, v
 
 
 def cpu_model():
@@ -281,14 +281,14 @@ def family_roof(launch, kind, n, b, step_us):
     floor, achieved = steps/s measured."""
     import re
 
-    m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, spread)?",
+    m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, each over \d+ XCDs)?",
                   launch)
     if not m:
         return {}
     cgrp, nq, clusters, members, cols, rows, k, spread = m.groups()
     planes = 2 if kind == "dl" else 1
     mfma_us = planes * (int(rows) // 4) * int(nq) * 8 / 2400.0  # 4x4x1 MFMAs of a wave x 8 cycles at 2.4 GHz
-    handoff_us = 2.4 if spread else 0.8                         # allgather over the chip / hand-off inside an XCD
+    handoff_us = 2.4 if spread else 0.8                         # across the fabric / hand-off inside an XCD
     floor_us = handoff_us + mfma_us
     return {
         "bound": "latency", "achieved": 1e6 / step_us, "peak": 1e6 / floor_us, "unit": "steps/s",

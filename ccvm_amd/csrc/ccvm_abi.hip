@@ -456,7 +456,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
     if (exchange_prepare(area, 2 * half, p.K, p.G * 4 * p.cgrp, sa.status, xid, step0, st)) return CCVM_E_HIP;
     sa.seed = nz->seed; sa.row_offset = nz->row_offset; sa.replay = nz->mode == CCVM_NOISE_REPLAY;
     sa.B = B; sa.N = N; sa.ld = ld;
-    sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.spread = p.spread;
+    sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.span = p.span;
     sa.nxcd = chip_of(tun).xcds;
     return CCVM_OK;
 }
@@ -542,10 +542,10 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
     if (const SlabPlan sp = want_persist(N, tun) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
-        const int nx = chip_of(tun).xcds;
+        char where[48] = "";
+        if (sp.span > 1) std::snprintf(where, sizeof(where), ", each over %d XCDs", sp.span);
         std::snprintf(buf, buf_len, "ccvm::slab_kernel<%d, %d, %d> grid %d x 256 threads (%d clusters of %d workgroups x %d columns, %d rows each, K = %d%s), up to %d steps per launch",
-                      solver, sp.cgrp, sp.nq, sp.spread ? sp.nclusters * sp.G : (sp.nclusters + nx - 1) / nx * nx * sp.G,
-                      sp.nclusters, sp.G, 4 * sp.cgrp, 4 * sp.rg, sp.K, sp.spread ? ", spread over the XCDs" : "", TABLE_STEPS);
+                      solver, sp.cgrp, sp.nq, sp.grid, sp.nclusters, sp.G, 4 * sp.cgrp, 4 * sp.rg, sp.K, where, TABLE_STEPS);
         return CCVM_OK;
     }
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {

@@ -32,11 +32,11 @@
 // is one contiguous run of C x 32 bytes (C = 4: exactly one 128-byte line) written by 16-byte stores
 // {x_row, tag, x_row+1, tag}, and a reader's 16-byte loads are contiguous over the whole input.
 //
-// Placement: with G members per cluster and ceil(clusters / XCDs) * G <= CUs per XCD a cluster stays inside one
-// XCD (blocks b, b + XCDs, ... share one: speed only, its exchange stays in that L2); otherwise G consecutive
-// blocks form a cluster and the exchange crosses the fabric (sc1 is agent scope: still coherent).  Workgroups
-// are dispatched in order, so at most one cluster per XCD (or per chip) is ever partially resident; every spin
-// is bounded all the same (status word + LDS flag, as in ccvm_cluster.h).
+// Placement: a cluster's members are confined to the smallest group of XCDs that holds them (1, 2, 4 or all 8; blocks
+// b, b + 8, ... share an XCD: speed only): inside one XCD the exchange stays in that L2 (a hand-off round trip of ~1000
+// cycles against ~3500 across the fabric); N > 1024 needs 63 members of 32 columns = two XCDs.  Workgroups are
+// dispatched in order and the whole grid is resident (one workgroup per CU); every spin is bounded all the same
+// (status word + LDS flag, as in ccvm_cluster.h).
 //
 // Same noise definition (global row, column, step), folded affine input map and pinned update arithmetic as the
 // other three kernel families; only the summation order of the contraction differs.
@@ -77,7 +77,7 @@ struct SlabArgs {
     int replay, adam;
     int B, N, ld;
     int nclusters, G, RG;  // clusters of G members; a cluster owns 4 RG batch rows
-    int spread;          // 1: a cluster = G consecutive blocks; 0: a cluster stays in one XCD
+    int span;            // XCDs a cluster's members are confined to (1, 2, 4, ... nxcd): speed only
     int nxcd;            // XCDs of the device (blocks b and b + nxcd share one)
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
     float in_scale, in_shift;
@@ -130,7 +130,7 @@ template <int MODE, int CGRP, int NQ>
 __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "slab kernel: solver loops only");
     static_assert(CGRP == 1 || CGRP == 2 || CGRP == 4 || CGRP == 8, "column groups per member");
-    static_assert(NQ % CGRP == 0 && NQ <= 128, "Q registers per lane");
+    static_assert(NQ % CGRP == 0 && NQ <= 256, "Q registers per lane (one wave per SIMD: 512 registers)");
     constexpr int C = 4 * CGRP;
     constexpr int KRES = 16 / CGRP;          // k residues inside one MFMA
     constexpr int NA = NQ / CGRP;            // A registers per wave, row group and plane (16 k each)
@@ -149,15 +149,12 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = a.G, RG = a.RG;
-    int cluster, member;
-    if (a.spread) {
-        cluster = blockIdx.x / G;
-        member = blockIdx.x % G;
-    } else {
-        const int xcd = blockIdx.x % a.nxcd, idx = blockIdx.x / a.nxcd;
-        cluster = (idx / G) * a.nxcd + xcd;
-        member = idx % G;
-    }
+    // Placement (speed only): blocks b, b + nxcd, ... share an XCD; a cluster's members are confined to a group of
+    // `span` XCDs (1: its exchange stays in one L2; nxcd: round-robin over the chip), the groups take the clusters in turn
+    const int xcd = blockIdx.x % a.nxcd, idx = blockIdx.x / a.nxcd;
+    const int slot = idx * a.span + xcd % a.span;          // position inside the group's run of members
+    const int cluster = (slot / G) * (a.nxcd / a.span) + xcd / a.span;
+    const int member = slot % G;
     if (cluster >= a.nclusters) return;  // a whole cluster out of range: nobody waits for it
     const int N = a.N, ld = a.ld;
     const int col0 = member * C;
@@ -303,6 +300,12 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         for (int j = 0; j < NLD; ++j) asm("v_min3_u32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(w[j][1]), "v"(w[j][3]));
         return __builtin_amdgcn_ballot_w64(lo != want) == 0;
     };
+    // what a wave sleeps before its first loads of a step (x 64 cycles): waves without owners start with what the
+    // generator takes; self-tuning below
+    int delay = (wave * 64 >= EP) ? CCVM_SL_DELAY : 0;
+    if (a.span > 1) delay += 28;  // across the fabric the packets take ~2000 cycles longer (converged values measured)
+    const int up = a.span > 1 ? 4 : 3, down_mask = a.span > 1 ? 7 : 1023;
+    bool retried = false;
     bool dead = false;
     auto await = [&](int b, int par, unsigned want, u32x4s (&w)[NLD]) {
         if constexpr (CCVM_SLAB_ABL & 4) return;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 break;
             }
             if constexpr (CCVM_SLAB_ABL & 64) seg[7] += 1;
+            retried = true;
             __builtin_amdgcn_s_sleep(CCVM_SL_SLEEP);
             // only the pieces that have not arrived travel again (a retry of the whole unit is 8 MB per round and
             // chip at N = 1000): the lanes of an arrived piece load from beyond the buffer (range-checked: zeros, no
@@ -347,7 +351,6 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         }
     };
 
-    const bool wave_delay = wave * 64 >= EP;  // no owner in this wave
     Row rnext = load_row(0);
     __syncthreads();  // xs is zeroed, DEAD is initialised
     if constexpr (CCVM_SLAB_ABL & 64) { unsigned long long dummy = 0; mark(dummy); }
@@ -377,14 +380,27 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                 stream_normals(step, it, nz);
             }
         }
-        if (wave_delay) __builtin_amdgcn_s_sleep(CCVM_SL_DELAY);
+        for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
         rnext = load_row(min(it + 1, a.nsteps - 1));
+        retried = false;
         issue(0, par, wa);
         mark(seg[0]);
         for (int u = 0; u < TU && !dead; u += 2) {
             if (u + 1 < TU) issue(u + 1, par, wb);
             await(u, par, want, wa);
-            if (u == 0) mark(seg[1]);
+            if (u == 0) {
+                mark(seg[1]);
+                // Self-tuning delay (x 64 cycles) before the first loads of a step: a miss costs a round trip (~1000
+                // cycles inside an XCD, ~3500 across the fabric) plus the retry's bookkeeping, waiting a little too
+                // long costs 64 cycles a unit.  Inside an XCD arrival times are steady and a cluster advances at the pace
+                // of its slowest wave (~100 waves probing downwards: somebody always misses), so a miss adds three units
+                // and only 1024 clean steps take one off; across the fabric the arrival times wander and the delay has to
+                // follow them: four units up, one off every eight clean steps (measured, us per step, static / slow /
+                // fast: N = 1000 B = 32 in XCDs 1.92 / 1.99 / 2.17; N = 2000 B = 32 over two XCDs 10.5 / 7.2 / 6.4; N = 1000
+                // B = 4 over the chip 3.0 / 2.7 / 2.2).  Timing only: the result does not depend on it.
+                if (retried) delay = min(delay + up, 192);
+                else if ((it & down_mask) == down_mask && delay > 0) delay -= 1;
+            }
             stage(u, wa);
             if (u + 2 < TU) issue(u + 2, par, wa);
             if (u + 1 < TU) {
@@ -522,14 +538,15 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
 }
 
 // ---- host side: the shapes that exist, and the plan for (B, N) -------------------------------------------
-// K = 64 NQ / CGRP in {512, 768, 1024, 1280, 1536, 2048}; NQ <= 128 registers per lane
+// K = 64 NQ / CGRP in {512, 768, 1024, 1280, 1536, 2048}; NQ <= 256 registers per lane
 struct SlabPlan {
     int ok;        // 0: the slab path does not serve this shape
     int cgrp, nq;  // template parameters
     int K;
     int rg;        // row groups of 4 per cluster
     int G, nclusters;
-    int spread;
+    int span;      // XCDs a cluster's members are confined to
+    int grid;
 };
 
 // The chip as the launch policy sees it (queried once per device by the ABI; tests pass their own)
@@ -546,29 +563,36 @@ inline int slab_k_for(int N) {
 }
 
 // Fewest rows per cluster first (the fetched input per member and step is R K packets, the contraction R C K MACs);
-// for that row count a cluster that fits one XCD if there is one (measured, N = 1000, B = 4, us per step: 32 members
-// x 32 columns inside an XCD 1.89; 63 x 16 / 125 x 8 / 250 x 4 spread over the chip 3.3 / 3.3 / 3.0: across the
-// fabric a hand-off round trip is ~3500 cycles against ~1000 inside an L2), else the narrowest member whose
-// clusters fit the chip.  force_cgrp / force_rg (tuning): 0 = choose.
+// for that row count the fewest XCDs per cluster (measured, N = 1000, B = 4, us per step: 32 members x 32 columns
+// inside an XCD 1.89; 63 x 16 / 125 x 8 / 250 x 4 over the chip 3.3 / 3.3 / 3.0: across the fabric a hand-off round
+// trip is ~3500 cycles against ~1000 inside an L2), then the narrowest member.  force_cgrp / force_rg (tuning): 0 =
+// choose.  Member widths: K C / 64 registers per lane hold the slab, at most 256 (one wave per SIMD).
 inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, int force_cgrp = 0, int force_rg = 0) {
     SlabPlan p{};
     if (N < SL_MIN_N || N > SL_MAX_N || B < 1 || B > SL_MAX_B || chip.cus < 8 || chip.xcds < 1) return p;
+    if (chip.cus % chip.xcds) return p;
     const int K = slab_k_for(N);
     const int cus_per_xcd = chip.cus / chip.xcds;
     for (int rg = 1; rg <= 32; ++rg) {
         if (force_rg && rg != force_rg) continue;
         if (planes * rg * K * 4 > SL_XS_FLOATS) break;
         const int nclusters = (B + 4 * rg - 1) / (4 * rg);
-        for (int pinned = 1; pinned >= 0; --pinned) {
+        int spans[8], nspans = 0;  // powers of two that divide the XCD count, then the whole chip
+        for (int sp = 1; sp < chip.xcds && nspans < 7 && chip.xcds % sp == 0; sp *= 2) spans[nspans++] = sp;
+        spans[nspans++] = chip.xcds;
+        for (int si = 0; si < nspans; ++si) {
+            const int span = spans[si];
+            const int groups = chip.xcds / span;
+            const int per_group = (nclusters + groups - 1) / groups;  // clusters a group of XCDs holds
             for (int cgrp = 1; cgrp <= 8; cgrp *= 2) {
                 if (force_cgrp && cgrp != force_cgrp) continue;
                 const int C = 4 * cgrp, nq = K * cgrp / 64;
-                if (nq > 128 || rg * C > SL_MAX_RC) continue;
+                if (nq > 256 || rg * C > SL_MAX_RC) continue;
                 const int G = (N + C - 1) / C;
-                const bool fits_xcd = ((nclusters + chip.xcds - 1) / chip.xcds) * G <= cus_per_xcd;
-                if (pinned ? !fits_xcd : (long)nclusters * G > chip.cus) continue;
+                if ((long)per_group * G > (long)span * cus_per_xcd) continue;
                 p.ok = 1; p.cgrp = cgrp; p.nq = nq; p.K = K; p.rg = rg; p.G = G; p.nclusters = nclusters;
-                p.spread = !fits_xcd;
+                p.span = span;
+                p.grid = (per_group * G + span - 1) / span * chip.xcds;
                 return p;
             }
         }
@@ -593,22 +617,16 @@ void launch_slab_nq(const SlabArgs& a, const SlabPlan& p, int grid, hipStream_t 
         case 512: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 8 * CGRP>), g, b, 0, st, a); break;
         case 768: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 12 * CGRP>), g, b, 0, st, a); break;
         case 1024: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 16 * CGRP>), g, b, 0, st, a); break;
-        case 1280:
-            if constexpr (CGRP <= 4) hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP>), g, b, 0, st, a);
-            break;
-        case 1536:
-            if constexpr (CGRP <= 4) hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP>), g, b, 0, st, a);
-            break;
-        case 2048:
-            if constexpr (CGRP <= 4) hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 32 * CGRP>), g, b, 0, st, a);
-            break;
+        case 1280: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP>), g, b, 0, st, a); break;
+        case 1536: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP>), g, b, 0, st, a); break;
+        case 2048: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 32 * CGRP>), g, b, 0, st, a); break;
         default: break;
     }
 }
 
 template <int MODE>
 void launch_slab(const SlabArgs& a, const SlabPlan& p, hipStream_t st) {
-    const int grid = (p.spread ? p.nclusters * p.G : ((p.nclusters + a.nxcd - 1) / a.nxcd) * a.nxcd * p.G) - a.drop;
+    const int grid = p.grid - a.drop;
     switch (p.cgrp) {
         case 1: launch_slab_nq<MODE, 1>(a, p, grid, st); break;
         case 2: launch_slab_nq<MODE, 2>(a, p, grid, st); break;

@@ -31,9 +31,9 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "step_kernel<2" in _describe(hip_lib, 2, 512, 2000)
     d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
     assert "slab_kernel<0, 8, 128>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
-    assert "spread" not in d
-    d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: a cluster spans XCDs
-    assert "slab_kernel<2" in d and "spread over the XCDs" in d
+    assert "XCDs" not in d
+    d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: 63 members of 32 columns = two XCDs
+    assert "slab_kernel<2, 8, 256>" in d and "each over 2 XCDs" in d
     assert "step_kernel" in _describe(hip_lib, 2, 64, 2000)                # no plan: 64 rows x 2048 do not fit
 
 
@@ -64,10 +64,10 @@ def test_slab_plans_fit_the_geometry_they_are_given(hip_lib, clean_env, geometry
     clusters, members, cols, rows, k = map(int, re.search(
         r"\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)", d).groups())
     assert clusters * rows >= b and members * cols >= n and k >= n
-    if "spread" in d:
-        assert clusters * members <= cus
-    else:
-        assert -(-clusters // xcds) * members <= cus // xcds
+    span = int(re.search(r"each over (\d+) XCDs", d).group(1)) if "each over" in d else 1
+    groups = xcds // span
+    assert -(-clusters // groups) * members <= span * (cus // xcds)
+    assert int(re.search(r"grid (\d+) x 256", d).group(1)) <= cus
 
 
 def test_no_plan_means_the_tile_kernel(hip_lib, clean_env):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The round's un-profiled bench lines on the GPU box (developer tool): gpurun_out/<tag>_bench*.json
-#   usage: tools/bench_round.sh <round tag, e.g. r02>      (then tools/collect_profiles.sh <tag>)
+#   usage: tools/bench_round.sh <round tag, e.g. r03>      (then tools/collect_profiles.sh <tag>)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
@@ -13,5 +13,11 @@ python3 bench.py --workload pl_n2000_b512 --post adam > $O/${TAG}_bench_pl_adam.
 for w in dl_n100_b1000 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000; do
   python3 bench.py --workload $w > $O/${TAG}_bench_$w.json 2>> $O/${TAG}_bench.err || exit 1
 done
+# small batches (column-slab kernel): 8192 steps = two launches
+for w in dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32; do
+  python3 bench.py --workload $w --steps 8192 --warmup 1024 > $O/${TAG}_bench_$w.json 2>> $O/${TAG}_bench.err || exit 1
+done
 CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 1000 --warmup 100 --no-cpu-baseline > $O/${TAG}_bench_gpus2_share.json 2>> $O/${TAG}_bench.err || exit 1
+# strong scaling (BASELINE config 5's global batch split over the ranks), rehearsed on one GPU over gloo
+CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --workload pl_n2000_b512 --post adam --global-batch 4096 --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_gpus2_share_strong.json 2>> $O/${TAG}_bench.err || exit 1
 echo BENCH_DONE

@@ -8,14 +8,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 def parse(path):
     out = {}
     for line in open(path):
-        m = re.match(r"(\w+):(\d+):(\d+)\s+RU=\w+\s+([\d.]+) us/step", line)
+        m = re.match(r"(\w+):(\d+):(\d+)(:adam)?\s+RU=\w+\s+([\d.]+) us/step", line)
         if m:
-            out[(m.group(1), int(m.group(2)), int(m.group(3)))] = float(m.group(4))
+            out[(m.group(1) + (" + Adam" if m.group(4) else ""), int(m.group(2)), int(m.group(3)))] = float(m.group(5))
     return out
 
 
 auto, tile = parse("gpurun_out/size_sweep_auto.txt"), parse("gpurun_out/size_sweep_tile.txt")
-flops = {"dl": 4, "mf": 2, "langevin": 2, "pl": 2}
+flops = {"dl": 4, "mf": 2, "langevin": 2, "pl": 2, "mf + Adam": 2, "langevin + Adam": 2}
 
 
 def path(n):

@@ -49,10 +49,9 @@ int main(int argc, char** argv) {
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb; a.xb1 = (float*)((char*)xb + half); a.table = table;
     a.seed = 7; a.nsteps = steps; a.status = sync;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
-    a.nclusters = p.nclusters; a.G = p.G; a.RG = p.rg; a.spread = p.spread; a.nxcd = 8;
-    if (getenv("SL_SPREAD")) a.spread = atoi(getenv("SL_SPREAD"));
-    SlabPlan q = p; q.spread = a.spread;
-    const int grid = q.spread ? q.nclusters * q.G : (q.nclusters + 7) / 8 * 8 * q.G;
+    a.nclusters = p.nclusters; a.G = p.G; a.RG = p.rg; a.span = p.span; a.nxcd = 8;
+    SlabPlan q = p;
+    const int grid = q.grid;
     unsigned long long* dbg; hipMalloc(&dbg, (size_t)grid * 16 * 8); hipMemset(dbg, 0, (size_t)grid * 16 * 8);
     a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -65,9 +64,9 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
-        if (rep == 2) printf("%s ABL=%2d SLEEP=%d N=%d B=%d: %d clusters x %d members x %d columns, %d rows, K=%d%s, grid %d: %.3f us/step%s\n",
+        if (rep == 2) printf("%s ABL=%2d SLEEP=%d N=%d B=%d: %d clusters x %d members x %d columns, %d rows, K=%d, %d XCD(s) per cluster, grid %d: %.3f us/step%s\n",
                              MODE == MODE_DL ? "DL" : "LV", CCVM_SLAB_ABL, CCVM_SL_SLEEP, N, B, p.nclusters, p.G, 4 * p.cgrp, 4 * p.rg, p.K,
-                             q.spread ? " spread" : " pinned", grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
+                             q.span, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
     }
     if (CCVM_SLAB_ABL & 64) {
         std::vector<unsigned long long> hd((size_t)grid * 16);

@@ -1,5 +1,6 @@
-"""Per-step time of the persistent small-N path (developer tool).
-   python tools/time_small.py [kind:N:B ...]     kinds: dl mf langevin pl"""
+"""Per-step time of the engine for kind:N:B[:adam] cases (developer tool).
+   python tools/time_small.py [kind:N:B[:adam] ...]     kinds: dl mf langevin pl; ":adam" = the Adam variant of the
+   example scripts (alpha 0.001, beta1 0.9, beta2 0.999)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,9 +10,10 @@ cases = sys.argv[1:] or ["dl:20:1000", "dl:64:1000", "dl:100:1000", "dl:128:1000
                          "langevin:20:1000", "langevin:100:1000", "pl:100:1000", "dl:100:4000", "dl:20:100"]
 steps = 4096
 for case in cases:
-    kind, n, b = case.split(":")
+    kind, n, b, *rest = case.split(":")
     n, b = int(n), int(b)
-    traj, _, _ = bench.make_trajectories(kind, n, b, 1 << 20, 0)
+    adam = {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False} if rest == ["adam"] else None
+    traj, _, _ = bench.make_trajectories(kind, n, b, 1 << 20, 0, adam=adam)
     traj.advance(steps)
     torch.cuda.synchronize()
     best = 1e9
@@ -20,5 +22,6 @@ for case in cases:
         traj.advance(steps)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
-    print(f"{case:20s} RU={os.environ.get('CCVM_AMD_PERSIST_RU', 'auto'):4s} {best / steps * 1e6:8.3f} us/step "
+    traj.check()
+    print(f"{case:24s} RU={os.environ.get('CCVM_AMD_PERSIST_RU', 'auto'):4s} {best / steps * 1e6:8.3f} us/step "
           f"{steps * b / best:.3e} row-steps/s", flush=True)
