@@ -34,7 +34,9 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "XCDs" not in d
     d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: 63 members of 32 columns = two XCDs
     assert "slab_kernel<2, 8, 256>" in d and "each over 2 XCDs" in d
-    assert "step_kernel" in _describe(hip_lib, 2, 64, 2000)                # no plan: 64 rows x 2048 do not fit
+    assert "16 rows each" in _describe(hip_lib, 2, 64, 2000)               # four clusters of 16 rows
+    assert "step_kernel" in _describe(hip_lib, 2, 128, 2000)               # no plan: 32 rows x 2048 do not fit in LDS
+    assert "step_kernel" in _describe(hip_lib, 0, 64, 2000)                # DL: two planes
 
 
 @pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])
