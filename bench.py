@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -153,6 +154,13 @@ def profiled_counters(workload):
         out["traffic_bytes_per_step"] = 1024.0 * (2.0 * c["FETCH_SIZE"]["mean_per_dispatch"]
                                                   + c["WRITE_SIZE"]["mean_per_dispatch"]) / doc.get("steps_per_dispatch", 1.0)
         out["dispatches"] = c["FETCH_SIZE"]["dispatches"]
+    m = re.search(r"persist_kernel<[^>]*> = .*B=(\d+)", doc.get("kernel") or "")
+    if "SQ_INSTS_VALU" in c and m:
+        # row-owner kernel: 256-thread workgroups of four waves; rows per workgroup from the kernel's own grid is not in
+        # the summary, but SQ_VALU_MFMA_BUSY_CYCLES / 8 cycles = MFMAs issued = waves x steps x 16 NCH
+        nch = int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, (\d+),", doc["kernel"]).group(1))
+        wave_steps = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 8.0 / (16 * nch)
+        out["valu_per_wave_step"] = c["SQ_INSTS_VALU"]["mean_per_dispatch"] / wave_steps
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # MFMA_BUSY is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (its
         # per-engine value is the kernel's length in cycles)
@@ -271,7 +279,7 @@ def tts99_leg():
     }
 
 
-def family_roof(launch, kind, n, b, step_us):
+def family_roof(launch, kind, n, b, step_us, wall_step_us):
     """Extra roofline fields for the kernel families whose binding roof is not the fp32 MFMA peak.
 
     slab_kernel (small batches, Q in registers, ccvm_slab.h): no byte of Q moves, the contraction of a member is
@@ -281,6 +289,26 @@ def family_roof(launch, kind, n, b, step_us):
     floor, achieved = steps/s measured."""
     import re
 
+    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x 256", launch)
+    if pm:
+        # Row-owner persistent kernel (N <= 256): one wave per SIMD issues its step's instructions one after the other
+        # (f32 MFMA and VALU do not overlap on a SIMD: tools/coissue.hip), so the roof is the ISSUE time of a step:
+        # 16 NCH v_mfma_f32_4x4x1 x 8 cycles + the other vector instructions x 4 cycles (one wave alone on a SIMD).
+        # The instruction count comes from the committed SQ pass of this workload; without one no roof is claimed.
+        nch, grid = int(pm.group(5)), int(pm.group(7))
+        prof = profiled_counters(f"{kind}_n{n}_b{b}")
+        if not prof or "valu_per_wave_step" not in prof:
+            return {}
+        mfma = 16 * nch
+        issue = 8.0 * mfma + 4.0 * (prof["valu_per_wave_step"] - mfma)
+        return {
+            "bound": "issue", "achieved": 1e6 / step_us, "peak": 2400.0e6 / issue, "unit": "steps/s",
+            "frac": issue / 2400.0 / step_us, "frac_wall": issue / 2400.0 / wall_step_us,
+            "issue_cycles_per_step": {"mfma": 8.0 * mfma, "other_valu": 4.0 * (prof["valu_per_wave_step"] - mfma),
+                                      "source": prof["source"] + " (SQ_INSTS_VALU per wave and step, MFMAs included)",
+                                      "clock_MHz": 2400},
+            "mfma_frac": 2.0 * (2 if kind == "dl" else 1) * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        }
     m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, each over \d+ XCDs)?",
                   launch)
     if not m:
@@ -292,7 +320,7 @@ def family_roof(launch, kind, n, b, step_us):
     floor_us = handoff_us + mfma_us
     return {
         "bound": "latency", "achieved": 1e6 / step_us, "peak": 1e6 / floor_us, "unit": "steps/s",
-        "frac": floor_us / step_us,
+        "frac": floor_us / step_us, "frac_wall": floor_us / wall_step_us,
         "latency_floor_us": {"handoff": handoff_us, "member_mfma": mfma_us,
                              "source": "MI355X_MICROARCH.md price list: handoff-1to1 0.8 us (one XCD, idle) / "
                                        "allgather 2.4 us (256 CUs, 8 KB); v_mfma_f32_4x4x1 8 cycles"},
@@ -465,7 +493,7 @@ def main():
             "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
             "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
-        roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3))
+        roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3, wall_ms_per_step * 1e3))
         out = {
             "metric": metric,
             "value": args.steps * global_rows / elapsed,

@@ -18,7 +18,7 @@
 //
 // Contraction: v_mfma_f32_4x4x1_16B_f32, sixteen independent 4 x 4 outer products per instruction.  The K range
 // is split over the four waves (one per SIMD) and, inside a wave, over the instruction's blocks: block
-// b = kr * CGRP + cg handles k residue kr (of KRES = 16 / CGRP) and column group cg (of CGRP = C / 4); the four
+// b = kr * CGRP + cg handles k residue class kr (of KRES = 16 / CGRP) and column group cg (of CGRP = C / 4); the four
 // rows of a row group are the A operand, broadcast over the column groups (CBSZ / ABID, as in ccvm_persist.h:
 // one ds_read_b32 of the staged input feeds CGRP MFMAs).  The matvec rows are then reduced at WAVEFRONT level
 // (log2 KRES butterfly steps over the k residues) and over the four waves through LDS (4 x R x C floats); the
@@ -162,18 +162,21 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     if (tid == 0) lds[DEAD] = 0.0f;
 
     // ---- Q slab, resident in registers for the whole launch -----------------------------------------
-    // lane = 4 (kr CGRP + cg) + j: B operand of MFMA q is Q[kw0 + q KRES + kr][col0 + 4 cg + j]
+    // lane = 4 (kr CGRP + cg) + j.  MFMA q = a CGRP + m of a wave covers, in residue kr, k = kw0 + 16 a + kr CGRP + m:
+    // its B operand is Q[k][col0 + 4 cg + j], its A operand x[row j][k] comes from block (kr, cg = m) of A register a
+    // -- so lane (kr, cg, j) reads x[row j][kw0 + 16 a + kr CGRP + cg], i.e. float kw0 * 4 + 64 a + lane of the block:
+    // one conflict-free ds_read_b32 per A register (with k = ... + m KRES + kr the eight column groups of C = 32 put two
+    // lanes of a half-wave on every bank: SQ_LDS_BANK_CONFLICT 256 cycles per CU and step)
     const int blk = lane >> 2, j4 = lane & 3;
     const int kr = blk / CGRP, cg = blk % CGRP;
     const int kw0 = wave * KW;
     float qf[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int k = kw0 + q * KRES + kr;
+        const int k = kw0 + (q / CGRP) * 16 + kr * CGRP + (q % CGRP);
         qf[q] = (k < ld) ? a.Q[(size_t)k * ld + col0 + 4 * cg + j4] : 0.0f;  // (col0 + C <= ld: C divides 128)
     }
-    // A operand a of a (plane, row group) block: x[row j][kw0 + 16 a + cg KRES + kr]
-    const int a_off = (kw0 + cg * KRES + kr) * 4 + j4;
+    const int a_off = kw0 * 4 + lane;
 
     // ---- owners: lane t < 2 RG C owns rows 2 h, 2 h + 1 of row group org at column col ------------------
     const int EP = 2 * RG * C;

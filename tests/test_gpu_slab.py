@@ -185,7 +185,8 @@ def test_slab_per_variable_saturation(slab):
         os.environ["CCVM_AMD_KERNEL"] = "slab"
         for k in out["tile"]:
             scale = max(1.0, float(out["tile"][k].abs().max()))
-            assert float((out["slab"][k] - out["tile"][k]).abs().max()) <= 1e-4 * scale, (kind, k)
+            gate = ATOL_X * (n / 20.0) ** 0.5 * scale  # the stated tolerance: two summation orders of the contraction
+            assert float((out["slab"][k] - out["tile"][k]).abs().max()) <= gate, (kind, k)
 
 
 def test_slab_long_trajectory_under_uneven_load(slab):
