@@ -294,7 +294,7 @@ size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float);
 // the per-step kernel; read once per ABI call so a test can flip it between calls).
 bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
-// ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 512, one-stream solvers ---------
+// ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 768, every solver and Adam variant ---------
 // batch rows per cluster: two row sets of 16, three above K = 512 (ccvm_cluster.h: NSETS)
 int cluster_rows(int N) { return round_up(N, 128) > CL_LDS_K ? 3 * CL_ROWS : 2 * CL_ROWS; }
 int cluster_count(int B, int N) { return (B + cluster_rows(N) - 1) / cluster_rows(N); }

@@ -22,7 +22,7 @@ Each function cites the reference lines it restates (paths relative to
 
 Noise: a source object with ``draw(step, stream, n, b) -> (b, n) tensor``.
 ``TorchStreamNoise`` consumes a torch CPU generator exactly as the reference does;
-``oracle.philox_ref.PhiloxNoise`` reproduces the engine's fused generator.
+``oracle.noise_ref.FusedNoise`` reproduces the engine's fused generator.
 """
 import math
 
