@@ -426,8 +426,8 @@ int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V,
 }
 
 // ---- column-slab persistent path (ccvm_slab.h): small batches above N = 256 --------------------------------
-// Default policy: the slab path wherever its plan exists (slab_plan: the batch's clusters fit the chip with <= 128 KB
-// of staged input per member).  Measured, us per step, slab vs what ran before (gpurun_out/slab8.txt,
+// Default policy: the slab path wherever its plan exists (slab_plan: the batch's clusters fit the chip with at most
+// 512 row pairs per member), except large batches at N <= 512 (below).  Measured, us per step, slab vs what ran before (gpurun_out/slab8.txt,
 // profiles/r03_small_batch.md): DL N = 1000: B <= 32 3.05 vs 18.5, B = 64 5.0 vs 18.8, B = 128 9.5 vs 19.4; Langevin
 // N = 1000: B = 32 2.1 vs 10.7, B = 128 5.7 vs 11.0; N = 500: Langevin B = 32 / 256 1.55 / 3.7 vs 4.8 (cluster kernel),
 // DL B = 128 3.6 vs 9.9; clusters spread over the XCDs (N > 1024): PL N = 2000 B = 8 / 32 5.6 / 13.9 vs 17.5, DL
@@ -439,6 +439,15 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     const SlabPlan p = slab_plan(B, N, planes, chip_of(tun), tun.slab_cgrp, tun.slab_rg);
     if (!p.ok) return none;
     if ((size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE >= ((size_t)1 << 31)) return none;
+    // up to N = 512 the alternative is the cluster kernel, whose time per step does not grow with the batch: beyond
+    // ~20 rows per cluster (DL ~28) it wins (N = 500, us per step, slab vs cluster: Langevin B = 256 3.4 vs 4.9, B = 512
+    // 6.2 vs 4.9; DL B = 256 5.7 vs 9.9, B = 512 10.8 vs 10.0; N = 300 B = 512: 4.9 vs 3.8)
+    if (tun.slab < 0 && N <= CL_LDS_K && p.rg > (planes == 2 ? 7 : 5)) return none;
+    // above that the alternative is the per-step tile kernel, whose time at these batches depends on N only (measured:
+    // Langevin 8.5 / 10.8 / 14.2 / 17.6 us at N = 700 / 1000 / 1500 / 2000, DL 13.9 / 18.5 / 25 / 32): the plan's own
+    // estimate must beat it by 10 % (Langevin N = 700, B = 256, 28 rows per cluster over the chip: 9.2 vs 8.6 measured)
+    const double tile_us = planes == 2 ? 0.0142 * N + 4.0 : 0.0088 * N + 2.0;
+    if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.9 * tile_us) return none;
     return p;
 }
 // the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]

@@ -30,7 +30,10 @@
 //
 // Exchange layout: [cluster][plane][row group][k][4 rows] packets, so a member's publish region per row group
 // is one contiguous run of C x 32 bytes (C = 4: exactly one 128-byte line) written by 16-byte stores
-// {x_row, tag, x_row+1, tag}, and a reader's 16-byte loads are contiguous over the whole input.
+// {x_row, tag, x_row+1, tag}, and a reader's 16-byte loads are contiguous over a whole (plane, row group) block.
+// The blocks of a step stream through a ring of two LDS slots: while the waves contract block u, the loads of blocks
+// u + 1 and u + 2 are in flight (one barrier per block), so the rows per cluster are bounded by the owners' registers
+// (two pairs of rows per lane: R C <= 1024), not by LDS.
 //
 // Placement: a cluster's members are confined to the smallest group of XCDs that holds them (1, 2, 4 or all 8; blocks
 // b, b + 8, ... share an XCD: speed only): inside one XCD the exchange stays in that L2 (a hand-off round trip of ~1000
@@ -48,10 +51,10 @@ namespace ccvm {
 constexpr int SL_THREADS = 256;          // four waves, one per SIMD
 constexpr int SL_NW = 4;
 constexpr unsigned SL_XE = 8;            // bytes per exchanged element: {value, tag}
-constexpr int SL_XS_FLOATS = 32768;      // staged GEMM input: planes x RG x K x 4 floats (128 KB)
-constexpr int SL_RED_FLOATS = 4096;      // partial sums of the four waves: 4 x planes x RG x C x 4 floats
+constexpr int SL_XS_FLOATS = 16384;      // staged GEMM input: a ring of two (plane, row group) blocks of K x 4 floats (64 KB)
+constexpr int SL_RED_FLOATS = 8192;      // partial sums of the four waves: 4 x planes x RG x C x 4 floats (32 KB)
 constexpr int SL_MIN_N = 257, SL_MAX_N = 2048;
-constexpr int SL_MAX_RC = 128;           // RG x C: two rows x one column per lane -> at most 256 owners
+constexpr int SL_MAX_RC = 256;           // RG x C: a lane owns up to two pairs of rows at one column (512 pairs per member)
 constexpr int SL_MAX_B = 512;            // batches the path is ever considered for (workspace sizing)
 constexpr unsigned SL_SPIN_LIMIT = 1u << 22;
 
@@ -96,6 +99,12 @@ struct SlabArgs {
 #ifndef CCVM_SL_SLEEP
 #define CCVM_SL_SLEEP 2
 #endif
+#ifndef CCVM_SL_DELAY_FABRIC
+#define CCVM_SL_DELAY_FABRIC 24
+#endif
+#ifndef CCVM_SL_UP_FABRIC
+#define CCVM_SL_UP_FABRIC 0
+#endif
 #ifndef CCVM_SL_DELAY
 #define CCVM_SL_DELAY 12   // x 64 cycles: what a wave without owners sleeps before its first loads of a step
 #endif
@@ -132,17 +141,19 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     static_assert(CGRP == 1 || CGRP == 2 || CGRP == 4 || CGRP == 8, "column groups per member");
     static_assert(NQ % CGRP == 0 && NQ <= 256, "Q registers per lane (one wave per SIMD: 512 registers)");
     constexpr int C = 4 * CGRP;
-    constexpr int KRES = 16 / CGRP;          // k residues inside one MFMA
-    constexpr int NA = NQ / CGRP;            // A registers per wave, row group and plane (16 k each)
+    constexpr int NA = NQ / CGRP;            // A registers per wave and block (16 k each)
     constexpr int KW = 16 * NA;              // k range of a wave
     constexpr int K = SL_NW * KW;
     constexpr int CBSZ = sl_log2(CGRP);
     constexpr int NPL = (MODE == MODE_DL) ? 2 : 1;
     constexpr int NLD = K / 128;             // 16-byte loads per lane and (plane, row group) block: 2 K loads / 256 lanes
+    constexpr int PPL = SL_MAX_RC * 2 / SL_THREADS;  // row pairs a lane may own (2 RG C pairs over 256 lanes)
+    static_assert(K * 4 <= SL_XS_FLOATS / 2, "a block of the staged input fits a ring slot");
     __shared__ __attribute__((aligned(16))) float lds[SL_XS_FLOATS + SL_RED_FLOATS + 4];
-    float* const xs = lds;                       // [plane][rg][K][4 rows]
+    float* const xs = lds;                       // ring of two blocks [K][4 rows]
     float* const red = lds + SL_XS_FLOATS;       // [wave][plane][rg][C][4 rows]
     constexpr int DEAD = SL_XS_FLOATS + SL_RED_FLOATS;
+    constexpr int SLOT = SL_XS_FLOATS / 2;
 
     // ---- who am I -----------------------------------------------------------------------------------
     const int tid = threadIdx.x;
@@ -152,9 +163,9 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     // Placement (speed only): blocks b, b + nxcd, ... share an XCD; a cluster's members are confined to a group of
     // `span` XCDs (1: its exchange stays in one L2; nxcd: round-robin over the chip), the groups take the clusters in turn
     const int xcd = blockIdx.x % a.nxcd, idx = blockIdx.x / a.nxcd;
-    const int slot = idx * a.span + xcd % a.span;          // position inside the group's run of members
-    const int cluster = (slot / G) * (a.nxcd / a.span) + xcd / a.span;
-    const int member = slot % G;
+    const int slot_in_group = idx * a.span + xcd % a.span;  // position inside the group's run of members
+    const int cluster = (slot_in_group / G) * (a.nxcd / a.span) + xcd / a.span;
+    const int member = slot_in_group % G;
     if (cluster >= a.nclusters) return;  // a whole cluster out of range: nobody waits for it
     const int N = a.N, ld = a.ld;
     const int col0 = member * C;
@@ -178,29 +189,36 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     }
     const int a_off = kw0 * 4 + lane;
 
-    // ---- owners: lane t < 2 RG C owns rows 2 h, 2 h + 1 of row group org at column col ------------------
+    // ---- owners: pair t (t = tid, tid + 256; t < 2 RG C) = rows 2 h, 2 h + 1 of row group t / (2 C) at column col.
+    // 2 C divides 256, so a lane's pairs share the column (and h): only their row groups differ.
     const int EP = 2 * RG * C;
-    const bool owner = tid < EP;
-    const int oh = tid & 1, oc = (tid >> 1) % C, org = tid / (2 * C);
+    const int oh = tid & 1, oc = (tid >> 1) % C;
     const int col = col0 + oc;
-    const bool col_ok = owner && col < N;
+    const bool col_ok = col < N;
     const float vj = col_ok ? a.V[col] : 0.0f;
-    const float shift_j = owner ? a.in_shift * a.qsum[col] : 0.0f;
+    const float shift_j = a.in_shift * a.qsum[col];
     const float sat_j = (a.s_cols && col_ok) ? a.s_cols[col] : 1.0f;
     const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
-    int brow[2];
-    bool ok[2];
-    float s0[2], s1[2], mt[2], wc[2], am[2], av[2];
-    auto gidx = [&](int e) { return (size_t)brow[e] * ld + col; };
+    bool owner[PPL];
+    int org[PPL], brow[PPL][2];
+    bool ok[PPL][2];
+    float s0[PPL][2], s1[PPL][2], mt[PPL][2], wc[PPL][2], am[PPL][2], av[PPL][2];
+    auto gidx = [&](int p, int e) { return (size_t)brow[p][e] * ld + col; };
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        brow[e] = crow0 + 4 * org + 2 * oh + e;
-        ok[e] = col_ok && brow[e] < a.B;
-        s0[e] = ok[e] ? a.x0[gidx(e)] : 0.0f;
-        s1[e] = (MODE != MODE_LANGEVIN && ok[e]) ? a.x1[gidx(e)] : 0.0f;
-        mt[e] = wc[e] = 0.0f;
-        am[e] = (a.adam && ok[e]) ? a.am[gidx(e)] : 0.0f;
-        av[e] = (a.adam && a.ad.use_v && ok[e]) ? a.av[gidx(e)] : 0.0f;
+    for (int p = 0; p < PPL; ++p) {
+        const int t = tid + SL_THREADS * p;
+        owner[p] = t < EP;
+        org[p] = t / (2 * C);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            brow[p][e] = crow0 + 4 * org[p] + 2 * oh + e;
+            ok[p][e] = owner[p] && col_ok && brow[p][e] < a.B;
+            s0[p][e] = ok[p][e] ? a.x0[gidx(p, e)] : 0.0f;
+            s1[p][e] = (MODE != MODE_LANGEVIN && ok[p][e]) ? a.x1[gidx(p, e)] : 0.0f;
+            mt[p][e] = wc[p][e] = 0.0f;
+            am[p][e] = (a.adam && ok[p][e]) ? a.am[gidx(p, e)] : 0.0f;
+            av[p][e] = (a.adam && a.ad.use_v && ok[p][e]) ? a.av[gidx(p, e)] : 0.0f;
+        }
     }
 
     // ---- exchange buffers ---------------------------------------------------------------------------
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     constexpr int SC1 = 16;  // aux bits of the buffer builtins: sc1
     constexpr unsigned blk_bytes = (unsigned)K * 4 * SL_XE;              // one (plane, row group) block
     const unsigned cbase = (unsigned)(cluster * NPL * RG) * blk_bytes;   // this cluster's blocks
-    const int TU = NPL * RG;                                             // fetch units = blocks
+    const int TU = NPL * RG;                                             // fetch units = blocks, plane-major
 
     unsigned long long t_last = 0, seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](unsigned long long& acc) {
@@ -224,55 +242,57 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         }
     };
 
-    // publish this lane's two elements of plane pl with tag `tag` into buffer `par`: one 16-byte store
-    const unsigned pub_off = cbase + (unsigned)(org * K + col) * 4 * SL_XE + (unsigned)oh * 16;
-    auto publish = [&](int par, const float (&x)[2], unsigned tag, int pl) {
-        if (!owner) return;
-        const u32x4s v = {__builtin_bit_cast(unsigned, ok[0] ? x[0] : 0.0f), tag,
-                          __builtin_bit_cast(unsigned, ok[1] ? x[1] : 0.0f), tag};
-        __builtin_amdgcn_raw_buffer_store_b128(v, par ? rs1 : rs0, pub_off, pl * RG * (int)blk_bytes, SC1);
+    // publish pair p's two elements of plane pl with tag `tag` into buffer `par`: one 16-byte store
+    const unsigned pub_off = cbase + (unsigned)col * 4 * SL_XE + (unsigned)oh * 16;
+    auto publish = [&](int p, int par, const float (&x)[2], unsigned tag, int pl) {
+        if (!owner[p]) return;
+        const u32x4s v = {__builtin_bit_cast(unsigned, ok[p][0] ? x[0] : 0.0f), tag,
+                          __builtin_bit_cast(unsigned, ok[p][1] ? x[1] : 0.0f), tag};
+        __builtin_amdgcn_raw_buffer_store_b128(v, par ? rs1 : rs0, pub_off, (pl * RG + org[p]) * (int)blk_bytes, SC1);
     };
 
-    // one-stream normals of this lane's two rows at `step` (it = index inside the launch)
-    auto stream_normals = [&](int step, int it, float* out) {
+    // one-stream normals of pair p's two rows at `step` (it = index inside the launch)
+    auto stream_normals = [&](int p, int step, int it, float* out) {
         if (a.replay) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) out[e] = ok[e] ? a.w0[((size_t)it * N + col) * a.B + brow[e]] : 0.0f;
+            for (int e = 0; e < 2; ++e) out[e] = ok[p][e] ? a.w0[((size_t)it * N + col) * a.B + brow[p][e]] : 0.0f;
         } else {
-            const NormalPair p = normal_two_rows(a.seed, a.row_offset + brow[0], step, col);
-            out[0] = p.n0;
-            out[1] = p.n1;
+            const NormalPair n = normal_two_rows(a.seed, a.row_offset + brow[p][0], step, col);
+            out[0] = n.n0;
+            out[1] = n.n1;
         }
     };
-    // DL: the (W_c, W_s) pairs of this lane's two elements
-    auto pair_normals = [&](int step, int it, float* n0, float* n1) {
+    // DL: the (W_c, W_s) pairs of pair p's two elements
+    auto pair_normals = [&](int p, int step, int it, float* n0, float* n1) {
         if (a.replay) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const size_t wi = ((size_t)it * N + col) * a.B + brow[e];
-                n0[e] = ok[e] ? a.w0[wi] : 0.0f;
-                n1[e] = ok[e] ? a.w1[wi] : 0.0f;
+                const size_t wi = ((size_t)it * N + col) * a.B + brow[p][e];
+                n0[e] = ok[p][e] ? a.w0[wi] : 0.0f;
+                n1[e] = ok[p][e] ? a.w1[wi] : 0.0f;
             }
         } else {
             NormalPair pa, pb;
-            normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
+            normal_pair_x2(a.seed, a.row_offset + brow[p][0], a.row_offset + brow[p][1], step, col, pa, pb);
             n0[0] = pa.n0; n1[0] = pa.n1; n0[1] = pb.n0; n1[1] = pb.n1;
         }
     };
 
     // ---- first input: x(step0) ----------------------------------------------------------------------
-    if (owner) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        if (!owner[p]) continue;
         if constexpr (MODE == MODE_MF) {
-            stream_normals(a.step0, 0, wc);  // mf_solver.py:551-554 for the first step of the launch
+            stream_normals(p, a.step0, 0, wc[p]);  // mf_solver.py:551-554 for the first step of the launch
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float bound = a.s_cols ? sat_j : a.S;
-                mt[e] = ok[e] ? clampf(__builtin_fmaf(a.k_first, wc[e], s0[e]), -bound, bound) : 0.0f;
+                mt[p][e] = ok[p][e] ? clampf(__builtin_fmaf(a.k_first, wc[p][e], s0[p][e]), -bound, bound) : 0.0f;
             }
-            publish(0, mt, (unsigned)a.step0 + 1u, 0);
+            publish(p, 0, mt[p], (unsigned)a.step0 + 1u, 0);
         } else {
-            publish(0, s0, (unsigned)a.step0 + 1u, 0);
-            if constexpr (MODE == MODE_DL) publish(0, s1, (unsigned)a.step0 + 1u, 1);
+            publish(p, 0, s0[p], (unsigned)a.step0 + 1u, 0);
+            if constexpr (MODE == MODE_DL) publish(p, 0, s1[p], (unsigned)a.step0 + 1u, 1);
         }
     }
 
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         return r;
     };
 
-    // ---- fetch: one unit = one (plane, row group) block = NLD 16-byte loads per lane, staged 1:1 into xs -----------
+    // ---- fetch: one unit = one (plane, row group) block = NLD 16-byte loads per lane, staged 1:1 into a ring slot ---
     u32x4s wa[NLD], wb[NLD];
     const unsigned ld_off = cbase + (unsigned)tid * 16u;
     auto issue = [&](int b, int par, u32x4s (&w)[NLD]) {
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
             w[j] = __builtin_amdgcn_raw_buffer_load_b128(par ? rs1 : rs0, ld_off + (unsigned)b * blk_bytes, j * SL_THREADS * 16, SC1);
     };
     // every packet of the unit carries the awaited tag (a stale tag is always smaller, the columns nobody owns carry
-    // 0xFFFFFFFF: ccvm_cluster.h, slab_init_kernel)
+    // 0xFFFFFFFF: ccvm_cluster.h, exchange_init_kernel)
     auto arrived = [&](unsigned want, const u32x4s (&w)[NLD]) {
         unsigned lo = want;
 #pragma unroll
@@ -306,20 +326,33 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     // what a wave sleeps before its first loads of a step (x 64 cycles): waves without owners start with what the
     // generator takes; self-tuning below
     int delay = (wave * 64 >= EP) ? CCVM_SL_DELAY : 0;
-    if (a.span > 1) delay += 28;  // across the fabric the packets take ~2000 cycles longer (converged values measured)
-    const int up = a.span > 1 ? 4 : 3, down_mask = a.span > 1 ? 7 : 1023;
+    // across the fabric the packets take longer, and longer with more blocks per step (static sweeps of tools/slab_ablate,
+    // best delay in units: one block 20-28, two 40-56, four 56+; N = 2000 B = 32: 10.9 us per step without, 7.2 with 56)
+    if (a.span > 1) delay += min(CCVM_SL_DELAY_FABRIC * TU, 3 * CCVM_SL_DELAY_FABRIC);
+    // Inside an XCD the delay tunes itself, conservatively: a miss adds three units, only 1024 clean steps take one off,
+    // and it never exceeds what a miss costs there (a round trip: ~16 units).  Across the fabric it stays what it is:
+    // any rule that adds delay after a miss RATCHETS in a coupled cluster -- the member with the smallest delay asks
+    // first, misses because its peers are still sleeping in THEIR delays, adds its units, and the next smallest takes
+    // its place: with +4 per miss / -1 per 8 clean steps the delays of a 250-member cluster climbed to 192 units
+    // (N = 1000, B = 4: 2.2 -> 9.4 us per step), with +2 / -1 per 1024 to whatever cap they were given.
+    const int up = a.span > 1 ? CCVM_SL_UP_FABRIC : 3, down_mask = 1023;
+    const int delay_cap = a.span > 1 ? 72 : 24;
     bool retried = false;
     bool dead = false;
     auto await = [&](int b, int par, unsigned want, u32x4s (&w)[NLD]) {
         if constexpr (CCVM_SLAB_ABL & 4) return;
         if (__builtin_expect(arrived(want, w), 1)) return;
+        if (dead) return;  // this wave gave up on an earlier unit of the step: on to the barriers
         unsigned spins = 0;
 #pragma nounroll
         do {
-            if (++spins > SL_SPIN_LIMIT) {
+            // give up: after ~1 s of retries, or as soon as another wave of the workgroup has (volatile: the flag is
+            // written without a barrier in between)
+            const bool peer_gave_up = (spins & 255u) == 255u && *reinterpret_cast<volatile float*>(lds + DEAD) != 0.0f;
+            if (++spins > SL_SPIN_LIMIT || peer_gave_up) {
                 if (lane == 0) {
                     __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lds[DEAD] = 1.0f;  // read by everyone behind the next barrier
+                    lds[DEAD] = 1.0f;  // read by everyone behind the step's last barrier
                 }
                 dead = true;
                 break;
@@ -344,18 +377,47 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         } while (!arrived(want, w));
     };
     float* const st_dst = xs + tid * 2;
-    auto stage = [&](int b, const u32x4s (&w)[NLD]) {
+    auto stage = [&](int slot, const u32x4s (&w)[NLD]) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0, hipcc 7.2)
             const unsigned u0 = w[j][0], u1 = w[j][2];
             const f32x2s v = {__uint_as_float(u0), __uint_as_float(u1)};
-            *reinterpret_cast<f32x2s*>(st_dst + (size_t)b * (K * 4) + j * SL_THREADS * 2) = v;
+            *reinterpret_cast<f32x2s*>(st_dst + slot * SLOT + j * SL_THREADS * 2) = v;
         }
+    };
+    // partial sums of this wave's k range for block b, staged in ring slot `slot` -> red[wave][b]
+    auto contract = [&](int slot, int b) {
+        const float* xsb = xs + slot * SLOT + a_off;
+        float af[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) af[i] = xsb[i * 64];
+        f32x4v acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (CCVM_SLAB_ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i & 3][0] += af[i] * qf[i];
+        } else {
+            mfma_chain<CBSZ, CGRP>(af, qf, acc, std::make_integer_sequence<int, NQ>{});
+        }
+        f32x4v sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        // wavefront-level reduction over the k residues (lanes that differ in kr only; strides 4 CGRP .. 32)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = sum[r];
+            if constexpr (CGRP == 1) v = sl_add_ror<4>(v);
+            if constexpr (CGRP <= 2) v = sl_add_ror<8>(v);
+            if constexpr (CGRP <= 4) v = sl_add_swap16(v);
+            v = sl_add_swap32(v);
+            sum[r] = v;
+        }
+        if (lane < 4 * CGRP)  // kr == 0: lane = column inside the member
+            *reinterpret_cast<f32x4v*>(red + ((size_t)(wave * TU + b) * C + lane) * 4) = sum;
     };
 
     Row rnext = load_row(0);
-    __syncthreads();  // xs is zeroed, DEAD is initialised
+    __syncthreads();  // DEAD is initialised
     if constexpr (CCVM_SLAB_ABL & 64) { unsigned long long dummy = 0; mark(dummy); }
 
     for (int it = 0; it < a.nsteps; ++it) {
@@ -366,130 +428,105 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         const Row rcur = rnext;
         const float* trow = rcur.w;
 
-        // ---- phase A: the cluster's GEMM input of this step -> LDS --------------------------------------
-        // This step's / the next step's normals first, THEN the loads: every member publishes at about the same
+        // ---- this step's / the next step's normals first, THEN the loads: every member publishes at about the same
         // time, and loads issued right behind the own publish mostly meet the peers' previous packets -- each such
-        // miss costs a whole round trip across the chip (1.0-1.4 retries per step when the loads went first).  The
-        // waves without owners sleep as long as the generator takes.
-        float nz[2] = {0.0f, 0.0f}, nz1[2] = {0.0f, 0.0f};
-        if constexpr (CCVM_SLAB_ABL & 2) {
-            nz[0] = nz[1] = nz1[0] = nz1[1] = 0.25f;
-        } else if (owner) {
-            if constexpr (MODE == MODE_DL) {
-                pair_normals(step, it, nz, nz1);
-            } else if constexpr (MODE == MODE_MF) {
-                if (has_next) stream_normals(step + 1, it + 1, nz);
-            } else {
-                stream_normals(step, it, nz);
+        // miss costs a whole round trip (1.0-1.4 retries per step when the loads went first).  The waves without
+        // owners sleep as long as the generator takes.
+        float nz[PPL][2], nz1[PPL][2];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            nz[p][0] = nz[p][1] = nz1[p][0] = nz1[p][1] = (CCVM_SLAB_ABL & 2) ? 0.25f : 0.0f;
+            if constexpr (!(CCVM_SLAB_ABL & 2)) {
+                if (owner[p]) {
+                    if constexpr (MODE == MODE_DL) {
+                        pair_normals(p, step, it, nz[p], nz1[p]);
+                    } else if constexpr (MODE == MODE_MF) {
+                        if (has_next) stream_normals(p, step + 1, it + 1, nz[p]);
+                    } else {
+                        stream_normals(p, step, it, nz[p]);
+                    }
+                }
             }
         }
         for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
         rnext = load_row(min(it + 1, a.nsteps - 1));
         retried = false;
         issue(0, par, wa);
+        if (TU > 1) issue(1, par, wb);
         mark(seg[0]);
-        for (int u = 0; u < TU && !dead; u += 2) {
-            if (u + 1 < TU) issue(u + 1, par, wb);
-            await(u, par, want, wa);
+
+        // ---- the cluster's GEMM input, block by block through the two-slot ring: while the waves contract block u, the
+        // loads of blocks u + 1 and u + 2 are in flight.  One barrier per block (the block is staged by all four waves);
+        // slot u % 2 is staged again only behind the barrier of block u + 1, which every wave reaches after it has
+        // finished contracting block u.
+        auto unit = [&](int u, int slot, u32x4s (&w)[NLD]) {
+            await(u, par, want, w);
             if (u == 0) {
                 mark(seg[1]);
-                // Self-tuning delay (x 64 cycles) before the first loads of a step: a miss costs a round trip (~1000
-                // cycles inside an XCD, ~3500 across the fabric) plus the retry's bookkeeping, waiting a little too
-                // long costs 64 cycles a unit.  Inside an XCD arrival times are steady and a cluster advances at the pace
-                // of its slowest wave (~100 waves probing downwards: somebody always misses), so a miss adds three units
-                // and only 1024 clean steps take one off; across the fabric the arrival times wander and the delay has to
-                // follow them: four units up, one off every eight clean steps (measured, us per step, static / slow /
-                // fast: N = 1000 B = 32 in XCDs 1.92 / 1.99 / 2.17; N = 2000 B = 32 over two XCDs 10.5 / 7.2 / 6.4; N = 1000
-                // B = 4 over the chip 3.0 / 2.7 / 2.2).  Timing only: the result does not depend on it.
-                if (retried) delay = min(delay + up, 192);
+                // the delay before the first loads of the next steps (see `up`, `down_mask`, `delay_cap` above).  Timing
+                // only: the result does not depend on it.
+                if (retried) delay = min(delay + up, delay_cap);
                 else if ((it & down_mask) == down_mask && delay > 0) delay -= 1;
             }
-            stage(u, wa);
-            if (u + 2 < TU) issue(u + 2, par, wa);
-            if (u + 1 < TU) {
-                await(u + 1, par, want, wb);
-                stage(u + 1, wb);
-            }
+            stage(slot, w);
+            if (u + 2 < TU) issue(u + 2, par, w);
+            mark(seg[2]);
+            __syncthreads();
+            mark(seg[3]);
+            contract(slot, u);
+            mark(seg[4]);
+        };
+        for (int u = 0; u < TU; u += 2) {
+            unit(u, 0, wa);
+            if (u + 1 < TU) unit(u + 1, 1, wb);
         }
-        mark(seg[2]);
-        __syncthreads();  // B1: the input is staged
-        if (lds[DEAD] != 0.0f) return;
-        mark(seg[3]);
-
-        // ---- phase B: partial sums of this wave's k range, every plane and row group --------------------
-        for (int b = 0; b < NPL * RG; ++b) {
-            const float* xsb = xs + (size_t)b * (K * 4) + a_off;
-            float af[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) af[i] = xsb[i * 64];
-            f32x4v acc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (CCVM_SLAB_ABL & 1) {
-#pragma unroll
-                for (int i = 0; i < NA; ++i) acc[i & 3][0] += af[i] * qf[i];
-            } else {
-                mfma_chain<CBSZ, CGRP>(af, qf, acc, std::make_integer_sequence<int, NQ>{});
-            }
-            f32x4v sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            // wavefront-level reduction over the k residues (lanes that differ in kr only; strides 4 CGRP .. 32)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = sum[r];
-                if constexpr (CGRP == 1) v = sl_add_ror<4>(v);
-                if constexpr (CGRP <= 2) v = sl_add_ror<8>(v);
-                if constexpr (CGRP <= 4) v = sl_add_swap16(v);
-                v = sl_add_swap32(v);
-                sum[r] = v;
-            }
-            if (lane < 4 * CGRP)  // kr == 0: lane = column inside the member
-                *reinterpret_cast<f32x4v*>(red + ((size_t)(wave * NPL * RG + b) * C + lane) * 4) = sum;
-        }
-        mark(seg[4]);
-        __syncthreads();  // B2: the four waves' partial sums are in LDS; xs may be overwritten
+        __syncthreads();  // the four waves' partial sums of every block are in LDS
+        if (lds[DEAD] != 0.0f) return;  // a bounded wait gave up: the whole workgroup leaves (the host recovers)
         mark(seg[5]);
 
-        // ---- phase C: the owners' update and the next input -------------------------------------------
-        if (owner) {
+        // ---- the owners' update and the next input -----------------------------------------------------
+        AdamScalars ad;
+        ad.beta1 = a.ad.beta1; ad.one_m_beta1 = a.ad.one_m_beta1; ad.inv_bc1 = trow[12];
+        ad.beta2 = a.ad.beta2; ad.one_m_beta2 = a.ad.one_m_beta2; ad.inv_bc2 = trow[13];
+        ad.alpha = a.ad.alpha; ad.eps = a.ad.eps; ad.use_v = a.ad.use_v; ad.add_assign = a.ad.add_assign;
+        const unsigned tag = has_next ? (unsigned)step + 2u : 0u;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            if (!owner[p]) continue;
             float qx[2], qx1[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 float t[NPL];
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
-                    float p[SL_NW];
+                    float part[SL_NW];
 #pragma unroll
                     for (int w = 0; w < SL_NW; ++w)
-                        p[w] = red[((size_t)(w * NPL * RG + pl * RG + org) * C + oc) * 4 + 2 * oh + e];
-                    t[pl] = (p[0] + p[1]) + (p[2] + p[3]);
+                        part[w] = red[((size_t)(w * TU + pl * RG + org[p]) * C + oc) * 4 + 2 * oh + e];
+                    t[pl] = (part[0] + part[1]) + (part[2] + part[3]);
                 }
                 qx[e] = __builtin_fmaf(a.in_scale, t[0], shift_j);
                 qx1[e] = __builtin_fmaf(a.in_scale, t[NPL - 1], shift_j);
             }
-            AdamScalars ad;
-            ad.beta1 = a.ad.beta1; ad.one_m_beta1 = a.ad.one_m_beta1; ad.inv_bc1 = trow[12];
-            ad.beta2 = a.ad.beta2; ad.one_m_beta2 = a.ad.one_m_beta2; ad.inv_bc2 = trow[13];
-            ad.alpha = a.ad.alpha; ad.eps = a.ad.eps; ad.use_v = a.ad.use_v; ad.add_assign = a.ad.add_assign;
             auto adam = [&](float gr, int e) {
                 if (!a.adam) return gr;
                 float m, v;
-                const float out = adam_precondition(ad, gr, am[e], av[e], m, v);
-                am[e] = m;
-                av[e] = v;
+                const float out = adam_precondition(ad, gr, am[p][e], av[p][e], m, v);
+                am[p][e] = m;
+                av[p][e] = v;
                 return out;
             };
-            const unsigned tag = has_next ? (unsigned)step + 2u : 0u;
             if constexpr (MODE == MODE_DL) {
                 const DlScalars k = *reinterpret_cast<const DlScalars*>(trow);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     float cn, sn;
-                    dl_update(k, s0[e], s1[e], qx[e], qx1[e], vj, nz[e], nz1[e], cn, sn);
-                    s0[e] = cn;
-                    s1[e] = sn;
+                    dl_update(k, s0[p][e], s1[p][e], qx[e], qx1[e], vj, nz[p][e], nz1[p][e], cn, sn);
+                    s0[p][e] = cn;
+                    s1[p][e] = sn;
                 }
-                publish(par ^ 1, s0, tag, 0);
-                publish(par ^ 1, s1, tag, 1);
+                publish(p, par ^ 1, s0[p], tag, 0);
+                publish(p, par ^ 1, s1[p], tag, 1);
             } else if constexpr (MODE == MODE_MF) {
                 const MfScalars k = *reinterpret_cast<const MfScalars*>(trow);
 #pragma unroll
@@ -497,23 +534,23 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                     const float bound = a.s_cols ? sat_j : k.S;
                     const float fb = adam(__builtin_fmaf(k.f_q, qx[e], k.f_v * vj) * inv_sat_j, e);
                     float mun, sgn;
-                    mf_update(k, s0[e], s1[e], fb, wc[e], mun, sgn);
-                    s0[e] = mun;
-                    s1[e] = sgn;
+                    mf_update(k, s0[p][e], s1[p][e], fb, wc[p][e], mun, sgn);
+                    s0[p][e] = mun;
+                    s1[p][e] = sgn;
                     // the last step's input is what mu_tilde_out returns: no new measurement after it
                     const bool nxt = k.has_next;
-                    mt[e] = nxt ? clampf(__builtin_fmaf(k.k_next, nz[e], s0[e]), -bound, bound) : mt[e];
-                    wc[e] = nxt ? nz[e] : wc[e];
+                    mt[p][e] = nxt ? clampf(__builtin_fmaf(k.k_next, nz[p][e], s0[p][e]), -bound, bound) : mt[p][e];
+                    wc[p][e] = nxt ? nz[p][e] : wc[p][e];
                 }
-                publish(par ^ 1, mt, tag, 0);
+                publish(p, par ^ 1, mt[p], tag, 0);
             } else {
                 const LvScalars k = *reinterpret_cast<const LvScalars*>(trow);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float gr = adam(__builtin_fmaf(k.g_q, qx[e], k.g_v * vj) * inv_sat_j, e);
-                    s0[e] = lv_update(k, s0[e], gr, nz[e], a.s_cols ? sat_j : k.S);
+                    s0[p][e] = lv_update(k, s0[p][e], gr, nz[p][e], a.s_cols ? sat_j : k.S);
                 }
-                publish(par ^ 1, s0, tag, 0);
+                publish(p, par ^ 1, s0[p], tag, 0);
             }
         }
         mark(seg[6]);
@@ -522,22 +559,27 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         if (tid == 0)
             for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 16 + k] = seg[k];
     }
+    if constexpr (CCVM_SLAB_ABL & 8) {  // the delay every wave ended with (no stamps: the timing is the product's)
+        if (lane == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + wave] = (unsigned long long)delay;
+    }
 
     // ---- write the state back (owner-only data: plain stores) ---------------------------------------
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        if (!ok[e]) continue;
-        a.x0[gidx(e)] = s0[e];
-        if constexpr (MODE == MODE_DL) a.x1[gidx(e)] = s1[e];
-        if constexpr (MODE == MODE_MF) {
-            a.x1[gidx(e)] = s1[e];
-            if (a.xt) a.xt[gidx(e)] = mt[e];
+    for (int p = 0; p < PPL; ++p)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!ok[p][e]) continue;
+            a.x0[gidx(p, e)] = s0[p][e];
+            if constexpr (MODE == MODE_DL) a.x1[gidx(p, e)] = s1[p][e];
+            if constexpr (MODE == MODE_MF) {
+                a.x1[gidx(p, e)] = s1[p][e];
+                if (a.xt) a.xt[gidx(p, e)] = mt[p][e];
+            }
+            if (a.adam) {
+                a.am[gidx(p, e)] = am[p][e];
+                if (a.ad.use_v) a.av[gidx(p, e)] = av[p][e];
+            }
         }
-        if (a.adam) {
-            a.am[gidx(e)] = am[e];
-            if (a.ad.use_v) a.av[gidx(e)] = av[e];
-        }
-    }
 }
 
 // ---- host side: the shapes that exist, and the plan for (B, N) -------------------------------------------
@@ -550,6 +592,7 @@ struct SlabPlan {
     int G, nclusters;
     int span;      // XCDs a cluster's members are confined to
     int grid;
+    double est_us; // the model's time per step (slab_step_estimate_us)
 };
 
 // The chip as the launch policy sees it (queried once per device by the ABI; tests pass their own)
@@ -565,24 +608,36 @@ inline int slab_k_for(int N) {
     return 0;
 }
 
-// Fewest rows per cluster first (the fetched input per member and step is R K packets, the contraction R C K MACs);
-// for that row count the fewest XCDs per cluster (measured, N = 1000, B = 4, us per step: 32 members x 32 columns
-// inside an XCD 1.89; 63 x 16 / 125 x 8 / 250 x 4 over the chip 3.3 / 3.3 / 3.0: across the fabric a hand-off round
-// trip is ~3500 cycles against ~1000 inside an L2), then the narrowest member.  force_cgrp / force_rg (tuning): 0 =
-// choose.  Member widths: K C / 64 registers per lane hold the slab, at most 256 (one wave per SIMD).
+// Every feasible (rows per cluster, XCDs per cluster, member width) is priced with a small model of a step fitted to
+// the measurements of profiles/r03_small_batch.md, and the cheapest wins:
+//   hand-off + local chain: 1.0 us inside an XCD, 2.0 over two, 2.6 over four or eight, + 6 ns per member (a round
+//     trip is ~1000 cycles inside an L2, ~3500 across the fabric; N = 1000, B = 4: 32 members x 32 columns in one XCD
+//     1.9 us per step, 250 x 4 over the chip 2.5-3.0; DL N = 2000, B = 4: 63 x 32 over two XCDs 6.2, 250 x 8 7.3);
+//   per (plane, row group) block: NQ MFMAs x 10 cycles + ~450 cycles of operand reads, reductions and barrier, plus
+//     the block's fetch (0.25 us per 1024 columns);
+//   the owners' noise + update: 0.7 us per pair of rows a lane owns.
+// force_cgrp / force_rg (tuning): 0 = choose.  Member widths: K C / 64 registers per lane hold the slab, at most 256.
+inline double slab_step_estimate_us(int planes, int rg, int span, int nq, int K, int C, int G) {
+    const double base = (span == 1 ? 1.0 : span == 2 ? 2.0 : 2.6) + 0.006 * G;
+    const double block = (nq * 10.0 + 450.0) / 2400.0 + 0.25 * K / 1024.0;
+    const int pairs = (2 * rg * C + SL_THREADS - 1) / SL_THREADS;
+    return base + planes * rg * block + 0.7 * (pairs - 1);
+}
+
 inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, int force_cgrp = 0, int force_rg = 0) {
-    SlabPlan p{};
-    if (N < SL_MIN_N || N > SL_MAX_N || B < 1 || B > SL_MAX_B || chip.cus < 8 || chip.xcds < 1) return p;
-    if (chip.cus % chip.xcds) return p;
+    SlabPlan best{};
+    if (N < SL_MIN_N || N > SL_MAX_N || B < 1 || B > SL_MAX_B || chip.cus < 8 || chip.xcds < 1) return best;
+    if (chip.cus % chip.xcds) return best;
     const int K = slab_k_for(N);
     const int cus_per_xcd = chip.cus / chip.xcds;
-    for (int rg = 1; rg <= 32; ++rg) {
+    int spans[8], nspans = 0;  // powers of two that divide the XCD count, then the whole chip
+    for (int sp = 1; sp < chip.xcds && nspans < 7 && chip.xcds % sp == 0; sp *= 2) spans[nspans++] = sp;
+    spans[nspans++] = chip.xcds;
+    double best_us = 0.0;
+    for (int rg = 1; rg <= SL_MAX_RC / 4; ++rg) {
         if (force_rg && rg != force_rg) continue;
-        if (planes * rg * K * 4 > SL_XS_FLOATS) break;
         const int nclusters = (B + 4 * rg - 1) / (4 * rg);
-        int spans[8], nspans = 0;  // powers of two that divide the XCD count, then the whole chip
-        for (int sp = 1; sp < chip.xcds && nspans < 7 && chip.xcds % sp == 0; sp *= 2) spans[nspans++] = sp;
-        spans[nspans++] = chip.xcds;
+        if (rg > 1 && (B + 4 * (rg - 1) - 1) / (4 * (rg - 1)) == nclusters) continue;  // same clusters, more padding
         for (int si = 0; si < nspans; ++si) {
             const int span = spans[si];
             const int groups = chip.xcds / span;
@@ -593,20 +648,23 @@ inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, in
                 if (nq > 256 || rg * C > SL_MAX_RC) continue;
                 const int G = (N + C - 1) / C;
                 if ((long)per_group * G > (long)span * cus_per_xcd) continue;
-                p.ok = 1; p.cgrp = cgrp; p.nq = nq; p.K = K; p.rg = rg; p.G = G; p.nclusters = nclusters;
-                p.span = span;
-                p.grid = (per_group * G + span - 1) / span * chip.xcds;
-                return p;
+                const double us = slab_step_estimate_us(planes, rg, span, nq, K, C, G);
+                if (best.ok && us >= best_us) continue;
+                best.ok = 1; best.cgrp = cgrp; best.nq = nq; best.K = K; best.rg = rg; best.G = G;
+                best.nclusters = nclusters; best.span = span;
+                best.grid = (per_group * G + span - 1) / span * chip.xcds;
+                best_us = us;
+                best.est_us = us;
             }
         }
     }
-    return p;
+    return best;
 }
 
 inline size_t slab_exchange_bytes(int B, int N, int planes) {
     if (N < SL_MIN_N || N > SL_MAX_N || B > SL_MAX_B) return 0;
-    // rows of all clusters < B + 4 RG <= B + 128; two buffers of [rows / 4][K][4 rows] packets per plane
-    return 2 * (size_t)(B + 128) * planes * slab_k_for(N) * SL_XE;
+    // rows of all clusters < B + 4 RG <= B + 256; two buffers of [rows / 4][K][4 rows] packets per plane
+    return 2 * (size_t)(B + 256) * planes * slab_k_for(N) * SL_XE;
 }
 
 void slab_launch_dl(const SlabArgs& a, const SlabPlan& p, hipStream_t st);

@@ -35,8 +35,13 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: 63 members of 32 columns = two XCDs
     assert "slab_kernel<2, 8, 256>" in d and "each over 2 XCDs" in d
     assert "16 rows each" in _describe(hip_lib, 2, 64, 2000)               # four clusters of 16 rows
-    assert "step_kernel" in _describe(hip_lib, 2, 128, 2000)               # no plan: 32 rows x 2048 do not fit in LDS
-    assert "step_kernel" in _describe(hip_lib, 0, 64, 2000)                # DL: two planes
+    assert "step_kernel" in _describe(hip_lib, 0, 128, 2000)               # a plan exists (32 rows x 32 columns per member)
+    clean_env.setenv("CCVM_AMD_KERNEL", "slab")                            # but is priced above the tile kernel
+    assert "32 rows each" in _describe(hip_lib, 0, 128, 2000)
+    clean_env.delenv("CCVM_AMD_KERNEL")
+    assert "step_kernel" in _describe(hip_lib, 2, 256, 2000)               # no plan at all
+    assert "cluster_kernel" in _describe(hip_lib, 2, 512, 500)             # N <= 512: large batches stay with the cluster kernel
+    assert "slab_kernel" in _describe(hip_lib, 2, 256, 500) and "slab_kernel" in _describe(hip_lib, 2, 256, 1000)
 
 
 @pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])

@@ -68,6 +68,16 @@ int main(int argc, char** argv) {
                              MODE == MODE_DL ? "DL" : "LV", CCVM_SLAB_ABL, CCVM_SL_SLEEP, N, B, p.nclusters, p.G, 4 * p.cgrp, 4 * p.rg, p.K,
                              q.span, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
     }
+    if (CCVM_SLAB_ABL & 8) {
+        std::vector<unsigned long long> hd((size_t)grid * 16);
+        hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; ++w) {
+            std::vector<double> v;
+            for (int g = 0; g < grid; ++g) v.push_back((double)hd[(size_t)g * 16 + 8 + w]);
+            std::sort(v.begin(), v.end());
+            printf("final delay of wave %d (x 64 cycles): min %.0f median %.0f max %.0f\n", w, v.front(), v[v.size() / 2], v.back());
+        }
+    }
     if (CCVM_SLAB_ABL & 64) {
         std::vector<unsigned long long> hd((size_t)grid * 16);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
