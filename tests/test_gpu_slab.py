@@ -5,7 +5,8 @@ rows reduced at wavefront level.  The reference runs any batch_size through the 
 
 Every word of every trajectory is compared with the oracle (fused noise through oracle/noise_ref.py) for every
 member width (4 / 8 / 16 / 32 columns), every K (512 ... 2048), clusters inside one XCD and spread over the chip,
-one to eight row groups, ragged batches and columns, odd shard starts and the Adam variants."""
+one to eight row groups (up to 32 rows per cluster: blocks streamed through the LDS ring, two row pairs per lane),
+ragged batches and columns, odd shard starts and the Adam variants."""
 import pytest
 import torch
 
@@ -62,6 +63,9 @@ def _check_against_oracle(kind, n, b, t, adam):
     ("langevin", 1000, 128, 10, "second_moment"), ("mf", 1000, 100, 10, None), ("dl", 700, 128, 8, None),
     ("langevin", 1200, 32, 8, None), ("dl", 1500, 16, 8, None), ("pl", 2000, 17, 8, None),
     ("langevin", 300, 128, 16, None), ("dl", 300, 64, 16, None),
+    # more than 16 rows per cluster: the blocks stream through the two-slot ring, a lane owns two pairs of rows
+    ("langevin", 1000, 256, 8, None), ("dl", 1000, 200, 6, None), ("mf", 500, 400, 8, "second_moment"),
+    ("dl", 2000, 64, 5, None), ("pl", 2000, 100, 5, "add_assign"), ("mf", 1000, 250, 6, None), ("dl", 700, 300, 5, None),
 ])
 def test_slab_kernel_matches_oracle(slab, kind, n, b, t, adam):
     assert "slab_kernel" in _describe(kind, b, n, adam is not None)
@@ -99,7 +103,8 @@ def test_slab_kernel_is_what_ran_and_is_the_default_for_small_batches(monkeypatc
     assert not torch.equal(a, b_) and float((a - b_).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("kind,n,b", [("mf", 1000, 24), ("pl", 2000, 12), ("dl", 1000, 32), ("langevin", 500, 40)])
+@pytest.mark.parametrize("kind,n,b", [("mf", 1000, 24), ("pl", 2000, 12), ("dl", 1000, 32), ("langevin", 500, 40),
+                                      ("langevin", 1000, 200)])
 def test_slab_chunking_is_exact_and_sharding_is_exact_at_equal_member_width(slab, monkeypatch, kind, n, b):
     """Chunked launches (evolution sampling, replay staging) reproduce the one-launch run bit for bit; so do batch
     shards whenever they run with the same member width (the summation order of a column's contraction depends on
@@ -210,7 +215,8 @@ def test_slab_long_trajectory_under_uneven_load(slab):
         assert bool(torch.isfinite(loaded).all())
 
 
-@pytest.mark.parametrize("kind,adam,n,b", [("dl", None, 1000, 32), ("pl", None, 2000, 8), ("mf", "second_moment", 500, 64)])
+@pytest.mark.parametrize("kind,adam,n,b", [("dl", None, 1000, 32), ("pl", None, 2000, 8), ("mf", "second_moment", 500, 64),
+                                           ("langevin", None, 1000, 256)])
 def test_slab_soak_is_deterministic(slab, kind, adam, n, b):
     """20 000 steps, twice (4096-step launches / ragged chunks): bit-identical and finite.  A single stale or torn
     exchange read anywhere would show here."""
