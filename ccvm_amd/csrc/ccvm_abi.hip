@@ -98,6 +98,7 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 //                             every size above 256 on the per-step tile kernel
 //   CCVM_AMD_KERNEL=slab      the column-slab small-batch kernel wherever it has a plan; =noslab: never
 //   CCVM_AMD_SLAB_CGRP=1|2|4|8, CCVM_AMD_SLAB_RG=n   force its member width (4 CGRP columns) / row groups per cluster
+//   CCVM_AMD_SLAB_DELAY=n     fetch delay of its clusters that span XCDs, x 64 cycles (timing only)
 //   CCVM_AMD_GEOMETRY=cus,xcds  plan for this chip instead of the device's
 //   CCVM_AMD_KS=1|2           force the tile shape (32 x 128 / 32 x 64 split-K)
 //   CCVM_AMD_XCD=0            linear block -> tile map instead of the XCD rectangles
@@ -115,6 +116,7 @@ struct Tuning {
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
+    int slab_delay = -1;             // >= 0: the fetch delay of clusters that span XCDs (x 64 cycles), else slab_fabric_delay
     ChipGeometry chip{0, 0};  // 0: ask the device
 };
 
@@ -129,6 +131,7 @@ Tuning read_tuning() {
     }
     if (const char* e = std::getenv("CCVM_AMD_SLAB_CGRP")) t.slab_cgrp = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_SLAB_RG")) t.slab_rg = std::atoi(e);
+    if (const char* e = std::getenv("CCVM_AMD_SLAB_DELAY")) t.slab_delay = std::atoi(e);
     // CCVM_AMD_GEOMETRY=cus,xcds: the launch policy plans for this chip instead of the device's (tests of the policy
     // functions, and a way to keep a solve inside a CU-masked or partitioned share of the chip)
     if (const char* e = std::getenv("CCVM_AMD_GEOMETRY")) {
@@ -467,6 +470,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
     sa.B = B; sa.N = N; sa.ld = ld;
     sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.span = p.span;
     sa.nxcd = chip_of(tun).xcds;
+    sa.delay_fabric = tun.slab_delay >= 0 ? tun.slab_delay : slab_fabric_delay(planes, p.rg, p.K);
     return CCVM_OK;
 }
 

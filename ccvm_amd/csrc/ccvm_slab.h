@@ -82,6 +82,7 @@ struct SlabArgs {
     int nclusters, G, RG;  // clusters of G members; a cluster owns 4 RG batch rows
     int span;            // XCDs a cluster's members are confined to (1, 2, 4, ... nxcd): speed only
     int nxcd;            // XCDs of the device (blocks b and b + nxcd share one)
+    int delay_fabric;    // x 64 cycles: what every wave of a cluster that spans XCDs waits before its first loads of a step
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
@@ -98,12 +99,6 @@ struct SlabArgs {
 #endif
 #ifndef CCVM_SL_SLEEP
 #define CCVM_SL_SLEEP 2
-#endif
-#ifndef CCVM_SL_DELAY_FABRIC
-#define CCVM_SL_DELAY_FABRIC 24
-#endif
-#ifndef CCVM_SL_UP_FABRIC
-#define CCVM_SL_UP_FABRIC 0
 #endif
 #ifndef CCVM_SL_DELAY
 #define CCVM_SL_DELAY 12   // x 64 cycles: what a wave without owners sleeps before its first loads of a step
@@ -328,14 +323,14 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     int delay = (wave * 64 >= EP) ? CCVM_SL_DELAY : 0;
     // across the fabric the packets take longer, and longer with more blocks per step (static sweeps of tools/slab_ablate,
     // best delay in units: one block 20-28, two 40-56, four 56+; N = 2000 B = 32: 10.9 us per step without, 7.2 with 56)
-    if (a.span > 1) delay += min(CCVM_SL_DELAY_FABRIC * TU, 3 * CCVM_SL_DELAY_FABRIC);
+    if (a.span > 1) delay += a.delay_fabric;
     // Inside an XCD the delay tunes itself, conservatively: a miss adds three units, only 1024 clean steps take one off,
     // and it never exceeds what a miss costs there (a round trip: ~16 units).  Across the fabric it stays what it is:
     // any rule that adds delay after a miss RATCHETS in a coupled cluster -- the member with the smallest delay asks
     // first, misses because its peers are still sleeping in THEIR delays, adds its units, and the next smallest takes
     // its place: with +4 per miss / -1 per 8 clean steps the delays of a 250-member cluster climbed to 192 units
     // (N = 1000, B = 4: 2.2 -> 9.4 us per step), with +2 / -1 per 1024 to whatever cap they were given.
-    const int up = a.span > 1 ? CCVM_SL_UP_FABRIC : 3, down_mask = 1023;
+    const int up = a.span > 1 ? 0 : 3, down_mask = 1023;
     const int delay_cap = a.span > 1 ? 72 : 24;
     bool retried = false;
     bool dead = false;
@@ -610,7 +605,7 @@ inline int slab_k_for(int N) {
 
 // Every feasible (rows per cluster, XCDs per cluster, member width) is priced with a small model of a step fitted to
 // the measurements of profiles/r03_small_batch.md, and the cheapest wins:
-//   hand-off + local chain: 1.0 us inside an XCD, 2.0 over two, 2.6 over four or eight, + 6 ns per member (a round
+//   hand-off + local chain: 1.0 us inside an XCD, 2.0 over two, 3.0 over four or eight, + 6 ns per member (a round
 //     trip is ~1000 cycles inside an L2, ~3500 across the fabric; N = 1000, B = 4: 32 members x 32 columns in one XCD
 //     1.9 us per step, 250 x 4 over the chip 2.5-3.0; DL N = 2000, B = 4: 63 x 32 over two XCDs 6.2, 250 x 8 7.3);
 //   per (plane, row group) block: NQ MFMAs x 10 cycles + ~450 cycles of operand reads, reductions and barrier, plus
@@ -618,7 +613,7 @@ inline int slab_k_for(int N) {
 //   the owners' noise + update: 0.7 us per pair of rows a lane owns.
 // force_cgrp / force_rg (tuning): 0 = choose.  Member widths: K C / 64 registers per lane hold the slab, at most 256.
 inline double slab_step_estimate_us(int planes, int rg, int span, int nq, int K, int C, int G) {
-    const double base = (span == 1 ? 1.0 : span == 2 ? 2.0 : 2.6) + 0.006 * G;
+    const double base = (span == 1 ? 1.0 : span == 2 ? 2.0 : 3.0) + 0.006 * G;
     const double block = (nq * 10.0 + 450.0) / 2400.0 + 0.25 * K / 1024.0;
     const int pairs = (2 * rg * C + SL_THREADS - 1) / SL_THREADS;
     return base + planes * rg * block + 0.7 * (pairs - 1);
@@ -659,6 +654,15 @@ inline SlabPlan slab_plan(int B, int N, int planes, const ChipGeometry& chip, in
         }
     }
     return best;
+}
+
+// Static fetch delay of clusters that span XCDs (x 64 cycles).  Best values of static sweeps with the library
+// (CCVM_AMD_SLAB_DELAY, tools/delay_sweep.sh; the time per step is within 5 % over +-8 units around them, 30-50 % worse
+// at 16 or 96): one block per step 24-32 (PL N = 2000 B = 8); two blocks 40-56 (DL N = 1200 / 1500 / 2000 at 4 rows:
+// 40 / 48 / 56; PL N = 2000 B = 32: 56; Langevin N = 1500 B = 32 prefers 24); four blocks 56-72.
+inline int slab_fabric_delay(int planes, int rg, int K) {
+    const int d = 24 + 16 * (planes * rg - 1) * K / 1024;
+    return d < 72 ? d : 72;
 }
 
 inline size_t slab_exchange_bytes(int B, int N, int planes) {
