@@ -92,6 +92,11 @@ __device__ __forceinline__ void mfma_chain_at(const float* af, const float* qf, 
 // K tail (measured and left off): the last chunk of 16 k-steps runs only the groups of four that hold
 // a k < N (N = 100: 100 MFMAs per
 // step instead of 112; wave-uniform scalar branches behind the straight-line part)
+// the next step's normals between this step's LDS publish and its barrier (waves side by side): measured, DL N = 100
+// B = 1000, three alternating runs: 0.982 / 1.026 / 0.984 us per step without, 1.014 / 1.016 / 1.018 with -- off
+#ifndef CCVM_PERSIST_NOISE_AHEAD
+#define CCVM_PERSIST_NOISE_AHEAD 0
+#endif
 #ifndef CCVM_PERSIST_KTAIL
 #define CCVM_PERSIST_KTAIL 0   // measured: DL N = 100 0.967 / 0.980 us per step without, 0.978 / 0.956 with -- no gain, off
 #endif
@@ -214,6 +219,9 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     // a row requested at the top of the step would be waited for together with the A operands)
     struct Row { float w[TABLE_WORDS]; };
     Row rnext = *reinterpret_cast<const Row*>(a.table);
+    float nzn0[NE], nzn1[NE];  // the next step's normals (NOISE_AHEAD)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) nzn0[e] = nzn1[e] = 0.0f;
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
         const Row rcur = rnext;
@@ -236,10 +244,13 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         // DL N=20 0.53 -> 0.46 us/step, N=64 0.63 -> 0.56); with two or four waves side by side the same
         // order was 3-12 % slower (same-box A/B), so those make them after the contraction.
         constexpr bool NOISE_FIRST = (NCG == 1);
+        // waves side by side: the NEXT step's normals are made between this step's LDS publish and its barrier (below),
+        // where the faster wave of a row set would only wait; nzn0 / nzn1 carry them over
+        constexpr bool NOISE_AHEAD = CCVM_PERSIST_NOISE_AHEAD && NCG > 1 && MODE != MODE_MF;
         float nz0[NE], nz1[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.0f;
-        auto make_step_noise = [&]() {
+        auto make_step_noise = [&](int step, int it) {
             if constexpr (MODE == MODE_DL) {
                 if (a.replay) {
     #pragma unroll
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
                 stream_normals(step, it, nz0);
             }
         };
-        if constexpr (NOISE_FIRST) make_step_noise();
+        if constexpr (NOISE_FIRST) make_step_noise(step, it);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(CCVM_PERSIST_ABL & 1)) {
             if constexpr (CCVM_PERSIST_KTAIL) {
@@ -287,7 +298,16 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
-        if constexpr (!NOISE_FIRST) make_step_noise();
+        if constexpr (NOISE_AHEAD) {
+            if (it == 0) {
+                make_step_noise(step, it);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { nz0[e] = nzn0[e]; nz1[e] = nzn1[e]; }
+            }
+        } else if constexpr (!NOISE_FIRST) {
+            make_step_noise(step, it);
+        }
         float qx[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -358,6 +378,13 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         if constexpr (!(CCVM_PERSIST_ABL & 8)) {
             cur ^= 1;
             publish(xs + cur * ROWS * LDX);
+            if constexpr (NOISE_AHEAD) {
+                if (it + 1 < a.nsteps) {
+                    make_step_noise(step + 1, it + 1);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { nzn0[e] = nz0[e]; nzn1[e] = nz1[e]; }
+                }
+            }
             // one-wave sets: a wave's LDS instructions execute in order, its reads see its own writes
             if constexpr (NCG > 1) __syncthreads();
         }
