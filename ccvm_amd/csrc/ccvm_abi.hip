@@ -471,6 +471,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
     sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.span = p.span;
     sa.nxcd = chip_of(tun).xcds;
     sa.delay_fabric = tun.slab_delay >= 0 ? tun.slab_delay : slab_fabric_delay(planes, p.rg, p.K);
+    sa.delay_fixed = tun.slab_delay >= 0;
     return CCVM_OK;
 }
 

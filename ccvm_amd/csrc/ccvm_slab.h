@@ -83,6 +83,7 @@ struct SlabArgs {
     int span;            // XCDs a cluster's members are confined to (1, 2, 4, ... nxcd): speed only
     int nxcd;            // XCDs of the device (blocks b and b + nxcd share one)
     int delay_fabric;    // x 64 cycles: what every wave of a cluster that spans XCDs waits before its first loads of a step
+    int delay_fixed;     // 1: no calibration of that delay (CCVM_AMD_SLAB_DELAY given)
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
@@ -99,6 +100,9 @@ struct SlabArgs {
 #endif
 #ifndef CCVM_SL_SLEEP
 #define CCVM_SL_SLEEP 2
+#endif
+#ifndef CCVM_SL_CALIBRATE
+#define CCVM_SL_CALIBRATE 1
 #endif
 #ifndef CCVM_SL_DELAY
 #define CCVM_SL_DELAY 12   // x 64 cycles: what a wave without owners sleeps before its first loads of a step
@@ -130,7 +134,10 @@ __device__ __forceinline__ float sl_add_swap32(float v) {
 }
 
 // CGRP = C / 4 column groups per member (1, 2, 4, 8); NQ = Q registers per lane; K = 64 NQ / CGRP >= N rounded up to C
-template <int MODE, int CGRP, int NQ>
+// CAL: the launch calibrates its fetch delay (clusters that span XCDs, launches of 512 steps or more); a template
+// parameter because the calibration's state costs the other launches 2-9 % when it is merely branched around
+// (same-box A/B: DL N = 300 B = 8 2.06 -> 2.25 us per step)
+template <int MODE, int CGRP, int NQ, bool CAL>
 __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "slab kernel: solver loops only");
     static_assert(CGRP == 1 || CGRP == 2 || CGRP == 4 || CGRP == 8, "column groups per member");
@@ -323,7 +330,18 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     int delay = (wave * 64 >= EP) ? CCVM_SL_DELAY : 0;
     // across the fabric the packets take longer, and longer with more blocks per step (static sweeps of tools/slab_ablate,
     // best delay in units: one block 20-28, two 40-56, four 56+; N = 2000 B = 32: 10.9 us per step without, 7.2 with 56)
+    const int delay_own = delay;   // what the wave sleeps for the generator's sake
     if (a.span > 1) delay += a.delay_fabric;
+    // Across the fabric the best delay moves with the shape, the solver and the clocks (24-72 units; a wrong one costs
+    // 30-50 %), and no closed-loop rule survives the coupling between members (below).  So a launch of 512 steps or
+    // more CALIBRATES: candidate delays 72, 64, ... 16 units for sixteen steps each (after a warm-up group), timed with
+    // s_memtime over the last twelve; the fastest candidate serves the rest of the launch (open loop: nothing to
+    // ratchet; the members of a cluster are in lockstep, see the same step times and choose alike).  144 of <= 4096
+    // steps run on candidates.
+    constexpr int CAL_STEPS = 16, CAL_CANDS = 8;  // + one warm-up group: the first steps of a launch are not typical
+    constexpr bool calibrate = CAL;
+    unsigned long long cal_mark = 0, cal_best_t = ~0ull;
+    int cal_best = delay;
     // Inside an XCD the delay tunes itself, conservatively: a miss adds three units, only 1024 clean steps take one off,
     // and it never exceeds what a miss costs there (a round trip: ~16 units).  Across the fabric it stays what it is:
     // any rule that adds delay after a miss RATCHETS in a coupled cluster -- the member with the smallest delay asks
@@ -442,6 +460,19 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                     }
                 }
             }
+        }
+        if constexpr (calibrate) if (it <= CAL_STEPS * (CAL_CANDS + 1)) {
+            const int g = it / CAL_STEPS - 1, r = it % CAL_STEPS;  // group -1: warm-up on the first candidate
+            if (r == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if (g > 0 && now - cal_mark < cal_best_t) {  // candidate g - 1, its steps 4 .. 15
+                    cal_best_t = now - cal_mark;
+                    cal_best = delay;
+                }
+                // from the longest delay down: the long ones never miss, so the cluster keeps its rhythm between them
+                delay = g < CAL_CANDS ? delay_own + 72 - 8 * (g < 0 ? 0 : g) : cal_best;
+            }
+            if (r == 4) cal_mark = __builtin_amdgcn_s_memtime();
         }
         for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
         rnext = load_row(min(it + 1, a.nsteps - 1));
@@ -675,30 +706,39 @@ void slab_launch_dl(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
 void slab_launch_mf(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
 void slab_launch_lv(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
 
-template <int MODE, int CGRP>
+inline bool slab_calibrates(const SlabArgs& a) {
+    return CCVM_SL_CALIBRATE && a.span > 1 && a.nsteps >= 512 && !a.delay_fixed;
+}
+
+template <int MODE, int CGRP, bool CAL>
 void launch_slab_nq(const SlabArgs& a, const SlabPlan& p, int grid, hipStream_t st) {
     const dim3 g(grid), b(SL_THREADS);
     switch (p.K) {
-        case 512: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 8 * CGRP>), g, b, 0, st, a); break;
-        case 768: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 12 * CGRP>), g, b, 0, st, a); break;
-        case 1024: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 16 * CGRP>), g, b, 0, st, a); break;
-        case 1280: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP>), g, b, 0, st, a); break;
-        case 1536: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP>), g, b, 0, st, a); break;
-        case 2048: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 32 * CGRP>), g, b, 0, st, a); break;
+        case 512: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 8 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 768: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 12 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1024: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 16 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1280: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1536: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 2048: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 32 * CGRP, CAL>), g, b, 0, st, a); break;
         default: break;
     }
 }
 
-template <int MODE>
-void launch_slab(const SlabArgs& a, const SlabPlan& p, hipStream_t st) {
+template <int MODE, bool CAL>
+void launch_slab_cal(const SlabArgs& a, const SlabPlan& p, hipStream_t st) {
     const int grid = p.grid - a.drop;
     switch (p.cgrp) {
-        case 1: launch_slab_nq<MODE, 1>(a, p, grid, st); break;
-        case 2: launch_slab_nq<MODE, 2>(a, p, grid, st); break;
-        case 4: launch_slab_nq<MODE, 4>(a, p, grid, st); break;
-        case 8: launch_slab_nq<MODE, 8>(a, p, grid, st); break;
+        case 1: launch_slab_nq<MODE, 1, CAL>(a, p, grid, st); break;
+        case 2: launch_slab_nq<MODE, 2, CAL>(a, p, grid, st); break;
+        case 4: launch_slab_nq<MODE, 4, CAL>(a, p, grid, st); break;
+        case 8: launch_slab_nq<MODE, 8, CAL>(a, p, grid, st); break;
         default: break;
     }
 }
+
+// the calibrating instantiations live in translation units of their own (ccvm_slab_*_cal.hip)
+void slab_launch_dl_cal(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
+void slab_launch_mf_cal(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
+void slab_launch_lv_cal(const SlabArgs& a, const SlabPlan& p, hipStream_t st);
 
 }  // namespace ccvm

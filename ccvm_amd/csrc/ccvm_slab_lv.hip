@@ -2,5 +2,8 @@
 #include "ccvm_slab.h"
 
 namespace ccvm {
-void slab_launch_lv(const SlabArgs& a, const SlabPlan& p, hipStream_t st) { launch_slab<MODE_LANGEVIN>(a, p, st); }
+void slab_launch_lv(const SlabArgs& a, const SlabPlan& p, hipStream_t st) {
+    if (slab_calibrates(a)) slab_launch_lv_cal(a, p, st);
+    else launch_slab_cal<MODE_LANGEVIN, false>(a, p, st);
+}
 }  // namespace ccvm

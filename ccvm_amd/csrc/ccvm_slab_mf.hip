@@ -2,5 +2,8 @@
 #include "ccvm_slab.h"
 
 namespace ccvm {
-void slab_launch_mf(const SlabArgs& a, const SlabPlan& p, hipStream_t st) { launch_slab<MODE_MF>(a, p, st); }
+void slab_launch_mf(const SlabArgs& a, const SlabPlan& p, hipStream_t st) {
+    if (slab_calibrates(a)) slab_launch_mf_cal(a, p, st);
+    else launch_slab_cal<MODE_MF, false>(a, p, st);
+}
 }  // namespace ccvm

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(init_xb, dim3(1024), dim3(256), 0, 0, (uint2*)xb, 2 * half / 8, p.K, p.G * 4 * p.cgrp);
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        launch_slab<MODE>(a, q, 0);
+        if (slab_calibrates(a)) launch_slab_cal<MODE, true>(a, q, 0); else launch_slab_cal<MODE, false>(a, q, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);

@@ -3,7 +3,10 @@ import sys, time, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-for kind, n, b, t in (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 300, 512, 20000), ("dl", 200, 256, 30000)):
+CASES = (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 300, 512, 20000), ("dl", 200, 256, 30000),
+         # the slab kernel: clusters inside XCDs, over two XCDs, streamed row groups
+         ("dl", 1000, 32, 100000), ("pl", 2000, 32, 50000), ("langevin", 1000, 256, 30000), ("mf", 500, 64, 100000))
+for kind, n, b, t in CASES:
     traj, q, v = bench.make_trajectories(kind, n, b, t, 0)
     t0 = time.time()
     done = 0
@@ -15,4 +18,5 @@ for kind, n, b, t in (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 3
     ok = all(bool(torch.isfinite(a).all()) for a in traj.state.values())
     name = "mu" if kind == "mf" else "c"
     x = traj.compact(name)
+    assert traj.fallbacks == 0
     print(f"{kind} N={n} B={b} T={t}: {dt:.2f} s ({dt/t*1e6:.2f} us/step) finite={ok} |x|max={float(x.abs().max()):.4f} mean={float(x.mean()):.4f}", flush=True)
