@@ -229,22 +229,24 @@ def test_slab_soak_is_deterministic(slab, kind, adam, n, b):
         assert torch.equal(x, y), name
 
 
-def test_slab_time_out_falls_back_to_the_tile_kernel(monkeypatch):
+@pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 32, 3), ("pl", 2000, 8, 600)])
+def test_slab_time_out_falls_back_to_the_tile_kernel(monkeypatch, kind, n, b, t):
     """Fault injection (CCVM_AMD_FAULT=cluster_drop: the launch omits its last 8 workgroups, so a member of every
     cluster never publishes): the peers' bounded waits give up (~1 s), the launch ends with the status word set, the
-    engine restores its snapshot and repeats the steps on the per-step tile kernel with a warning."""
+    engine restores its snapshot and repeats the steps on the per-step tile kernel with a warning.  Second case: clusters
+    over two XCDs in a launch that calibrates its fetch delay."""
     monkeypatch.setenv("CCVM_AMD_KERNEL", "tile")
-    want = {k: v for k, v in _state_of(_run_engine("dl", 1000, 32, 3, None, 21, 0)).items()}
+    want = {k: v for k, v in _state_of(_run_engine(kind, n, b, t, None, 21, 0)).items()}
     monkeypatch.setenv("CCVM_AMD_KERNEL", "slab")
     monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
-    traj = _run_engine("dl", 1000, 32, 3, None, 21, 0)
+    traj = _run_engine(kind, n, b, t, None, 21, 0)
     with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
         got = _state_of(traj)
     assert traj.fallbacks == 1
     for k in want:
         assert torch.equal(got[k], want[k]), k
     monkeypatch.delenv("CCVM_AMD_FAULT")
-    good = _run_engine("dl", 1000, 32, 3, None, 21, 0)
+    good = _run_engine(kind, n, b, t, None, 21, 0)
     assert bool(torch.isfinite(good.compact("c")).all()) and good.fallbacks == 0
 
 
