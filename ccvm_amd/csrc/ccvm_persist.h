@@ -93,7 +93,10 @@ __device__ __forceinline__ void mfma_chain_at(const float* af, const float* qf, 
 // a k < N (N = 100: 100 MFMAs per
 // step instead of 112; wave-uniform scalar branches behind the straight-line part)
 // the next step's normals between this step's LDS publish and its barrier (waves side by side): measured, DL N = 100
-// B = 1000, three alternating runs: 0.982 / 1.026 / 0.984 us per step without, 1.014 / 1.016 / 1.018 with -- off
+// B = 1000, three alternating runs: 0.982 / 1.026 / 0.984 us per step without, 1.014 / 1.016 / 1.018 with -- off.
+// (A third placement -- the next step's generator calls in the same straight-line code as this step's update, four
+// independent dependency chains instead of two -- measured 0.971 / 0.973 / 0.967 without, 1.000 / 0.991 / 0.995 with:
+// the step is not waiting on VALU dependencies either.)
 #ifndef CCVM_PERSIST_NOISE_AHEAD
 #define CCVM_PERSIST_NOISE_AHEAD 0
 #endif
