@@ -44,9 +44,7 @@ def _cases(count=int(os.environ.get("CCVM_FUZZ_COUNT", "128")), seed=int(os.envi
     return out
 
 
-@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp,vec_s,force_cluster", _cases())
-def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s,
-                                             force_cluster, monkeypatch):
+def _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s, force_cluster, monkeypatch):
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
     from oracle import ccvm_oracle as oracle
@@ -109,3 +107,64 @@ def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts
     for name, arr in traj.state.items():  # padding stays zero
         assert float(arr[b:].abs().max() if arr.shape[0] > b else 0.0) == 0.0
         assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,bounds,g,ramp,vec_s,force_cluster", _cases())
+def test_random_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s,
+                                             force_cluster, monkeypatch):
+    _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, bounds, g, ramp, vec_s, force_cluster, monkeypatch)
+
+
+# ---- the column-slab small-batch kernel: sizes up to 2048, small batches, forced member widths ------------------
+SLAB_SIZES = [257, 300, 511, 512, 513, 700, 767, 769, 1000, 1023, 1025, 1100, 1279, 1300, 1537, 1900, 2047, 2048]
+SLAB_BATCHES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 33, 64, 100, 130, 200, 256]
+
+
+def _slab_cases(count=int(os.environ.get("CCVM_FUZZ_SLAB_COUNT", "64")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
+    rng = random.Random(seed + 1)
+    out = []
+    for _ in range(count):
+        kind = rng.choice(["dl", "mf", "langevin", "pl"])
+        n, b, t = rng.choice(SLAB_SIZES), rng.choice(SLAB_BATCHES), rng.choice([1, 2, 5, 9])
+        if n * n * b > 4.2e8:
+            b = max(1, int(4.2e8 / (n * n)))
+        adam = None if kind == "dl" else rng.choice(ADAMS)
+        offset = rng.choice([0, 1, 64, 4097, 123456])
+        cuts = sorted(rng.sample(range(1, t), min(t - 1, rng.choice([0, 1, 2])))) if t > 1 else []
+        replay = rng.random() < 0.3
+        vec_s = kind != "dl" and rng.random() < 0.3
+        cgrp = rng.choice([0, 0, 1, 2, 4, 8])  # 0: the plan's own choice
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else offset, tuple(cuts), replay, vec_s, cgrp))
+    return out
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,vec_s,cgrp", _slab_cases())
+def test_random_slab_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, vec_s, cgrp, monkeypatch):
+    """The same sweep for the slab kernel (CCVM_AMD_KERNEL=slab: wherever a plan exists, also where the default would
+    take another path; CCVM_AMD_SLAB_CGRP forces the member width when that width has a plan)."""
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "slab")
+    if cgrp:
+        monkeypatch.setenv("CCVM_AMD_SLAB_CGRP", str(cgrp))
+        buf = ctypes.create_string_buffer(512)
+        _lib.load().ccvm_describe_launch({"dl": 0, "mf": 1}.get(kind, 2), b, n, 0, 0, buf, 512)
+        if b"slab_kernel" not in buf.value:
+            monkeypatch.delenv("CCVM_AMD_SLAB_CGRP")  # no plan at that width: the plan's own choice
+    _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, (0.0, 1.0), None, True, vec_s, False,
+                         _KeepEnv(monkeypatch))
+
+
+class _KeepEnv:
+    """A monkeypatch stand-in for the shared body: keeps the kernel selection this test made."""
+
+    def __init__(self, mp):
+        self.mp = mp
+
+    def setenv(self, *a, **k):
+        pass
+
+    def delenv(self, *a, **k):
+        pass
