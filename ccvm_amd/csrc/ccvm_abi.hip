@@ -184,8 +184,17 @@ ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : d
 // a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).
 int choose_ks(int B, int N, const Tuning& tun) {
     if (tun.ks) return tun.ks;
-    const int tiles = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
-    return tiles <= chip_of(tun).cus / 2 ? 2 : 1;
+    const int cus = chip_of(tun).cus;
+    const int nrb = (B + BM - 1) / BM;
+    const int tiles1 = nrb * ((N + BN - 1) / BN), tiles2 = nrb * ((N + BN / 2 - 1) / (BN / 2));
+    if (tiles1 <= cus / 2) return 2;
+    // Several workgroups per CU, one after the other: a launch costs the rounds the fullest CU runs, and a 32 x 64
+    // split-K workgroup takes 0.54 of a 32 x 128 one (tools/ks_sweep.sh: DL N = 1000, 36.8 us for two rounds
+    // against 34.2 for one).  The finer tiles win where they round up less: N = 1200 ... 1500 at B = 1000 is
+    // 3 rounds of 0.54 against 2 of 1 (DL N = 1500: 92.4 -> 74.5 us per step, Langevin 48.7 -> 40.6); the model
+    // matched all 25 measured points of the sweep.
+    const int r1 = (tiles1 + cus - 1) / cus, r2 = (tiles2 + cus - 1) / cus;
+    return 0.54 * r2 < 0.97 * r1 ? 2 : 1;
 }
 
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,

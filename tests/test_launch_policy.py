@@ -44,6 +44,21 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "slab_kernel" in _describe(hip_lib, 2, 256, 500) and "slab_kernel" in _describe(hip_lib, 2, 256, 1000)
 
 
+def test_tile_shape_follows_the_rounds_a_cu_runs(hip_lib, clean_env):
+    """32 x 64 split-K tiles (KS = 2) where the grid would leave half the chip idle, and where several workgroups per CU
+    round up less with the finer tiles (N = 1200 ... 1500 at B = 1000: 3 rounds of 0.54 against 2 of 1)."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    clean_env.setenv("CCVM_AMD_KERNEL", "tile")
+    ks = lambda solver, b, n: int(re.search(r"step_kernel<\d, \w+, 0, (\d)", _describe(hip_lib, solver, b, n)).group(1))
+    assert ks(0, 1000, 1000) == 1 and ks(0, 1000, 896) == 1 and ks(2, 512, 2000) == 1   # one workgroup per CU
+    assert ks(2, 1000, 500) == 2 and ks(0, 256, 1000) == 2 and ks(0, 32, 2000) == 2      # half the chip or less
+    assert ks(0, 1000, 1200) == 2 and ks(2, 1000, 1500) == 2 and ks(0, 1000, 2500) == 2  # 3 x 0.54 < 2, 5 x 0.54 < 3
+    assert ks(0, 1000, 1700) == 1 and ks(0, 1000, 2000) == 1 and ks(0, 1000, 3000) == 1  # 4 x 0.54 > 2, 6 x 0.54 > 3
+    assert ks(0, 2000, 1000) == 1 and ks(0, 500, 1500) == 1
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")                                      # half a chip: N = 1000 is two rounds
+    assert ks(0, 1000, 1000) == 1 and ks(0, 1000, 700) == 2                             # 192 tiles: 2 rounds; 352: 3 x 0.54
+
+
 @pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])
 def test_other_geometries_never_take_the_cluster_kernel_unless_it_is_8_xcds(hip_lib, clean_env, geometry):
     clean_env.setenv("CCVM_AMD_GEOMETRY", geometry)
