@@ -139,7 +139,7 @@ Tuning read_tuning() {
         if (std::sscanf(e, "%d,%d", &cus, &xcds) == 2 && cus > 0 && xcds > 0) t.chip = ChipGeometry{cus, xcds};
     }
     if (const char* e = std::getenv("CCVM_AMD_KS"))
-        if (e[0] == '1' || e[0] == '2') t.ks = e[0] - '0';
+        if (e[0] == '1' || e[0] == '2' || e[0] == '4') t.ks = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD")) t.xcd = e[0] != '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
@@ -182,19 +182,26 @@ ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : d
 
 // Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
 // a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).
-int choose_ks(int B, int N, const Tuning& tun) {
-    if (tun.ks) return tun.ks;
+int choose_ks(int B, int N, const Tuning& tun, int max_ks) {
+    if (tun.ks) return tun.ks < max_ks ? tun.ks : max_ks;
+    // A launch costs the rounds its fullest CU runs times what one workgroup of that tile shape takes: a 32 x 64
+    // split-K workgroup 0.54 of a 32 x 128 one (tools/ks_sweep.sh: DL N = 1000, B = 1000: 36.8 us for two rounds
+    // against 34.2 for one), a 32 x 32 one 0.37 (DL N = 1000, B = 256: 11.8 us against 19.1 with 32 x 64 tiles on
+    // half the chip; Langevin 8.0 against 11.2; solver steps only: max_ks).  Finer tiles win where the grid leaves
+    // CUs idle and where several workgroups per CU round up less: N = 1100 ... 1536 at B = 1000 is 3 rounds of 0.54
+    // against 2 of 1 (DL N = 1500: 92.4 -> 74.5 us per step, Langevin 48.7 -> 40.6); the model matched all 61
+    // measured points of profiles/r03_tile_shape_sweep.txt.  Ties go to the larger tile.
     const int cus = chip_of(tun).cus;
     const int nrb = (B + BM - 1) / BM;
-    const int tiles1 = nrb * ((N + BN - 1) / BN), tiles2 = nrb * ((N + BN / 2 - 1) / (BN / 2));
-    if (tiles1 <= cus / 2) return 2;
-    // Several workgroups per CU, one after the other: a launch costs the rounds the fullest CU runs, and a 32 x 64
-    // split-K workgroup takes 0.54 of a 32 x 128 one (tools/ks_sweep.sh: DL N = 1000, 36.8 us for two rounds
-    // against 34.2 for one).  The finer tiles win where they round up less: N = 1200 ... 1500 at B = 1000 is
-    // 3 rounds of 0.54 against 2 of 1 (DL N = 1500: 92.4 -> 74.5 us per step, Langevin 48.7 -> 40.6); the model
-    // matched all 25 measured points of the sweep.
-    const int r1 = (tiles1 + cus - 1) / cus, r2 = (tiles2 + cus - 1) / cus;
-    return 0.54 * r2 < 0.97 * r1 ? 2 : 1;
+    static const double rel[3] = {1.0, 0.54, 0.37};
+    int best_ks = 1;
+    double best = 0.0;
+    for (int i = 0, ks = 1; ks <= max_ks && i < 3; ++i, ks *= 2) {
+        const int tiles = nrb * ((N + BN / ks - 1) / (BN / ks));
+        const double cost = rel[i] * ((tiles + cus - 1) / cus);
+        if (i == 0 || cost < 0.97 * best) { best = cost; best_ks = ks; }
+    }
+    return best_ks;
 }
 
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
@@ -221,7 +228,7 @@ void set_grid(StepArgs& a, const Tuning& tun) {
 }
 
 // Everything of a launch that does not change from step to step: operands, tile shape and grid.
-void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun) {
+void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun, int max_ks = 2) {
     std::memset(&a, 0, sizeof(a));
     a.Q = Q;
     a.V = V;
@@ -231,7 +238,7 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
     a.qsum = V;  // any valid array while in_shift == 0
-    a.ks = choose_ks(B, N, tun);
+    a.ks = choose_ks(B, N, tun, max_ks);
     set_grid(a, tun);
 }
 
@@ -282,6 +289,14 @@ int launch_step(const StepArgs& a, hipStream_t st, const char* name) {
     const int ks = a.ks;
     const int grid = a.nrb * a.ncb;
     constexpr bool CAN_VS = (MODE == MODE_MF || MODE == MODE_LANGEVIN);
+    if (ks == 4) {  // solver steps only (base_args(..., max_ks = 4))
+        if constexpr (MODE == MODE_DL) tile4_launch_dl(a, grid, st);
+        else if constexpr (MODE == MODE_MF) tile4_launch_mf(a, grid, ADAM, a.s_cols != nullptr, st);
+        else if constexpr (MODE == MODE_LANGEVIN) tile4_launch_lv(a, grid, ADAM, a.s_cols != nullptr, st);
+        else return fail(CCVM_E_INVALID, "%s: no 32 x 32 tiles for this kernel", name);
+        CCVM_CHECK_LAUNCH(name);
+        return CCVM_OK;
+    }
     if (CAN_VS && a.s_cols) {  // per-variable saturation
         if constexpr (CAN_VS) {
             if (ks == 2)
@@ -455,10 +470,14 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     // ~20 rows per cluster (DL ~28) it wins (N = 500, us per step, slab vs cluster: Langevin B = 256 3.4 vs 4.9, B = 512
     // 6.2 vs 4.9; DL B = 256 5.7 vs 9.9, B = 512 10.8 vs 10.0; N = 300 B = 512: 4.9 vs 3.8)
     if (tun.slab < 0 && N <= CL_LDS_K && p.rg > (planes == 2 ? 7 : 5)) return none;
-    // above that the alternative is the per-step tile kernel, whose time at these batches depends on N only (measured:
-    // Langevin 8.5 / 10.8 / 14.2 / 17.6 us at N = 700 / 1000 / 1500 / 2000, DL 13.9 / 18.5 / 25 / 32): the plan's own
-    // estimate must beat it by 10 % (Langevin N = 700, B = 256, 28 rows per cluster over the chip: 9.2 vs 8.6 measured)
-    const double tile_us = planes == 2 ? 0.0142 * N + 4.0 : 0.0088 * N + 2.0;
+    // above that the alternative is the per-step tile kernel, whose time at these batches depends on N and the tile
+    // shape only (measured, us per step: 32 x 64 tiles Langevin 8.5 / 10.8 / 14.2 / 17.6 at N = 700 / 1000 / 1500 / 2000,
+    // DL 13.9 / 18.5 / 25 / 32; 32 x 32 tiles Langevin 5.9 / 7.8 / 10.0 / 12.5 at N = 600 / 1000 / 1500 / 2000, DL 7.9 /
+    // 11.4 / 14.3 / 17.9): the plan's own estimate must beat it by 10 % (Langevin N = 700, B = 256, 28 rows per
+    // cluster over the chip: 9.2 vs 8.6 measured)
+    const bool fine = choose_ks(B, N, tun, 4) == 4;
+    const double tile_us = fine ? (planes == 2 ? 0.0072 * N + 3.9 : 0.0047 * N + 3.1)
+                                : (planes == 2 ? 0.0142 * N + 4.0 : 0.0088 * N + 2.0);
     if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.9 * tile_us) return none;
     return p;
 }
@@ -585,7 +604,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
                       solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.grid, TABLE_STEPS);
     } else {
         StepArgs a;
-        base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun);
+        base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
         std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
                       solver, ad ? "true" : "false", a.ks, (per_variable_s && solver != 0) ? "true" : "false",
                       a.nrb * a.ncb, WG_THREADS, a.xr, a.xc);
@@ -645,7 +664,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun);
+    base_args(a, Q, V, B, N, ld, tun, 4);
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
     if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
@@ -964,7 +983,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     }
 
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun);
+    base_args(a, Q, V, B, N, ld, tun, 4);
     a.in_scale = (float)(ul / S_eff);
     a.in_shift = (float)up;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum, p->qsum))) return rc;
@@ -1048,7 +1067,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun);
+    base_args(a, Q, V, B, N, ld, tun, s_full ? 2 : 4);  // (the composed per-element-saturation path below runs MODE_AFFINE)
     a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;

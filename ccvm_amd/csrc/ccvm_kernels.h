@@ -139,12 +139,16 @@ typedef const __attribute__((address_space(1))) void global_cvoid;
 // reads, 8 no MFMA, 16 no epilogue, 32 no loop barrier (timing only), 64 no noise,
 // 128 s_memtime stamps of the consumer loop into a.dbg (diagnostic build: shares, not run time).
 //
-// KS (1 or 2): in-workgroup split of K.  KS = 1: tile 32 x 128, consumer wave w = column strip w.
+// KS (1, 2 or 4): in-workgroup split of K.  KS = 1: tile 32 x 128, consumer wave w = column strip w.
 // KS = 2: tile 32 x 64 for grids that would leave CUs idle (e.g. N = 500, B = 1000: 128 tiles of
 // 32 x 128); consumer wave w = column strip (w & 1), K half (w >> 1): within every K tile it runs
 // the k-steps [8 kh, 8 kh + 8) of each lane-half.  After the loop the two halves swap 8 accumulator
 // registers through LDS, so each wave ends up with the full sum of 8 of the 16 rows and the
 // epilogue work stays balanced.
+// KS = 4: tile 32 x 32 for batches that leave three quarters of the chip idle even with KS = 2 (B = 129 ... 256 at
+// N = 1000: 64 tiles of 32 x 128); consumer wave w = K quarter w of the one column strip: k-steps [4 w, 4 w + 4) of
+// each lane-half.  After the loop every wave leaves its 16 partial registers in LDS and sums the four partials of
+// registers 4 w ... 4 w + 3 in a fixed order; the epilogue (4 elements per lane) stays with the consumers.
 // VS: per-variable saturation (StepArgs::s_cols).  A template parameter, not a run-time test of the
 // pointer: with the run-time form the scalar path of the N = 500 kernels lost 0.4 us per step.
 // RING: LDS ring depth = DMA prefetch distance in tiles (0 = the default of 4; even, >= 4; a tuning knob
@@ -154,7 +158,7 @@ typedef const __attribute__((address_space(1))) void global_cvoid;
 // more tiles queued in front only delay the first one.
 template <int MODE, bool ADAM, int ABL = 0, int KS = 1, bool VS = false, int RING = 0>
 __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
-    static_assert(KS == 1 || KS == 2, "KS");
+    static_assert(KS == 1 || KS == 2 || KS == 4, "KS");
     static_assert(!VS || MODE == MODE_MF || MODE == MODE_LANGEVIN, "per-variable saturation: MF and Langevin steps");
     constexpr int NA = (MODE == MODE_DL) ? 2 : 1;
     constexpr bool NOISY = (MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN);
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHREADS;
-    const int cs = (KS == 1) ? wave : (wave & 1);   // column strip of 32
-    const int kh = (KS == 1) ? 0 : (wave >> 1);     // K half
+    const int cs = (KS == 1) ? wave : (KS == 2) ? (wave & 1) : 0;   // column strip of 32
+    const int kh = (KS == 1) ? 0 : (KS == 2) ? (wave >> 1) : wave;  // K half / quarter
     const int R0 = kh * NR;                         // first accumulator register this wave finishes
 
     // Blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).  When the
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     // stalls; with the consumers alone the 16-element epilogue cost 2.2 us of the 35 us step.
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
-    constexpr bool SHARE = NOISY && !(ABL & 16);
+    constexpr bool SHARE = NOISY && !(ABL & 16) && KS != 4;
     constexpr int H = SHARE ? NR / 2 : NR;  // epilogue elements per thread
     static_assert(H % 4 == 0, "element i uses lane offset eoff[i & 3]");
     constexpr bool HAS_E0 = (MODE != MODE_AFFINE);
@@ -592,7 +596,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 4)) {
                 // NG read groups over slots 0 .. NSLOT-3: slots 0,1 carry two
-                if (sl < 2) { read_part(nxt, rstage, 2 * sl); read_part(nxt, rstage, 2 * sl + 1); }
+                if (sl < 2) {
+                    if (2 * sl < NG) read_part(nxt, rstage, 2 * sl);
+                    if (2 * sl + 1 < NG) read_part(nxt, rstage, 2 * sl + 1);
+                }
                 else if (sl + 2 < NG) read_part(nxt, rstage, sl + 2);
             }
             mfma_range(cur, 2 * sl, 2 * sl + 2);
@@ -658,6 +665,26 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         for (int n = 0; n < NA; ++n)
 #pragma unroll
             for (int i = 0; i < NR; ++i) fin[n][i] = acc[n][i];
+    } else if constexpr (KS == 4) {
+        // every wave leaves its 16 partial registers per accumulator: [source quarter][n][register quad][lane][4]
+        f32x4* xq = reinterpret_cast<f32x4*>(lds);
+        auto quad = [&](int src, int n, int q) { return ((src * NA + n) * 4 + q) * 64 + lane; };
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[n][4 * q + i];
+                xq[quad(kh, n, q)] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const f32x4 p0 = xq[quad(0, n, kh)], p1 = xq[quad(1, n, kh)], p2 = xq[quad(2, n, kh)], p3 = xq[quad(3, n, kh)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fin[n][i] = ((p0[i] + p1[i]) + p2[i]) + p3[i];  // K quarters in order
+        }
     } else {
         float* xb = lds;  // [kh][cs][n][8][64]
         auto slot = [&](int k_, int n, int i) { return (((k_ * 2 + cs) * NA + n) * 8 + i) * 64 + lane; };
@@ -757,6 +784,26 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     }
 }
 
+// 32 x 32 split-K tiles (KS = 4) of the solver steps: instantiated in ccvm_tile4_{dl,mf,lv}.hip
+void tile4_launch_dl(const StepArgs& a, int grid, hipStream_t st);
+void tile4_launch_mf(const StepArgs& a, int grid, bool adam, bool per_variable_s, hipStream_t st);
+void tile4_launch_lv(const StepArgs& a, int grid, bool adam, bool per_variable_s, hipStream_t st);
+template <int MODE>
+void launch_tile4(const StepArgs& a, int grid, bool adam, bool vs, hipStream_t st) {
+    if constexpr (MODE == MODE_DL) {
+        hipLaunchKernelGGL((step_kernel<MODE, false, 0, 4>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+    } else {
+        if (adam) {
+            if (vs) hipLaunchKernelGGL((step_kernel<MODE, true, 0, 4, true>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((step_kernel<MODE, true, 0, 4>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+        } else {
+            if (vs) hipLaunchKernelGGL((step_kernel<MODE, false, 0, 4, true>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((step_kernel<MODE, false, 0, 4>), dim3(grid), dim3(WG_THREADS), 0, st, a);
+        }
+    }
+}
+
+#ifndef CCVM_STEP_KERNEL_ONLY  // the instantiation units ccvm_tile4_*.hip take the step kernel only
 // ---- small elementwise kernels ---------------------------------------------------
 
 __global__ void pack_kernel(const float* __restrict__ src, int rows, int cols, int src_ld,
@@ -1133,5 +1180,7 @@ __global__ void symmetrize_kernel(const float* Q, float* Qs, int ld) {
         Qs[i] = 0.5f * (Q[i] + Q[(size_t)c * ld + r]);
     }
 }
+
+#endif  // CCVM_STEP_KERNEL_ONLY
 
 }  // namespace ccvm

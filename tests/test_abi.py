@@ -110,7 +110,8 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (0, 1100, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 210 x 512",
         (2, 2000, 640, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 480 x 512 threads (42 clusters of 10 workgroups)",
         (2, 1500, 640, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 235 x 512",
-        (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 378 x 512",
+        (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 756 x 512",   # 3 rounds of 32 x 64 tiles < 2 of 32 x 128
+        (0, 256, 1000, 0): "ccvm::step_kernel<0, false, 0, 4, false, 0> grid 256 x 512",   # 32 x 32 tiles fill the chip
         (2, 512, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 192 x 512",
         (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",
     }

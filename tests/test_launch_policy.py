@@ -41,17 +41,20 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     clean_env.delenv("CCVM_AMD_KERNEL")
     assert "step_kernel" in _describe(hip_lib, 2, 256, 2000)               # no plan at all
     assert "cluster_kernel" in _describe(hip_lib, 2, 512, 500)             # N <= 512: large batches stay with the cluster kernel
-    assert "slab_kernel" in _describe(hip_lib, 2, 256, 500) and "slab_kernel" in _describe(hip_lib, 2, 256, 1000)
+    assert "slab_kernel" in _describe(hip_lib, 2, 256, 500) and "slab_kernel" in _describe(hip_lib, 2, 128, 1000)
+    assert "step_kernel<2, false, 0, 4" in _describe(hip_lib, 2, 256, 1000)  # 32 rows per cluster: 32 x 32 tiles win (8.0 vs 9.1 us)
 
 
 def test_tile_shape_follows_the_rounds_a_cu_runs(hip_lib, clean_env):
-    """32 x 64 split-K tiles (KS = 2) where the grid would leave half the chip idle, and where several workgroups per CU
-    round up less with the finer tiles (N = 1200 ... 1500 at B = 1000: 3 rounds of 0.54 against 2 of 1)."""
+    """32 x 64 split-K tiles (KS = 2) where the grid would leave half the chip idle, 32 x 32 (KS = 4) where three quarters,
+    and where several workgroups per CU round up less with the finer tiles (N = 1200 ... 1500 at B = 1000: 3 rounds of
+    0.54 against 2 of 1)."""
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
     clean_env.setenv("CCVM_AMD_KERNEL", "tile")
     ks = lambda solver, b, n: int(re.search(r"step_kernel<\d, \w+, 0, (\d)", _describe(hip_lib, solver, b, n)).group(1))
     assert ks(0, 1000, 1000) == 1 and ks(0, 1000, 896) == 1 and ks(2, 512, 2000) == 1   # one workgroup per CU
-    assert ks(2, 1000, 500) == 2 and ks(0, 256, 1000) == 2 and ks(0, 32, 2000) == 2      # half the chip or less
+    assert ks(2, 1000, 500) == 2 and ks(0, 384, 1000) == 2 and ks(0, 256, 2000) == 2     # half the chip or less
+    assert ks(0, 256, 1000) == 4 and ks(2, 129, 1000) == 4 and ks(0, 128, 2000) == 4     # a quarter or less: 32 x 32 tiles
     assert ks(0, 1000, 1200) == 2 and ks(2, 1000, 1500) == 2 and ks(0, 1000, 2500) == 2  # 3 x 0.54 < 2, 5 x 0.54 < 3
     assert ks(0, 1000, 1700) == 1 and ks(0, 1000, 2000) == 1 and ks(0, 1000, 3000) == 1  # 4 x 0.54 > 2, 6 x 0.54 > 3
     assert ks(0, 2000, 1000) == 1 and ks(0, 500, 1500) == 1
