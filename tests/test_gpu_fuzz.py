@@ -168,3 +168,30 @@ class _KeepEnv:
 
     def delenv(self, *a, **k):
         pass
+
+
+# ---- the per-step tile kernel with a forced tile shape (32 x 128, 32 x 64 split-K, 32 x 32 split-K) ---------------
+def _tile_cases(count=int(os.environ.get("CCVM_FUZZ_TILE_COUNT", "48")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
+    rng = random.Random(seed + 2)
+    out = []
+    for _ in range(count):
+        kind = rng.choice(["dl", "mf", "langevin", "pl"])
+        n = rng.choice([1, 31, 32, 33, 64, 100, 129, 257, 300, 511, 640, 769, 1000, 1025, 1300])
+        b = rng.choice([1, 2, 31, 32, 33, 64, 100, 130, 257, 600])
+        t = rng.choice([1, 2, 5, 9])
+        if n * n * b > 4.2e8:
+            b = max(1, int(4.2e8 / (n * n)))
+        adam = None if kind == "dl" else rng.choice(ADAMS)
+        cuts = sorted(rng.sample(range(1, t), min(t - 1, rng.choice([0, 1, 2])))) if t > 1 else []
+        replay = rng.random() < 0.3
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else rng.choice([0, 1, 64, 4097]), tuple(cuts), replay,
+                    kind != "dl" and rng.random() < 0.3, rng.choice([1, 2, 4])))
+    return out
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,vec_s,ks", _tile_cases())
+def test_random_tile_shape_configuration_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, vec_s, ks, monkeypatch):
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "tile")
+    monkeypatch.setenv("CCVM_AMD_KS", str(ks))
+    _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, (0.0, 1.0), None, True, vec_s, False,
+                         _KeepEnv(monkeypatch))
