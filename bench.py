@@ -54,6 +54,9 @@ WORKLOADS = {
     "langevin_n1000_b32": ("langevin", 1000, 32),
     "mf_n500_b32": ("mf", 500, 32),
     "pl_n2000_b32": ("pl", 2000, 32),
+    # mid-size batches: the per-step tile kernel with 32 x 32 split-K tiles (a quarter of the chip or less with wider ones)
+    "dl_n1000_b256": ("dl", 1000, 256),
+    "langevin_n1000_b256": ("langevin", 1000, 256),
 }
 SOLVER_ID = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
 SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example scripts' S (workloads.py)

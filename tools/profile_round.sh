@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
 if [ "${PART:-stats}" = stats ]; then
-for w in dl_n1000_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000; do
+for w in dl_n1000_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256; do
   rocprofv3 --kernel-trace --stats -d $OUT/${w}_stats -o s --output-format csv -- python3 bench.py --workload $w --steps 3000 --warmup 500 --no-cpu-baseline > $OUT/${w}_stats.json 2> $OUT/${w}_stats.err || exit 1
   echo "stats $w done"
 done
