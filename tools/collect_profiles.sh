@@ -19,3 +19,4 @@ cp gpurun_out/size_sweep_auto.txt profiles/${TAG}_size_sweep_auto.txt; cp gpurun
 python tools/make_size_sweep_md.py $TAG > profiles/${TAG}_size_sweep.md
 cp gpurun_out/small_batch_sweep.jsonl profiles/${TAG}_small_batch_sweep.jsonl
 python tools/make_small_batch_md.py $TAG > profiles/${TAG}_small_batch.md
+cp gpurun_out/regime_map.jsonl profiles/${TAG}_regime_map.jsonl; python tools/regime_map.py --md $TAG > profiles/${TAG}_regime_map.md
