@@ -469,7 +469,8 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     // up to N = 512 the alternative is the cluster kernel, whose time per step does not grow with the batch: beyond
     // ~20 rows per cluster (DL ~28) it wins (N = 500, us per step, slab vs cluster: Langevin B = 256 3.4 vs 4.9, B = 512
     // 6.2 vs 4.9; DL B = 256 5.7 vs 9.9, B = 512 10.8 vs 10.0; N = 300 B = 512: 4.9 vs 3.8)
-    if (tun.slab < 0 && N <= CL_LDS_K && p.rg > (planes == 2 ? 7 : 5)) return none;
+    // (DL at K = 384, where the cluster kernel takes 7.9 us: N = 300, B = 512 in 24-row clusters 8.4 -> 20 rows at most)
+    if (tun.slab < 0 && N <= CL_LDS_K && p.rg > (planes == 2 ? (round_up(N, 128) <= 384 ? 5 : 7) : 5)) return none;
     // above that the alternative is the per-step tile kernel, whose time at these batches depends on N and the tile
     // shape only (measured, us per step: 32 x 64 tiles Langevin 8.5 / 10.8 / 14.2 / 17.6 at N = 700 / 1000 / 1500 / 2000,
     // DL 13.9 / 18.5 / 25 / 32; 32 x 32 tiles Langevin 5.9 / 7.8 / 10.0 / 12.5 at N = 600 / 1000 / 1500 / 2000, DL 7.9 /
