@@ -312,7 +312,7 @@ def family_roof(launch, kind, n, b, step_us, wall_step_us):
                                       "clock_MHz": 2400},
             "mfma_frac": 2.0 * (2 if kind == "dl" else 1) * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         }
-    m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, each over \d+ XCDs)?",
+    m = re.search(r"slab_kernel<\d, (\d+), (\d+), \w+>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, each over \d+ XCDs)?",
                   launch)
     if not m:
         return {}

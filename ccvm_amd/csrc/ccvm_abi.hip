@@ -585,10 +585,14 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
     if (const SlabPlan sp = want_persist(N, tun) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
+        // the fourth template argument: launches of 512 steps or more of clusters that span XCDs calibrate their
+        // fetch delay (ccvm_slab.h: slab_calibrates); shorter launches of the same shape run the `false` variant
         char where[48] = "";
         if (sp.span > 1) std::snprintf(where, sizeof(where), ", each over %d XCDs", sp.span);
-        std::snprintf(buf, buf_len, "ccvm::slab_kernel<%d, %d, %d> grid %d x 256 threads (%d clusters of %d workgroups x %d columns, %d rows each, K = %d%s), up to %d steps per launch",
-                      solver, sp.cgrp, sp.nq, sp.grid, sp.nclusters, sp.G, 4 * sp.cgrp, 4 * sp.rg, sp.K, where, TABLE_STEPS);
+        const bool cal = CCVM_SL_CALIBRATE && sp.span > 1 && tun.slab_delay < 0;
+        std::snprintf(buf, buf_len, "ccvm::slab_kernel<%d, %d, %d, %s> grid %d x 256 threads (%d clusters of %d workgroups x %d columns, %d rows each, K = %d%s), up to %d steps per launch",
+                      solver, sp.cgrp, sp.nq, cal ? "true" : "false", sp.grid, sp.nclusters, sp.G, 4 * sp.cgrp, 4 * sp.rg, sp.K,
+                      where, TABLE_STEPS);
         return CCVM_OK;
     }
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {

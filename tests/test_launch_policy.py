@@ -30,10 +30,10 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "step_kernel<0" in _describe(hip_lib, 0, 1000, 1000)
     assert "step_kernel<2" in _describe(hip_lib, 2, 512, 2000)
     d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
-    assert "slab_kernel<0, 8, 128>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
+    assert "slab_kernel<0, 8, 128, false>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
     assert "XCDs" not in d
     d = _describe(hip_lib, 2, 32, 2000)                                    # N > 1024: 63 members of 32 columns = two XCDs
-    assert "slab_kernel<2, 8, 256>" in d and "each over 2 XCDs" in d
+    assert "slab_kernel<2, 8, 256, true>" in d and "each over 2 XCDs" in d
     assert "16 rows each" in _describe(hip_lib, 2, 64, 2000)               # four clusters of 16 rows
     assert "step_kernel" in _describe(hip_lib, 0, 128, 2000)               # a plan exists (32 rows x 32 columns per member)
     clean_env.setenv("CCVM_AMD_KERNEL", "slab")                            # but is priced above the tile kernel

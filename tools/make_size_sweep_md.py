@@ -27,6 +27,8 @@ def path(n):
         return "column-cluster persistent (3 row sets, k >= 512 in registers)"
     if n <= 768:
         return "column-cluster persistent (3 row sets, spread over the XCDs)"
+    if 1024 < n <= 1536 or 2048 < n <= 2560:
+        return "per-step tile kernel (32 x 64 tiles: fewer CU rounds)"
     return "per-step tile kernel"
 
 

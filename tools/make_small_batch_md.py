@@ -15,7 +15,7 @@ print("`python3 tools/small_batch_sweep.py`: 2048-step run calls of the engine (
 print("| solver | N | B | default: us/step | row-steps/s | plan | noslab: us/step | speed-up |")
 print("|---|---|---|---|---|---|---|---|")
 for r in rows:
-    m = re.search(r"slab_kernel<\d, (\d+), (\d+)>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(?:, each over (\d+) XCDs)?",
+    m = re.search(r"slab_kernel<\d, (\d+), (\d+), \w+>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(?:, each over (\d+) XCDs)?",
                   r["auto_kernel"])
     plan = "-"
     if m:

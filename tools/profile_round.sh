@@ -28,7 +28,7 @@ pmc() {  # name, workload, counters...   (one launch per step: 45 dispatches; pe
   rocprofv3 --pmc "$@" --kernel-trace -d $OUT/${w}_pmc_$name -o pmc --output-format csv -- python3 bench.py --workload $w $steps --spinup-ms 0 --no-cpu-baseline > $OUT/${w}_pmc_$name.log 2>&1 || exit 1
   echo "pmc $w $name done"
 }
-for w in dl_n1000_b1000 langevin_n500_b1000 dl_n100_b1000 dl_n1000_b32; do
+for w in dl_n1000_b1000 langevin_n500_b1000 dl_n100_b1000 dl_n1000_b32 dl_n1000_b256; do
   pmc fetch $w FETCH_SIZE
   pmc write $w WRITE_SIZE
   pmc sq1 $w SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
