@@ -89,6 +89,8 @@ void sweep(StepArgs a, StepArgs b, int it) {
     printf("no MFMA/noise/epilogue       (88) : %7.2f us\n", run<MODE_LANGEVIN, 88, KS>(a, b, it));
     printf("no MFMA/noise/epi/DMA/reads  (93) : %7.2f us\n", run<MODE_LANGEVIN, 93, KS>(a, b, it));
     printf("MFMA + barriers only         (85) : %7.2f us\n", run<MODE_LANGEVIN, 85, KS>(a, b, it));
+    printf("no loop barrier (timing only)(32) : %7.2f us\n", run<MODE_LANGEVIN, 32, KS>(a, b, it));
+    printf("MFMA only, no loop barrier  (117) : %7.2f us\n", run<MODE_LANGEVIN, 117, KS>(a, b, it));
     printf("affine epilogue (no noise, x'=f(qx)) [MODE_GD] : %7.2f us\n", run<MODE_GD, 0, KS>(a, b, it));
 }
 
@@ -130,5 +132,6 @@ int main(int argc, char** argv) {
            time_us([&] { hipLaunchKernelGGL(empty_kernel, dim3(512), dim3(512), 0, 0, 0); }, it));
     sweep<1>(a, b, it);
     sweep<2>(a, b, it);
+    sweep<4>(a, b, it);
     return 0;
 }
