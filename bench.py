@@ -161,8 +161,9 @@ def profiled_counters(workload):
     if "SQ_INSTS_VALU" in c and m:
         # row-owner kernel: 256-thread workgroups of four waves; rows per workgroup from the kernel's own grid is not in
         # the summary, but SQ_VALU_MFMA_BUSY_CYCLES / 8 cycles = MFMAs issued = waves x steps x 16 NCH
-        nch = int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, (\d+),", doc["kernel"]).group(1))
-        wave_steps = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 8.0 / (16 * nch)
+        pk = re.search(r"persist_kernel<\d, \w+, \d+, \d+, (\d+), \d+(?:, (\d+))?>", doc["kernel"])
+        nch, kh = int(pk.group(1)), int(pk.group(2) or 1)   # K split: a wave runs 16 NCH / KH MFMAs per step
+        wave_steps = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 8.0 / (16 * nch / kh)
         out["valu_per_wave_step"] = c["SQ_INSTS_VALU"]["mean_per_dispatch"] / wave_steps
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # MFMA_BUSY is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (its
@@ -292,22 +293,25 @@ def family_roof(launch, kind, n, b, step_us, wall_step_us):
     floor, achieved = steps/s measured."""
     import re
 
-    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x 256", launch)
+    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x 256", launch)
     if pm:
-        # Row-owner persistent kernel (N <= 256): one wave per SIMD issues its step's instructions one after the other
-        # (f32 MFMA and VALU do not overlap on a SIMD: tools/coissue.hip), so the roof is the ISSUE time of a step:
-        # 16 NCH v_mfma_f32_4x4x1 x 8 cycles + the other vector instructions x 4 cycles (one wave alone on a SIMD).
+        # Row-owner persistent kernel (N <= 256): a SIMD issues the instructions of its waves' steps one after the other
+        # (f32 MFMA and VALU do not overlap on a SIMD: tools/coissue.hip), so the roof is the ISSUE time of a step on the
+        # fullest SIMD: per wave 16 NCH / KH v_mfma_f32_4x4x1 x 8 cycles + the other vector instructions x 4 cycles,
+        # times the waves that SIMD holds (4 per workgroup over 1024 SIMDs: one, or two with the K split at B = 1000).
         # The instruction count comes from the committed SQ pass of this workload; without one no roof is claimed.
-        nch, grid = int(pm.group(5)), int(pm.group(7))
+        nch, kh, grid = int(pm.group(5)), int(pm.group(7)), int(pm.group(8))
         prof = profiled_counters(f"{kind}_n{n}_b{b}")
         if not prof or "valu_per_wave_step" not in prof:
             return {}
-        mfma = 16 * nch
-        issue = 8.0 * mfma + 4.0 * (prof["valu_per_wave_step"] - mfma)
+        waves_per_simd = -(-4 * grid // 1024)
+        mfma = 16 * nch / kh * waves_per_simd
+        issue = 8.0 * mfma + 4.0 * (prof["valu_per_wave_step"] * waves_per_simd - mfma)
         return {
             "bound": "issue", "achieved": 1e6 / step_us, "peak": 2400.0e6 / issue, "unit": "steps/s",
             "frac": issue / 2400.0 / step_us, "frac_wall": issue / 2400.0 / wall_step_us,
-            "issue_cycles_per_step": {"mfma": 8.0 * mfma, "other_valu": 4.0 * (prof["valu_per_wave_step"] - mfma),
+            "issue_cycles_per_step": {"mfma": 8.0 * mfma, "other_valu": 4.0 * (prof["valu_per_wave_step"] * waves_per_simd - mfma),
+                                      "waves_per_simd": waves_per_simd,
                                       "source": prof["source"] + " (SQ_INSTS_VALU per wave and step, MFMAs included)",
                                       "clock_MHz": 2400},
             "mfma_frac": 2.0 * (2 if kind == "dl" else 1) * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -113,6 +113,7 @@ struct Tuning {
     bool xcd = true;
     int xcd_xc = 0;      // 0: choose by L2 footprint
     int persist_ru = 0;  // 0: choose by batch size
+    int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
@@ -144,6 +145,8 @@ Tuning read_tuning() {
     if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
         if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_KH"))
+        if (e[0] == '1' || e[0] == '2') t.persist_kh = e[0] - '0';
     // CCVM_AMD_FAULT=cluster_drop: the cluster path launches without its last 8 workgroups, so the last member of
     // up to 8 clusters never runs and their peers' bounded waits must give up (status word, ~1 s): the error path
     // of tests/test_gpu_cluster.py -- never set in production
@@ -604,9 +607,9 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return CCVM_OK;
     }
     if (want_persist(N, tun)) {
-        const PersistShape sh = persist_shape(solver == 0, B, N, tun.persist_ru);
-        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d> grid %d x 256 threads, up to %d steps per launch",
-                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.grid, TABLE_STEPS);
+        const PersistShape sh = persist_shape(solver == 0, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus);
+        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d> grid %d x 256 threads, up to %d steps per launch",
+                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, TABLE_STEPS);
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
@@ -682,6 +685,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
+        pa.kh_override = tun.persist_kh;
+        pa.simds = 4 * chip_of(tun).cus;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
@@ -891,6 +896,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
         pa.S = (float)S_eff;
         pa.ru_override = tun.persist_ru;
+        pa.kh_override = tun.persist_kh;
+        pa.simds = 4 * chip_of(tun).cus;
         pa.s_cols = s_cols;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
@@ -1129,6 +1136,8 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
+        pa.kh_override = tun.persist_kh;
+        pa.simds = 4 * chip_of(tun).cus;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {

@@ -17,6 +17,12 @@
 //     double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per workgroup.
 //   RU (2 or 4) = MFMA rows in use per group: 4 when that still gives every SIMD a wave, else 2
 //     (half the per-step VALU chain per wave, twice the waves).
+//   KH (1 or 2; 2 with NCG = 2 only, round 3) = split of K over two waves: wave (cg, kh) contracts half of the
+//     k-steps for all four rows, the halves swap the partial sums of two rows each through LDS (one more barrier)
+//     and each finishes -- normals, update, publish -- the rows it received: half the per-step chain per wave
+//     WITHOUT idle MFMA rows.  A workgroup is then ONE row set of four waves, and two workgroups share a CU: a
+//     wave alone on its SIMD stalls a third of the step (LDS round trip, barrier, dependent-issue latency:
+//     2250 cycles for 1540 of issue at DL N = 100), with a second, independent wave those stalls are filled.
 //   Rows of a group: DL (c_b0, s_b0, c_b1, s_b1) -- both quadratures of an element and its
 //     (W_c, W_s) noise pair live in ONE lane; one-stream solvers: 4 consecutive batch rows, adjacent
 //     rows sharing a generator call exactly as in the tile kernel.
@@ -62,6 +68,8 @@ struct PersistArgs {
     float S;            // MF: clamp of the measured amplitude
     const float* s_cols; // per-variable saturation S_j (length ld) or NULL (see StepArgs::s_cols)
     int ru_override;     // host only: 2 / 4 forces the rows in use per group (tuning), 0 = by batch size
+    int kh_override;     // host only: 1 / 2 forces the K split off / on (tuning), 0 = by batch size
+    int simds;           // host only: SIMDs of the chip the shape is planned for (4 per CU; 0 = 1024)
     AdamConsts ad;
 };
 
@@ -89,6 +97,13 @@ __device__ __forceinline__ void mfma_chain_at(const float* af, const float* qf, 
                                                               (OFF + I) % KC, 0)), ...);
 }
 
+// K split: the k-steps OFF .. OFF + sizeof...(I) - 1 of one half; qf holds that half's fragments from index 0
+template <int CBSZ, int KC, int OFF, int... I>
+__device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf, f32x4v* acc,
+                                                std::integer_sequence<int, I...>) {
+    ((acc[I & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[(OFF + I) / KC], qf[I], acc[I & 3], CBSZ, (OFF + I) % KC, 0)), ...);
+}
+
 // K tail (measured and left off): the last chunk of 16 k-steps runs only the groups of four that hold
 // a k < N (N = 100: 100 MFMAs per
 // step instead of 112; wave-uniform scalar branches behind the straight-line part)
@@ -104,8 +119,9 @@ __device__ __forceinline__ void mfma_chain_at(const float* af, const float* qf, 
 #define CCVM_PERSIST_KTAIL 0   // measured: DL N = 100 0.967 / 0.980 us per step without, 0.978 / 0.956 with -- no gain, off
 #endif
 
-template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU>
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1>
 __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
+    static_assert(KH == 1 || (KH == 2 && NCG == 2 && RU == 4), "K split: two waves side by side, all four rows in use");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
     static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || ((NCG == 2 || NCG == 4) && CW == 64)), "shape");
@@ -115,8 +131,9 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     constexpr int KMAX = 16 * NCH;                             // K in use: 16 * ceil(N / 16), compile time so
                                                                // that the contraction is straight-line code
     constexpr int ROWS = RU * RG;                              // MFMA rows per workgroup
-    constexpr int NE = (MODE == MODE_DL) ? RU / 2 : RU;        // batch rows (elements) per lane
-    constexpr int BR = NE * RG;                                // batch rows per workgroup
+    constexpr int NEG = (MODE == MODE_DL) ? RU / 2 : RU;       // batch rows (elements) per lane position of a row group
+    constexpr int NE = NEG / KH;                               // of which this wave finishes NE (K split: half)
+    constexpr int BR = NEG * RG;                               // batch rows per row set
     constexpr int LDX = CW * NCG + 8;                          // LDS row stride: == 8 (mod 32), the 4 rows x 8 k
                                                                // of a half-wave read hit 32 distinct banks
     constexpr int KC = CW / 4;                                 // k-steps fed by one A register (blocks per row group)
@@ -125,13 +142,16 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     // (N > 64) or four one-wave sets.  Smaller workgroups landed unevenly on the SIMDs (DL N=100:
     // 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with two of these waves takes twice as
     // long.  The sets of a workgroup share nothing (N > 64: but the barrier).
-    constexpr int RSW = 4 / NCG;
-    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX];
+    constexpr int RSW = 4 / (NCG * KH);
+    constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF];
+    float* const px = xs_all + RSW * 2 * ROWS * LDX;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cg = wave % NCG;
-    float* const xs = xs_all + (wave / NCG) * (2 * ROWS * LDX);
+    const int kh = (KH == 2) ? wave / NCG : 0;  // K half (wave-uniform)
+    float* const xs = xs_all + (wave / (NCG * KH)) * (2 * ROWS * LDX);
     const int rs = lane / CW;            // row group
     const int col = cg * CW + (lane % CW);
     const int i4 = lane & 3;             // the A-operand row this lane supplies to its block
@@ -140,22 +160,26 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     const bool col_ok = col < N;
 
     // ---- Q fragments, resident for the whole launch (rows >= N of the pitched Q are zero) ------
-    float qf[KMAX];
+    // (K split: half kh holds the fragments of k = KSPLIT kh ... KSPLIT kh + KSPLIT - 1, those below KMAX)
+    constexpr int KSPLIT = (KH == 2) ? (KMAX / 2 + 3) / 4 * 4 : KMAX;  // k-steps per half, a multiple of 4
+    constexpr int KQ = (KH == 2) ? KSPLIT : KMAX;
+    const int koff = kh * KSPLIT;
+    float qf[KQ];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) qf[k] = a.Q[(size_t)k * ld + col];
+    for (int k = 0; k < KQ; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
     const float vj = col_ok ? a.V[col] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[col];  // shift * colsum(Q)[j]
     const float sat_j = (a.s_cols && col_ok) ? a.s_cols[col] : 1.0f;  // per-variable saturation
     const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
 
     // ---- this lane's elements: batch rows brow[e] at column col -------------------------------
-    const int row0 = (blockIdx.x * RSW + wave / NCG) * BR;
+    const int row0 = (blockIdx.x * RSW + wave / (NCG * KH)) * BR;
     int brow[NE];
     bool ok[NE];
     size_t gidx[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        brow[e] = row0 + rs * NE + e;
+        brow[e] = row0 + rs * NEG + kh * NE + e;
         ok[e] = col_ok && brow[e] < a.B;
         gidx[e] = (size_t)brow[e] * ld + col;  // inside the padded arrays for every lane
     }
@@ -204,12 +228,12 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if constexpr (MODE == MODE_DL) {
-                buf[(rs * RU + 2 * e) * LDX + col] = s0[e];
-                buf[(rs * RU + 2 * e + 1) * LDX + col] = s1[e];
+                buf[(rs * RU + 2 * (kh * NE + e)) * LDX + col] = s0[e];
+                buf[(rs * RU + 2 * (kh * NE + e) + 1) * LDX + col] = s1[e];
             } else if constexpr (MODE == MODE_MF) {
-                buf[(rs * RU + e) * LDX + col] = mt[e];
+                buf[(rs * RU + kh * NE + e) * LDX + col] = mt[e];
             } else {
-                buf[(rs * RU + e) * LDX + col] = s0[e];
+                buf[(rs * RU + kh * NE + e) * LDX + col] = s0[e];
             }
         }
     };
@@ -225,6 +249,11 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     float nzn0[NE], nzn1[NE];  // the next step's normals (NOISE_AHEAD)
 #pragma unroll
     for (int e = 0; e < NE; ++e) nzn0[e] = nzn1[e] = 0.0f;
+    // H: this wave's K half, a compile-time constant inside (the MFMA's block select is an immediate): the wave-uniform
+    // branch is taken once, in front of the whole loop
+    auto run_steps = [&](auto h_tag) {
+    constexpr int H = decltype(h_tag)::value;
+    constexpr int K0 = H * KSPLIT, K1 = (K0 + KSPLIT < KMAX) ? K0 + KSPLIT : KMAX;  // this wave's k-steps [K0, K1)
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
         const Row rcur = rnext;
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
         // row-broadcast b128 per 4 k-steps left one read in flight and exposed the LDS latency 28 times).
         float af[16 * NCH / KC];
 #pragma unroll
-        for (int c = 0; c < 16 * NCH / KC; ++c) af[c] = xb[c * KC];
+        for (int c = K0 / KC; c <= (K1 - 1) / KC; ++c) af[c] = xb[c * KC];
         __builtin_amdgcn_sched_barrier(0);  // all reads in flight before anything else (one latency, not NCH)
         // ---- this step's normals -- DL: (W_c, W_s) per element; MF: the NEXT step's; Langevin: this step's.
         // One-wave row sets make them HERE, while the A reads are in flight (they do not depend on them:
@@ -292,15 +321,26 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
                 if (rem > 4) mfma_chain_at<CBSZ, KC, FULL + 4>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 8) mfma_chain_at<CBSZ, KC, FULL + 8>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 12) mfma_chain_at<CBSZ, KC, FULL + 12>(af, qf, acc, std::make_integer_sequence<int, 4>{});
+            } else if constexpr (KH == 2) {
+                mfma_chain_half<CBSZ, KC, K0>(af, qf, acc, std::make_integer_sequence<int, K1 - K0>{});
             } else {
                 mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, 16 * NCH>{});
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 16 * NCH / KC; ++c) acc[c & 3][0] += af[c] * qf[c];
+            for (int c = K0 / KC; c <= (K1 - 1) / KC; ++c) acc[c & 3][0] += af[c] * qf[c - K0 / KC];
         }
         __builtin_amdgcn_sched_barrier(0);
         rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
+        // K split: the partial sums of the twin's rows leave before this wave makes its normals (the LDS write and the
+        // twin's arrival at the barrier run under them)
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (KH == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            px[((H * NCG + cg) * 2 + 0) * 64 + lane] = part[2 * (1 - H)];
+            px[((H * NCG + cg) * 2 + 1) * 64 + lane] = part[2 * (1 - H) + 1];
+        }
         if constexpr (NOISE_AHEAD) {
             if (it == 0) {
                 make_step_noise(step, it);
@@ -312,9 +352,20 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             make_step_noise(step, it);
         }
         float qx[4];
+        if constexpr (KH == 2) {
+            // the halves swap partial sums: this wave finishes rows 2 H, 2 H + 1 (its NE elements) and hands the other
+            // two to its twin; sum = (half 0) + (half 1)
+            __syncthreads();
+            const float o0 = px[(((1 - H) * NCG + cg) * 2 + 0) * 64 + lane], o1 = px[(((1 - H) * NCG + cg) * 2 + 1) * 64 + lane];
+            const float t0 = (H == 0) ? part[0] + o0 : o0 + part[2], t1 = (H == 0) ? part[1] + o1 : o1 + part[3];
+            qx[0] = __builtin_fmaf(a.in_scale, t0, shift_j);
+            qx[1] = __builtin_fmaf(a.in_scale, t1, shift_j);
+            qx[2] = qx[3] = 0.0f;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            qx[r] = __builtin_fmaf(a.in_scale, (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]), shift_j);
+            for (int r = 0; r < 4; ++r)
+                qx[r] = __builtin_fmaf(a.in_scale, (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]), shift_j);
+        }
 
         AdamScalars ad;
         if constexpr (ADAM) {
@@ -391,6 +442,13 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
             // one-wave sets: a wave's LDS instructions execute in order, its reads see its own writes
             if constexpr (NCG > 1) __syncthreads();
         }
+    }
+    };  // run_steps
+    if constexpr (KH == 2) {
+        if (kh == 0) run_steps(std::integral_constant<int, 0>{});
+        else run_steps(std::integral_constant<int, 1>{});
+    } else {
+        run_steps(std::integral_constant<int, 0>{});
     }
 
     // ---- write the state back -----------------------------------------------------------------

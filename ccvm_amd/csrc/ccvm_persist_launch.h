@@ -19,9 +19,11 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 // The launch shape of the persistent kernel for (solver, B, N): ONE definition, used by the launcher below and
 // by ccvm_describe_launch (so that the name a benchmark line reports is the instantiation that runs).
 struct PersistShape {
-    int cw, ncg, nch, ru, grid;
+    int cw, ncg, nch, ru, grid, kh;
 };
-inline PersistShape persist_shape(bool dl, int B, int N, int ru_override) {
+// kh_override: 1 / 2 forces the K split off / on (where the shape has one), 0 = by batch size
+inline PersistShape persist_shape(bool dl, int B, int N, int ru_override, int kh_override = 0, int simds = 1024) {
+    if (simds <= 0) simds = 1024;
     PersistShape s;
     s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
     s.cw = s.nch == 1 ? 16 : s.nch == 2 ? 32 : 64;                   // columns a wave covers
@@ -29,7 +31,23 @@ inline PersistShape persist_shape(bool dl, int B, int N, int ru_override) {
     const int br4 = (dl ? 2 : 4) * (64 / s.cw);                      // batch rows per row set at RU = 4
     s.ru = ((B + br4 - 1) / br4) * s.ncg >= 768 ? 4 : 2;
     if (ru_override == 2 || ru_override == 4) s.ru = ru_override;
-    const int per = br4 * s.ru / 4 * (4 / s.ncg);                    // batch rows per workgroup
+    // Two waves side by side (64 < N <= 128): K can be split over two waves instead of idling two MFMA rows -- twice the
+    // waves at half the chain each.  A step costs what the fullest SIMD issues: with w = waves per SIMD at four rows in
+    // use, ceil(w) whole chains against ceil(2 w) half chains (DL N = 100, us per step, whole / split: B = 1500, w = 1.46:
+    // 1.56 / 1.24; B = 2000, w = 1.95: 1.56 / 1.60; B = 4000: 2.84 / 2.93; Langevin B = 3000, w = 1.46: 1.61 / 1.32) --
+    // and a wave alone on its SIMD stalls a third of its step (LDS round trip, barrier, dependent issue), which a
+    // second, independent half-chain wave fills: w <= 1 takes the split too (Langevin B = 1000 0.82 -> 0.68, MF 0.94 ->
+    // 0.84, DL B <= 512 0.79 -> 0.66, DL B = 1000 0.95 -> 0.94).
+    s.kh = 1;
+    if (s.ncg == 2) {
+        const int waves4 = ((B + br4 - 1) / br4) * s.ncg;
+        const int whole = (waves4 + simds - 1) / simds, halves = (2 * waves4 + simds - 1) / simds;
+        if ((halves < 2 * whole || waves4 <= simds) && !(ru_override == 2 || ru_override == 4)) s.kh = 2;
+        if (kh_override == 1) s.kh = 1;
+        if (kh_override == 2) s.kh = 2;
+        if (s.kh == 2) s.ru = 4;
+    }
+    const int per = br4 * s.ru / 4 * (4 / (s.ncg * s.kh));           // batch rows per workgroup
     s.grid = (B + per - 1) / per;
     return s;
 }
@@ -39,8 +57,14 @@ inline PersistShape persist_shape(bool dl, int B, int N, int ru_override) {
 // wave, twice the waves).  PersistArgs::ru_override (CCVM_AMD_PERSIST_RU=2|4, read by the ABI) forces one.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
-    const PersistShape sh = persist_shape(MODE == MODE_DL, a.B, a.N, a.ru_override);  // sh.cw == CW etc. by construction
+    const PersistShape sh = persist_shape(MODE == MODE_DL, a.B, a.N, a.ru_override, a.kh_override, a.simds);  // sh.cw == CW etc.
     const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
+    if constexpr (NCG == 2) {
+        if (sh.kh == 2) {
+            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), block, 0, st, a);
+            return;
+        }
+    }
     if (sh.ru == 4)
         hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4>), dim3(sh.grid), block, 0, st, a);
     else

@@ -91,7 +91,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
     buf = ctypes.create_string_buffer(256)
     want = {
         (0, 1000, 1000, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 256 x 512",
-        (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4> grid 250 x 256",
+        (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> grid 500 x 256",   # K split: one row set per workgroup
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 500, 0): "ccvm::cluster_kernel<0, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",

@@ -1,0 +1,58 @@
+"""GPU tests of the K split of the row-owner persistent kernel (ccvm_amd/csrc/ccvm_persist.h, KH = 2: 64 < N <= 128,
+two waves side by side x two K halves; the halves swap partial sums through LDS and each finishes two of the four
+MFMA rows).  The reference's loop bodies: dl_solver.py:523-564, mf_solver.py:549-589, langevin_solver.py:411-433.
+
+Every word of every trajectory against the oracle with the split forced on and off, for every count of K chunks
+(NCH = 5 ... 8), ragged batches, odd shard starts and the Adam variants; chunking and sharding bit-exact per variant."""
+import re
+
+import pytest
+import torch
+
+from test_gpu_cluster import _ADAMS, _run_engine
+from test_gpu_slab import _check_against_oracle, _describe
+
+pytestmark = pytest.mark.gpu
+
+
+def _kh(kind, b, n, adam=False):
+    return int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, \d+, \d+, (\d)>", _describe(kind, b, n, adam)).group(1))
+
+
+@pytest.mark.parametrize("kh", [1, 2])
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("dl", 100, 1000, 30, None), ("dl", 65, 7, 30, None), ("dl", 80, 33, 30, None), ("dl", 96, 130, 30, None),
+    ("dl", 113, 1, 30, None), ("dl", 128, 257, 30, None), ("mf", 100, 1000, 30, None), ("mf", 72, 9, 30, "second_moment"),
+    ("mf", 128, 100, 30, "add_assign"), ("langevin", 100, 1000, 30, None), ("langevin", 81, 5, 30, "first_moment_only"),
+    ("pl", 100, 300, 30, "second_moment"), ("pl", 127, 66, 30, None), ("langevin", 97, 2, 30, None),
+])
+def test_k_split_matches_oracle(monkeypatch, kh, kind, n, b, t, adam):
+    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", str(kh))
+    assert _kh(kind, b, n, adam is not None) == kh
+    _check_against_oracle(kind, n, b, t, adam)
+
+
+def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves(monkeypatch):
+    monkeypatch.delenv("CCVM_AMD_PERSIST_KH", raising=False)
+    monkeypatch.delenv("CCVM_AMD_PERSIST_RU", raising=False)
+    assert _kh("dl", 1000, 100) == 2 and _kh("mf", 1000, 100) == 2 and _kh("dl", 8, 100) == 2
+    assert _kh("dl", 2000, 100) == 1 and _kh("langevin", 4000, 100) == 1      # two whole chains = four halves
+    assert _kh("dl", 1500, 100) == 2 and _kh("langevin", 3000, 100) == 2      # 1.46 waves per SIMD: three halves < two wholes
+    assert _kh("dl", 1000, 64) == 1 and _kh("dl", 1000, 200) == 1             # one wave / four waves side by side: no split
+
+
+@pytest.mark.parametrize("kind,n,b", [("dl", 100, 200), ("mf", 120, 77), ("langevin", 90, 300)])
+def test_chunking_and_sharding_are_exact_with_the_split(monkeypatch, kind, n, b):
+    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "2")
+    t = 24
+    adam = None if kind == "dl" else _ADAMS["add_assign"]
+    whole = _run_engine(kind, n, b, t, adam, 777, 0)
+    parts = _run_engine(kind, n, b, t, adam, 777, 0, chunks=[1, 9, 3, 11])
+    for name in whole.state:
+        assert torch.equal(whole.compact(name), parts.compact(name)), name
+    cut = 37
+    lo = _run_engine(kind, n, cut, t, adam, 777, 0)
+    hi = _run_engine(kind, n, b - cut, t, adam, 777, cut)
+    for name in whole.state:
+        w = whole.compact(name)
+        assert torch.equal(w[:cut], lo.compact(name)) and torch.equal(w[cut:], hi.compact(name)), name

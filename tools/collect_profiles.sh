@@ -7,7 +7,7 @@ cp $P/dl_n1000_b1000_stats/s_kernel_stats.csv profiles/${TAG}_bench_kernel_stats
 CMD='rocprofv3 --pmc <counter set> --kernel-trace --output-format csv -- python3 bench.py --workload W --steps 40 --warmup 5 [persistent kernels: --steps 1000 --warmup 200] --spinup-ms 0 --no-cpu-baseline (one pass per counter set: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*; tools/profile_round.sh)'
 python tools/pmc_summary.py --kernel 'step_kernel<0, false, 0, 1' --name 'ccvm::step_kernel<0, false, 0, 1, false, 0> = DL step, N=1000, B=1000 (headline)' --command "${CMD/W/dl_n1000_b1000}" --out profiles/${TAG}_bench_pmc.json $P/dl_n1000_b1000_pmc_fetch $P/dl_n1000_b1000_pmc_write $P/dl_n1000_b1000_pmc_sq1 $P/dl_n1000_b1000_pmc_tcc > /dev/null
 python tools/pmc_summary.py --kernel 'cluster_kernel<2' --steps-per-dispatch 600 --name 'ccvm::cluster_kernel<2, false, 4, false> = Langevin, N=500, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/langevin_n500_b1000}" --out profiles/${TAG}_langevin_n500_b1000_pmc.json $P/langevin_n500_b1000_pmc_fetch $P/langevin_n500_b1000_pmc_write $P/langevin_n500_b1000_pmc_sq1 $P/langevin_n500_b1000_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'persist_kernel<0, false, 64, 2, 7, 4>' --steps-per-dispatch 600 --name 'ccvm::persist_kernel<0, false, 64, 2, 7, 4> = DL, N=100, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n100_b1000}" --out profiles/${TAG}_dl_n100_b1000_pmc.json $P/dl_n100_b1000_pmc_fetch $P/dl_n100_b1000_pmc_write $P/dl_n100_b1000_pmc_sq1 $P/dl_n100_b1000_pmc_tcc > /dev/null
+python tools/pmc_summary.py --kernel 'persist_kernel<0, false, 64, 2, 7, 4, 2>' --steps-per-dispatch 600 --name 'ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> = DL, N=100, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n100_b1000}" --out profiles/${TAG}_dl_n100_b1000_pmc.json $P/dl_n100_b1000_pmc_fetch $P/dl_n100_b1000_pmc_write $P/dl_n100_b1000_pmc_sq1 $P/dl_n100_b1000_pmc_tcc > /dev/null
 python tools/pmc_summary.py --kernel 'slab_kernel<0, 8, 128' --steps-per-dispatch 600 --name 'ccvm::slab_kernel<0, 8, 128> = DL, N=1000, B=32 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n1000_b32}" --out profiles/${TAG}_dl_n1000_b32_pmc.json $P/dl_n1000_b32_pmc_fetch $P/dl_n1000_b32_pmc_write $P/dl_n1000_b32_pmc_sq1 $P/dl_n1000_b32_pmc_tcc > /dev/null
 python tools/pmc_summary.py --kernel 'step_kernel<0, false, 0, 4' --name 'ccvm::step_kernel<0, false, 0, 4, false, 0> = DL step, N=1000, B=256 (32 x 32 split-K tiles)' --command "${CMD/W/dl_n1000_b256}" --out profiles/${TAG}_dl_n1000_b256_pmc.json $P/dl_n1000_b256_pmc_fetch $P/dl_n1000_b256_pmc_write $P/dl_n1000_b256_pmc_sq1 $P/dl_n1000_b256_pmc_tcc > /dev/null
 cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
