@@ -28,15 +28,21 @@ _REPLAY_CHUNK_FLOATS = 32 * 1024 * 1024  # per noise stream, per chunk (128 MiB)
 # --------------------------------------------------------------------------- #
 # device / library access
 # --------------------------------------------------------------------------- #
+_gpu_seen = False
+
+
 def gpu_device():
     """The torch device the engine runs on; raises if there is none."""
+    global _gpu_seen
     lib = _lib.load()  # fail on a missing library before touching the GPU
     del lib
-    if not torch.cuda.is_available():
-        raise EngineUnavailable(
-            "no MI355X visible (torch.cuda.is_available() is False); the CCVM dynamics engine"
-            " has no CPU fallback"
-        )
+    if not _gpu_seen:  # (asked once per process: torch.cuda.is_available() costs milliseconds per call on ROCm)
+        if not torch.cuda.is_available():
+            raise EngineUnavailable(
+                "no MI355X visible (torch.cuda.is_available() is False); the CCVM dynamics engine"
+                " has no CPU fallback"
+            )
+        _gpu_seen = True
     index = int(os.environ.get("CCVM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     return torch.device("cuda", index)
 
@@ -95,8 +101,9 @@ def prime(kind, n, batch, adam=None):
         traj = Trajectories(prob, batch, kind, 1, params, (0.0, 1.0), NoiseSpec(mode="philox", seed=1),
                             adam=dict(adam) if adam else None)
         traj.advance(1)
-        for name in traj.state:  # the runtime's host staging buffers for results of this size
-            traj.compact(name).cpu()
+        for name in traj.state:  # the runtime's host staging buffers for results of this size, through the very
+            traj.compact(name).cpu()          # operations a solver's __call__ uses (the strided view's first copy loads
+            traj.view(name).to("cpu")         # torch's copy kernel: 50 ms inside the first solve_time otherwise)
         torch.cuda.synchronize(dev)
     _primed.add(key)  # only after it succeeded
 
