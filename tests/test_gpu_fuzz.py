@@ -195,3 +195,30 @@ def test_random_tile_shape_configuration_matches_oracle(kind, n, b, t, adam_i, o
     monkeypatch.setenv("CCVM_AMD_KS", str(ks))
     _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, (0.0, 1.0), None, True, vec_s, False,
                          _KeepEnv(monkeypatch))
+
+
+# ---- the row-owner persistent kernel with its shape knobs forced (rows in use per group, K split) ------------------
+def _persist_cases(count=int(os.environ.get("CCVM_FUZZ_PERSIST_COUNT", "48")), seed=int(os.environ.get("CCVM_FUZZ_SEED", "20240607"))):
+    rng = random.Random(seed + 3)
+    out = []
+    for _ in range(count):
+        kind = rng.choice(["dl", "mf", "langevin", "pl"])
+        n = rng.choice([1, 16, 17, 33, 64, 65, 66, 80, 81, 96, 97, 100, 112, 113, 127, 128, 129, 200, 256])
+        b = rng.choice([1, 2, 3, 5, 31, 64, 100, 257, 1000, 3000])
+        t = rng.choice([1, 2, 5, 9])
+        adam = None if kind == "dl" else rng.choice(ADAMS)
+        cuts = sorted(rng.sample(range(1, t), min(t - 1, rng.choice([0, 1, 2])))) if t > 1 else []
+        replay = rng.random() < 0.3
+        out.append((kind, n, b, t, ADAMS.index(adam), 0 if replay else rng.choice([0, 1, 64, 4097]), tuple(cuts), replay,
+                    kind != "dl" and rng.random() < 0.3, rng.choice([1, 2]), rng.choice([0, 0, 2, 4])))
+    return out
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam_i,offset,cuts,replay,vec_s,kh,ru", _persist_cases())
+def test_random_row_owner_shape_matches_oracle(kind, n, b, t, adam_i, offset, cuts, replay, vec_s, kh, ru, monkeypatch):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", str(kh))
+    if ru:
+        monkeypatch.setenv("CCVM_AMD_PERSIST_RU", str(ru))
+    _check_configuration(kind, n, b, t, adam_i, offset, cuts, replay, (0.0, 1.0), None, True, vec_s, False,
+                         _KeepEnv(monkeypatch))
