@@ -293,7 +293,7 @@ def family_roof(launch, kind, n, b, step_us, wall_step_us):
     floor, achieved = steps/s measured."""
     import re
 
-    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x 256", launch)
+    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x (?:256|512)", launch)
     if pm:
         # Row-owner persistent kernel (N <= 256): a SIMD issues the instructions of its waves' steps one after the other
         # (f32 MFMA and VALU do not overlap on a SIMD: tools/coissue.hip), so the roof is the ISSUE time of a step on the
@@ -304,7 +304,7 @@ def family_roof(launch, kind, n, b, step_us, wall_step_us):
         prof = profiled_counters(f"{kind}_n{n}_b{b}")
         if not prof or "valu_per_wave_step" not in prof:
             return {}
-        waves_per_simd = -(-4 * grid // 1024)
+        waves_per_simd = -(-(8 if int(pm.group(4)) * kh > 4 else 4) * grid // 1024)
         mfma = 16 * nch / kh * waves_per_simd
         issue = 8.0 * mfma + 4.0 * (prof["valu_per_wave_step"] * waves_per_simd - mfma)
         return {

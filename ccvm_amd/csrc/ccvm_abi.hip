@@ -607,9 +607,10 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return CCVM_OK;
     }
     if (want_persist(N, tun)) {
-        const PersistShape sh = persist_shape(solver == 0, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus);
-        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d> grid %d x 256 threads, up to %d steps per launch",
-                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, TABLE_STEPS);
+        const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus);
+        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d> grid %d x %d threads, up to %d steps per launch",
+                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid,
+                      sh.ncg * sh.kh > 4 ? 512 : 256, TABLE_STEPS);
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);

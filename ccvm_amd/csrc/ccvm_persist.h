@@ -17,7 +17,7 @@
 //     double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per workgroup.
 //   RU (2 or 4) = MFMA rows in use per group: 4 when that still gives every SIMD a wave, else 2
 //     (half the per-step VALU chain per wave, twice the waves).
-//   KH (1 or 2; 2 with NCG = 2 only, round 3) = split of K over two waves: wave (cg, kh) contracts half of the
+//   KH (1 or 2; 2 with NCG = 2 or 4, round 3) = split of K over two waves: wave (cg, kh) contracts half of the
 //     k-steps for all four rows, the halves swap the partial sums of two rows each through LDS (one more barrier)
 //     and each finishes -- normals, update, publish -- the rows it received: half the per-step chain per wave
 //     WITHOUT idle MFMA rows.  A workgroup is then ONE row set of four waves, and two workgroups share a CU: a
@@ -120,8 +120,8 @@ __device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf
 #endif
 
 template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1>
-__global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
-    static_assert(KH == 1 || (KH == 2 && NCG == 2 && RU == 4), "K split: two waves side by side, all four rows in use");
+__global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_kernel(const PersistArgs a) {
+    static_assert(KH == 1 || (KH == 2 && (NCG == 2 || NCG == 4) && RU == 4), "K split: waves side by side, all four rows in use");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
     static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || ((NCG == 2 || NCG == 4) && CW == 64)), "shape");
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void persist_kernel(const PersistArgs a) {
     // (N > 64) or four one-wave sets.  Smaller workgroups landed unevenly on the SIMDs (DL N=100:
     // 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with two of these waves takes twice as
     // long.  The sets of a workgroup share nothing (N > 64: but the barrier).
-    constexpr int RSW = 4 / (NCG * KH);
+    constexpr int RSW = (NCG * KH > 4) ? 1 : 4 / (NCG * KH);  // (four waves side by side x two K halves: eight waves)
     constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums
     __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF];
     float* const px = xs_all + RSW * 2 * ROWS * LDX;

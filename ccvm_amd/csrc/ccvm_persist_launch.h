@@ -22,7 +22,9 @@ struct PersistShape {
     int cw, ncg, nch, ru, grid, kh;
 };
 // kh_override: 1 / 2 forces the K split off / on (where the shape has one), 0 = by batch size
-inline PersistShape persist_shape(bool dl, int B, int N, int ru_override, int kh_override = 0, int simds = 1024) {
+// solver: 0 DL, 1 MF, 2 Langevin / pumped Langevin (the C ABI's numbering)
+inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_override, int kh_override = 0, int simds = 1024) {
+    const bool dl = solver == 0;
     if (simds <= 0) simds = 1024;
     PersistShape s;
     s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
@@ -39,15 +41,25 @@ inline PersistShape persist_shape(bool dl, int B, int N, int ru_override, int kh
     // second, independent half-chain wave fills: w <= 1 takes the split too (Langevin B = 1000 0.82 -> 0.68, MF 0.94 ->
     // 0.84, DL B <= 512 0.79 -> 0.66, DL B = 1000 0.95 -> 0.94).
     s.kh = 1;
-    if (s.ncg == 2) {
+    if (s.ncg >= 2) {
         const int waves4 = ((B + br4 - 1) / br4) * s.ncg;
         const int whole = (waves4 + simds - 1) / simds, halves = (2 * waves4 + simds - 1) / simds;
-        if ((halves < 2 * whole || waves4 <= simds) && !(ru_override == 2 || ru_override == 4)) s.kh = 2;
+        // Four waves side by side (128 < N <= 256): from this many K chunks on the unsplit kernel needs more than 256
+        // VGPRs (its Q fragments alone are 16 NCH), i.e. a SIMD holds ONE of its waves; the split kernel (half the
+        // fragments) fits two, and wins at every batch (N = 256: DL 3.54 -> 2.88 us per step at B = 1000, 14.2 -> 11.5
+        // at B = 4000; Langevin 1.89 -> 1.48, MF 2.30 -> 1.69; N = 240 DL -12 %, N = 224 MF -18 %).  Below that the
+        // unsplit kernel holds two waves itself and the rule above decides (N = 208 Langevin, B = 2000: 2.30 unsplit
+        // vs 2.61 split).  Register counts from the code objects of this build (hipcc 7.2): DL 258 at NCH = 13, MF 272
+        // at 11, MF + Adam 270 at 10, Langevin 272 at 14, Langevin + Adam 266 at 12.
+        const int lone_from = dl ? 13 : solver == 1 ? (adam ? 10 : 11) : (adam ? 12 : 14);
+        const bool lone = s.ncg == 4 && s.nch >= lone_from;
+        if ((halves < 2 * whole || waves4 <= simds || lone) && !(ru_override == 2 || ru_override == 4)) s.kh = 2;
         if (kh_override == 1) s.kh = 1;
         if (kh_override == 2) s.kh = 2;
         if (s.kh == 2) s.ru = 4;
     }
-    const int per = br4 * s.ru / 4 * (4 / (s.ncg * s.kh));           // batch rows per workgroup
+    const int sets = s.ncg * s.kh > 4 ? 1 : 4 / (s.ncg * s.kh);      // row sets per workgroup
+    const int per = br4 * s.ru / 4 * sets;                           // batch rows per workgroup
     s.grid = (B + per - 1) / per;
     return s;
 }
@@ -57,11 +69,13 @@ inline PersistShape persist_shape(bool dl, int B, int N, int ru_override, int kh
 // wave, twice the waves).  PersistArgs::ru_override (CCVM_AMD_PERSIST_RU=2|4, read by the ABI) forces one.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
-    const PersistShape sh = persist_shape(MODE == MODE_DL, a.B, a.N, a.ru_override, a.kh_override, a.simds);  // sh.cw == CW etc.
+    const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, ADAM, a.B, a.N, a.ru_override,
+                                          a.kh_override, a.simds);  // sh.cw == CW etc. by construction
     const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
-    if constexpr (NCG == 2) {
-        if (sh.kh == 2) {
-            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), block, 0, st, a);
+    if constexpr (NCG >= 2) {
+        if (sh.kh == 2) {  // one row set of NCG x 2 waves
+            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), dim3(NCG == 4 ? 512 : 256), 0,
+                               st, a);
             return;
         }
     }

@@ -1,5 +1,5 @@
-"""GPU tests of the K split of the row-owner persistent kernel (ccvm_amd/csrc/ccvm_persist.h, KH = 2: 64 < N <= 128,
-two waves side by side x two K halves; the halves swap partial sums through LDS and each finishes two of the four
+"""GPU tests of the K split of the row-owner persistent kernel (ccvm_amd/csrc/ccvm_persist.h, KH = 2: 64 < N <= 256,
+two or four waves side by side x two K halves; the halves swap partial sums through LDS and each finishes two of the four
 MFMA rows).  The reference's loop bodies: dl_solver.py:523-564, mf_solver.py:549-589, langevin_solver.py:411-433.
 
 Every word of every trajectory against the oracle with the split forced on and off, for every count of K chunks
@@ -25,6 +25,10 @@ def _kh(kind, b, n, adam=False):
     ("dl", 113, 1, 30, None), ("dl", 128, 257, 30, None), ("mf", 100, 1000, 30, None), ("mf", 72, 9, 30, "second_moment"),
     ("mf", 128, 100, 30, "add_assign"), ("langevin", 100, 1000, 30, None), ("langevin", 81, 5, 30, "first_moment_only"),
     ("pl", 100, 300, 30, "second_moment"), ("pl", 127, 66, 30, None), ("langevin", 97, 2, 30, None),
+    # four waves side by side (128 < N <= 256): one row set of eight waves
+    ("dl", 129, 33, 20, None), ("dl", 200, 500, 12, None), ("dl", 256, 64, 12, None), ("dl", 177, 3, 20, None),
+    ("mf", 144, 50, 20, "second_moment"), ("mf", 250, 700, 10, None), ("langevin", 256, 1000, 8, "add_assign"),
+    ("pl", 193, 129, 16, None), ("langevin", 225, 7, 20, "first_moment_only"), ("dl", 240, 1000, 6, None),
 ])
 def test_k_split_matches_oracle(monkeypatch, kh, kind, n, b, t, adam):
     monkeypatch.setenv("CCVM_AMD_PERSIST_KH", str(kh))
@@ -38,10 +42,13 @@ def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves
     assert _kh("dl", 1000, 100) == 2 and _kh("mf", 1000, 100) == 2 and _kh("dl", 8, 100) == 2
     assert _kh("dl", 2000, 100) == 1 and _kh("langevin", 4000, 100) == 1      # two whole chains = four halves
     assert _kh("dl", 1500, 100) == 2 and _kh("langevin", 3000, 100) == 2      # 1.46 waves per SIMD: three halves < two wholes
-    assert _kh("dl", 1000, 64) == 1 and _kh("dl", 1000, 200) == 1             # one wave / four waves side by side: no split
+    assert _kh("dl", 1000, 64) == 1                                           # one wave per row set: nothing to split
+    assert _kh("dl", 1000, 192) == 1 and _kh("dl", 500, 192) == 2 and _kh("langevin", 1000, 256) == 2  # 128 < N <= 256: same rule ...
+    assert _kh("dl", 4000, 256) == 2 and _kh("mf", 4000, 176) == 2 and _kh("langevin", 2000, 208) == 1  # ... unless a SIMD holds one unsplit wave
 
 
-@pytest.mark.parametrize("kind,n,b", [("dl", 100, 200), ("mf", 120, 77), ("langevin", 90, 300)])
+@pytest.mark.parametrize("kind,n,b", [("dl", 100, 200), ("mf", 120, 77), ("langevin", 90, 300), ("dl", 200, 150),
+                                      ("langevin", 256, 90)])
 def test_chunking_and_sharding_are_exact_with_the_split(monkeypatch, kind, n, b):
     monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "2")
     t = 24
