@@ -21,6 +21,8 @@ flops = {"dl": 4, "mf": 2, "langevin": 2, "pl": 2, "mf + Adam": 2, "langevin + A
 def path(n):
     if 64 < n <= 128:
         return "persistent row-owner (K split over two waves per SIMD)"
+    if 128 < n <= 256:
+        return "persistent row-owner (K split where the unsplit kernel leaves one wave per SIMD: N > ~200)"
     if n <= 256:
         return "persistent row-owner"
     if n <= 512:
