@@ -106,3 +106,31 @@ def test_no_plan_means_the_tile_kernel(hip_lib, clean_env):
     assert "step_kernel" in _describe(hip_lib, 2, 32, 500)
     clean_env.setenv("CCVM_AMD_KERNEL", "tile")
     assert "step_kernel" in _describe(hip_lib, 0, 1000, 100)
+
+
+def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_counts(hip_lib, clean_env):
+    """Code-object metadata of the built library (tools/kernel_resources.py, no GPU): no kernel uses scratch, and the
+    row-owner kernel's "one unsplit wave per SIMD" thresholds (ccvm_persist_launch.h: lone_from) are the K chunk counts
+    from which the unsplit four-wave kernels need more than 256 VGPRs -- a compiler change that moves them fails here."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    ks = kernel_resources.kernels()
+    assert len(ks) > 300
+    bad = [k["name"] for k in ks if k["scratch"] or k["spill"]]
+    assert not bad, bad
+    regs = {}
+    for k in ks:
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, 4, (\d+), 4, 1>", k["name"])
+        if m:
+            regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    for solver, adam in ((0, False), (1, False), (1, True), (2, False), (2, True)):
+        for nch in range(9, 17):
+            # B = 4096 rows per ... : whole rounds either way, so the split is taken only for the register reason
+            d = _describe(hip_lib, solver, 8192 if solver else 4096, 16 * nch, 1 if adam else 0)
+            split = int(re.search(r"persist_kernel<\d, \w+, 64, 4, \d+, 4, (\d)>", d).group(1)) == 2
+            assert split == (regs[(solver, adam, nch)] > 256), (solver, adam, nch, regs[(solver, adam, nch)], d)
