@@ -171,7 +171,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
     constexpr int NR = 16 / KS;              // accumulator registers a wave finishes (epilogue rows)
     constexpr int NSTAGE = RING ? RING : 4;
     static_assert(NSTAGE >= 4 && NSTAGE % 2 == 0, "ring depth: the consumer loop alternates two fragment sets");
-    constexpr int NOISE_LDS = NOISY ? NA * 16 * NTHREADS : 0;  // DL: (W_c, W_s) per accumulator register
+    // DL: (W_c, W_s) per accumulator register a wave finishes (NR of the 16: the split-K shapes keep their LDS small
+    // enough for two workgroups per CU -- 32 x 64 tiles: 80 KB instead of 96 -- which pays where a CU runs several
+    // workgroups one after the other)
+    constexpr int NOISE_LDS = NOISY ? NA * NR * NTHREADS : 0;
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE + NOISE_LDS];
     float* const lds_noise = lds + NSTAGE * STAGE;
@@ -235,14 +238,14 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
             if constexpr (MODE == MODE_DL) {
                 const int r = R0 + u;
                 const NormalPair p = normal_pair(a.seed, a.row_offset + row0 + erow(r), a.step, j);
-                lds_noise[(0 * 16 + r) * NTHREADS + tid] = p.n0;
-                lds_noise[(1 * 16 + r) * NTHREADS + tid] = p.n1;
+                lds_noise[(0 * NR + u) * NTHREADS + tid] = p.n0;
+                lds_noise[(1 * NR + u) * NTHREADS + tid] = p.n1;
             } else {
                 const int r = R0 + 2 * u;  // rows b (even) and b + 1
                 const int st = (MODE == MODE_MF) ? a.step + 1 : a.step;
                 const NormalPair p = normal_two_rows(a.seed, a.row_offset + row0 + erow(r), st, j);
-                lds_noise[r * NTHREADS + tid] = p.n0;
-                lds_noise[(r + 1) * NTHREADS + tid] = p.n1;
+                lds_noise[(2 * u) * NTHREADS + tid] = p.n0;
+                lds_noise[(2 * u + 1) * NTHREADS + tid] = p.n1;
             }
         }
     };
@@ -307,10 +310,10 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                     // written in the prologue by this thread or its twin
                     if constexpr (MODE == MODE_MF) {
                         n0 = hcar[ii];  // this step's normal, generated one step ago
-                        n0n = a.s.mf.has_next ? lds_noise[r * NTHREADS + tid] : 0.0f;
+                        n0n = a.s.mf.has_next ? lds_noise[(ibase + ii) * NTHREADS + tid] : 0.0f;
                     } else {
-                        n0 = lds_noise[(0 * 16 + r) * NTHREADS + tid];
-                        if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * 16 + r) * NTHREADS + tid];
+                        n0 = lds_noise[(0 * NR + ibase + ii) * NTHREADS + tid];
+                        if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * NR + ibase + ii) * NTHREADS + tid];
                     }
                 } else if (ok) {
                     const size_t widx = (size_t)j * a.B + row0 + erow(r);
