@@ -7,7 +7,9 @@ CASES = (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 300, 512, 2000
          # the slab kernel: clusters inside XCDs, over two XCDs, streamed row groups
          ("dl", 1000, 32, 100000), ("pl", 2000, 32, 50000), ("langevin", 1000, 128, 30000), ("mf", 500, 64, 100000),
          # the tile kernel's 32 x 32 and multi-round 32 x 64 shapes
-         ("dl", 1000, 256, 20000), ("langevin", 1500, 1000, 5000))
+         ("dl", 1000, 256, 20000), ("langevin", 1500, 1000, 5000),
+         # the row-owner kernel's K split: two and four waves side by side
+         ("mf", 100, 1000, 100000), ("dl", 256, 1000, 30000), ("langevin", 200, 500, 50000))
 for kind, n, b, t in CASES:
     traj, q, v = bench.make_trajectories(kind, n, b, t, 0)
     t0 = time.time()
