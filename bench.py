@@ -65,6 +65,21 @@ SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example 
 # --------------------------------------------------------------------------- #
 # launcher (no GPU call may happen in this process before the ranks are started)
 # --------------------------------------------------------------------------- #
+#: Multi-process GPU work on this pool's hosts: the kernel driver only supports dmabuf IPC, and with the ROCr default
+#: (legacy IPC handles) RCCL's intra-node transport set-up -- hipIpcGetMemHandle of the peers' buffers -- fails with
+#: "invalid argument".  The image exports the variable already; the launcher and every rank keep it (setdefault: an
+#: explicit value in the caller's environment wins).  tests/test_gpu_sharded.py sets the same for its ranks.
+IPC_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def shard_rows(total_rows, world, rank):
+    """(first row, rows) of rank `rank` when `total_rows` rows are split over `world` ranks: total // world each, the
+    first total % world ranks one more -- every rank gets at least one row whenever total >= world (ceil-sized
+    shards left trailing ranks EMPTY, e.g. 9 rows on 8 ranks: ADVICE r3)."""
+    base, extra = divmod(int(total_rows), int(world))
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
 def visible_gpu_count():
     """GPUs this process may use, counted WITHOUT the HIP runtime (the launcher must not initialise the GPU before
     it starts its ranks: torch.cuda.device_count() can fall back to hipGetDeviceCount): the *_VISIBLE_DEVICES
@@ -107,6 +122,7 @@ def launch_ranks(n, argv, script=None, timeout=None):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault(*IPC_ENV)
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=env))
     deadline = time.time() + float(timeout or os.environ.get("CCVM_BENCH_LAUNCH_TIMEOUT", "1500"))
     codes = [None] * n
@@ -392,6 +408,7 @@ def main():
     comm_dev = torch.device("cpu") if share else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault(*IPC_ENV)  # before the process group exists (under torch.distributed.run too)
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -402,9 +419,7 @@ def main():
     if args.global_batch is not None:
         if args.global_batch < world:
             raise SystemExit(f"--global-batch {args.global_batch} < {world} ranks")
-        per = -(-args.global_batch // world)
-        row0 = rank * per
-        b = min(per, args.global_batch - row0)
+        row0, b = shard_rows(args.global_batch, world, rank)
     global_rows = args.global_batch if args.global_batch is not None else b * world
     total = args.warmup + args.steps
     traj, q, v = make_trajectories(kind, n, b, total, rank, row_offset=row0)
@@ -421,26 +436,30 @@ def main():
             torch.cuda.synchronize(dev)
         del scratch
     traj.advance(args.warmup)
-    torch.cuda.synchronize(dev)
-    barrier()
     # HIP events on the stream the engine launches on (torch's current stream: engine._stream_ptr)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()  # torch creates the HIP event at its first record (15-20 us): the measuring apparatus is set up
     ev1.record()  # BEFORE the timed region (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
+    torch.cuda.synchronize(dev)
+    barrier()     # every rank starts its K steps together ...
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
     traj.advance(args.steps)
     ev1.record()
     torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
+    barrier()                           # inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
+    #                                     loss" on the driver's 0.7 ms); the job's time is the MAX over ranks
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # stream time of the timed region / steps
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+    per_rank_elapsed = [elapsed]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        each = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(each, t)
+        per_rank_elapsed = [float(x.item()) for x in each]
+    elapsed = max(per_rank_elapsed)
 
     # the steps right after the loop (device-side finalize: clamp, change of variables, optional
     # post-processor, energy) + the one collective: all-gather of the objective values (RCCL)
@@ -456,7 +475,7 @@ def main():
     ranks_seen = 1
     if world > 1:
         obj = obj.to(comm_dev)
-        if args.global_batch is not None:  # the last shard may be shorter: gather equal-length, -inf-padded vectors
+        if args.global_batch is not None:  # shards differ by a row: gather equal-length, +inf-padded vectors
             per = -(-args.global_batch // world)
             obj = torch.cat([obj, torch.full((per - obj.numel(),), float("inf"), dtype=obj.dtype, device=obj.device)])
         gathered = [torch.empty_like(obj) for _ in range(world)]
@@ -511,6 +530,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall_ms_per_step,
+            "ms_per_step_per_rank": [e / args.steps * 1e3 for e in per_rank_elapsed],
             "higher_is_better": True,
             "scaling": "strong" if args.global_batch is not None else "weak",
             "vs_baseline": None,
@@ -525,6 +545,7 @@ def main():
                             + f"fp32 state, fused Threefry noise, schedule of a {total}-step run"
                             + (f", {args.post} post-processor on device after the loop" if args.post else ""),
                 "global_batch": global_rows,
+                "rows_per_rank": [shard_rows(global_rows, world, r)[1] for r in range(world)],
                 "parallelism": f"batch-sharded x{world}, no data-path collective; one all-gather of "
                                f"{global_rows} objective values after the loop "
                                f"({'gloo rehearsal on one GPU' if share else 'RCCL' if world > 1 else 'single rank'})",

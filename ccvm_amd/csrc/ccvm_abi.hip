@@ -412,6 +412,10 @@ __global__ void exchange_init_kernel(uint2* xb, size_t packets, int K, int Kx, c
         xb[i] = make_uint2(0u, pad ? 0xFFFFFFFFu : 0u);
     }
 }
+// Between the init kernel and the commit kernel of a call the record is INVALID (id 0 matches no layout): a call that
+// returns early -- a failed launch in the middle of its chunk loop -- leaves tags of its own steps in the area, and a
+// retry of the same steps must clear them instead of taking them for the peers' packets.
+__global__ void exchange_open_kernel(unsigned* hdr) { hdr[XHDR_ID] = 0u; }
 __global__ void exchange_commit_kernel(unsigned* hdr, unsigned id, unsigned max_tag) {
     hdr[XHDR_ID] = id;
     hdr[XHDR_MAXTAG] = max_tag;
@@ -425,6 +429,7 @@ int exchange_prepare(void* area, size_t bytes, int K, int Kx, unsigned* hdr, uns
     const size_t packets = bytes / 8;
     hipLaunchKernelGGL(exchange_init_kernel, dim3(ew_grid(packets)), dim3(256), 0, st, static_cast<uint2*>(area), packets,
                        K, Kx, hdr, id, (unsigned)step0);
+    hipLaunchKernelGGL(exchange_open_kernel, dim3(1), dim3(1), 0, st, hdr);  // stream order: after every init thread's read
     return hipGetLastError() == hipSuccess ? CCVM_OK : CCVM_E_HIP;
 }
 int exchange_commit(unsigned* hdr, unsigned id, int step_end, hipStream_t st) {

@@ -13,6 +13,7 @@ back.  The GPU used is ``cuda:$LOCAL_RANK`` (or ``$CCVM_AMD_DEVICE``, default 0)
 """
 import ctypes
 import os
+import threading
 import time
 from dataclasses import dataclass
 from typing import Optional
@@ -47,10 +48,19 @@ def gpu_device():
     return torch.device("cuda", index)
 
 
+# Host threads may drive the engine concurrently (one stream each): the module-level caches below -- which devices
+# are warm, which configurations are primed, the staged problems -- are only touched under this lock (re-entrant:
+# prime() warms up, and both stage problems).
+_cache_lock = threading.RLock()
 _warm = set()
 
 
 def warmup():
+    with _cache_lock:
+        _warmup_locked()
+
+
+def _warmup_locked():
     """Once per process and device: create the HIP context and load every code object of the library
     (one per translation unit: the ABI + tile kernels, and the five persistent-kernel units), so that
     this one-time cost (~0.2 s) never lands inside a solver's timed region.  One elementwise launch
@@ -86,6 +96,11 @@ def prime(kind, n, batch, adam=None):
     warmup()
     if n > 2048:
         return  # a dry run would stage a zero N x N matrix; at these sizes the first-use costs are noise
+    with _cache_lock:
+        _prime_locked(kind, n, batch, adam)
+
+
+def _prime_locked(kind, n, batch, adam):
     dev = gpu_device()
     use_v = bool(adam) and float(adam["beta2"]) != 1.0
     key = (dev.index, kind, int(n), int(batch), bool(adam), use_v)
@@ -249,8 +264,11 @@ class DeviceProblem:
     def __init__(self, q_matrix, v_vector):
         self.device = gpu_device()
         self.n = int(q_matrix.shape[0])
-        if tuple(q_matrix.shape) != (self.n, self.n) or tuple(v_vector.shape) != (self.n,):
-            raise ValueError("q_matrix must be (N, N) and v_vector (N,)")
+        # V: anything with N elements -- the reference only ever broadcasts it against (batch, N) arrays, so a (1, N)
+        # row vector works there too (its test_mf_solver.py:255 passes one)
+        if tuple(q_matrix.shape) != (self.n, self.n) or v_vector.numel() != self.n:
+            raise ValueError("q_matrix must be (N, N) and v_vector must hold N values")
+        v_vector = v_vector.reshape(-1)
         self.ld = ld_of(self.n)
         with torch.cuda.device(self.device):
             self.q = pack(q_matrix.detach().to(self.device), self.ld, self.ld)
@@ -264,6 +282,10 @@ class DeviceProblem:
                                             _stream_ptr()), "ccvm_column_sums")
 
 
+#: device index -> time.monotonic() until which new Trajectories avoid the cluster / slab kernels (set by a time-out
+#: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 30)
+_exchange_blocked_until = {}
+
 _problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device index, DeviceProblem, ready event)
 
 
@@ -276,6 +298,11 @@ def device_problem(q_matrix, v_vector):
     bypass the version counter -- ``q.data.mul_()``, ``set_`` -- are not seen: re-create the tensor.)
     A cached entry served to another stream is recorded on it (``record_stream``), so the caching
     allocator cannot hand its memory out again while kernels of that stream still read it."""
+    with _cache_lock:
+        return _device_problem_locked(q_matrix, v_vector)
+
+
+def _device_problem_locked(q_matrix, v_vector):
     import weakref
 
     dev = gpu_device()
@@ -379,7 +406,10 @@ class Trajectories:
         # Time-out recovery (see check): the state at the last verified point, taken before the first run call that
         # may launch a kernel whose workgroups wait for each other; None while nothing unverified has run.
         self._snap = None
-        self.no_exchange = False   # True after a time-out: the rest of the run stays on the tile kernel
+        # True after a time-out: the rest of the run stays on the tile kernel.  A time-out anywhere in this process
+        # also keeps NEW trajectories on this device off the exchange kernels for a cool-down period (ADVICE r3:
+        # whatever held the GPU -- another process, a CU mask -- would cost each of them its own ~1 s wait)
+        self.no_exchange = time.monotonic() < _exchange_blocked_until.get(self.device.index, 0.0)
         self.fallbacks = 0         # time-outs recovered so far
 
     def _set_saturation(self, cp, S):
@@ -465,7 +495,10 @@ class Trajectories:
 
     def _snapshot(self):
         """Everything a repeat of the coming steps needs: the state arrays (one device-to-device copy each), the
-        step counter and, in replay mode, the host generator's state."""
+        step counter and, in replay mode, the host generator's state.  Without an explicit generator that is torch's
+        GLOBAL CPU generator (what the reference consumes): a recovery rewinds it to this point, so draws other code
+        made from it between the run call and the check are replayed as well -- pass ``NoiseSpec.generator`` to keep
+        the run's stream private."""
         gen = self.feeder.spec.generator
         rng = None
         if self.feeder.spec.mode == "replay":
@@ -521,6 +554,9 @@ class Trajectories:
             self._status.zero_()
         self.no_exchange = True
         self.fallbacks += 1
+        with _cache_lock:
+            _exchange_blocked_until[self.device.index] = time.monotonic() + float(
+                os.environ.get("CCVM_AMD_EXCHANGE_COOLDOWN", "30"))
         warnings.warn(
             f"ccvm_{self.kind}_run: a persistent kernel timed out waiting for its workgroups (is another process "
             f"using this GPU?); steps {snap['step']}..{reached} are repeated on the per-step tile kernel",

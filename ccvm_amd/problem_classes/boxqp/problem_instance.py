@@ -119,8 +119,12 @@ class ProblemInstance:
             self.file_delimiter = file_delimiter
         path, delim = self.file_path, self.file_delimiter
 
+        # opening the file is outside the guarded block, as in the reference (problem_instance.py:154):
+        # a missing file raises FileNotFoundError (its test_problem_instance.py:78-86), only the
+        # parsing errors are re-raised as "Error reading instance file"
+        stream = open(path, "r")
         try:
-            with open(path, "r") as stream:
+            with stream:
                 lines = stream.readlines()
             header = _split(lines[0], delim)
             n = int(header[0])

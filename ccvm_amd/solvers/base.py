@@ -28,6 +28,13 @@ from .algorithms import AdamParameters
 _SAMPLE_RING_BYTES = 256 * 1024 * 1024
 
 
+def builtin_hook(fn):
+    """Marks a ``_<hook>_boxqp`` method as this package's implementation of the hook (see
+    ``CCVMSolver._is_builtin``)."""
+    fn._ccvm_builtin = True
+    return fn
+
+
 class DeviceType(enum.Enum):
     CPU_DEVICE = "cpu"
     CUDA_DEVICE = "cuda"
@@ -137,25 +144,55 @@ class CCVMSolver(ABC):
         self.fit_to_constraints = self._fit_to_constraints_boxqp
 
     # ------------------------------------------------------------------ #
-    # hooks: kept as overridable attributes for API compatibility
+    # hooks: overridable attributes, honoured wherever the reference calls them
     # ------------------------------------------------------------------ #
-    def _fused_hooks_intact(self):
-        """True while drift/grads are the built-ins (which live inside the HIP kernels)."""
-        return (
-            getattr(self.calculate_drift, "__func__", None) is type(self)._calculate_drift_boxqp
-            and getattr(self.calculate_grads, "__func__", None) is type(self)._calculate_grads_boxqp
-        )
+    #: hooks the time loop calls, by variant (False: _solve, True: _solve_adam); set by subclasses from the
+    #: reference's call sites (solvers/composed.py lists them).  A replaced hook that is NOT in the selected
+    #: loop's tuple is never looked at, as in the reference (mf_solver.py:561-572 calls calculate_drift only,
+    #: :709-716 calculate_grads only).
+    _LOOP_HOOKS = {False: (), True: ()}
 
-    def _require_fused_hooks(self):
-        if not self._fused_hooks_intact():
-            raise NotImplementedError(
-                "calculate_drift / calculate_grads were replaced on this solver; the HIP engine fuses"
-                " the built-in BoxQP drift into its step kernel and cannot call Python hooks"
-            )
+    def _is_builtin(self, name):
+        """True while hook ``name`` is this package's own implementation bound to this solver (the one the
+        fused kernels contain).  An attribute assigned by the caller, or a subclass override of
+        ``_<name>_boxqp``, is a replaced hook."""
+        fn = getattr(self, name, None)
+        return getattr(fn, "__self__", None) is self and getattr(fn.__func__, "_ccvm_builtin", False)
 
+    def _replaced_on_path(self, adam):
+        """Names of the hooks the selected loop calls that are not the built-ins."""
+        return [name for name in self._LOOP_HOOKS[bool(adam)] if not self._is_builtin(name)]
+
+    def _call_hook(self, name, *args):
+        """Call hook ``name`` from the composed per-step path.  A built-in takes its tensors where they are (the
+        GPU) and leaves its result there; a replaced hook gets every tensor argument on the solver's ``device``
+        -- where the caller's own tensors live, as in the reference -- and its result is brought back."""
+        fn = getattr(self, name)
+        if self._is_builtin(name):
+            return fn(*args)
+        gpu = engine.gpu_device()
+        out = fn(*[a.to(self.device) if torch.is_tensor(a) else a for a in args])
+        back = lambda t: t.to(device=gpu, dtype=torch.float32) if torch.is_tensor(t) else t
+        return tuple(back(o) for o in out) if isinstance(out, (tuple, list)) else back(out)
+
+    def _composed_path(self, adam):
+        """The hooks that force the composed per-step path (solvers/composed.py) for this call, after
+        warning about it; empty: the fused kernels run."""
+        replaced = self._replaced_on_path(adam)
+        if replaced:
+            import warnings
+
+            warnings.warn(
+                f"{type(self).__name__}: {', '.join(replaced)} replaced on this solver; the fused HIP kernels "
+                "contain the built-in BoxQP hooks, so this call runs the composed per-step path (Python loop, "
+                "hooks called per step): correct but orders of magnitude slower", RuntimeWarning, stacklevel=3)
+        return replaced
+
+    @builtin_hook
     def _change_variables_boxqp(self, problem_variables, lower_limit=0, upper_limit=1, S=1):
         return engine.change_variables(problem_variables, S, lower_limit, upper_limit)
 
+    @builtin_hook
     def _fit_to_constraints_boxqp(self, c=None, lower_clamp=None, upper_clamp=None, **kwargs):
         # the reference names the first argument after the solver's state (mf_solver.py:252: mu_tilde);
         # its own tests call it by keyword
@@ -226,7 +263,7 @@ class CCVMSolver(ABC):
         return S
 
     def _new_trajectories(self, kind, batch_size, iterations, params, adam=None):
-        self._require_fused_hooks()
+        assert not self._replaced_on_path(adam), "the fused kernels contain the built-in hooks"
         problem = engine.device_problem(self.q_matrix, self.v_vector)
         noise = engine.default_noise(self.noise_mode, row_offset=self.row_offset, seed=self.noise_seed,
                                      global_batch=self.replay_global_batch)
@@ -250,10 +287,7 @@ class CCVMSolver(ABC):
         one hop per hook)."""
         from ..problem_classes.boxqp.problem_instance import ProblemInstance
 
-        hooks = (
-            getattr(self.change_variables, "__func__", None) is type(self)._change_variables_boxqp
-            and getattr(self.fit_to_constraints, "__func__", None) is type(self)._fit_to_constraints_boxqp
-        )
+        hooks = self._is_builtin("change_variables") and self._is_builtin("fit_to_constraints")
         energy = (
             isinstance(instance, ProblemInstance)
             and type(instance).compute_energy is ProblemInstance.compute_energy
@@ -285,6 +319,7 @@ class CCVMSolver(ABC):
         ``self.<name>_sample[:, :, k]`` at the reference's sample points."""
         if not evolution_step_size:
             traj.advance(iterations)
+            traj.check()  # verify (or recover: see Trajectories.check) BEFORE anything reads or clamps the state
             return
         # Samples are collected in a device-side ring (<= _SAMPLE_RING_BYTES per sampled array, (depth, B, N): a
         # strided device copy per sample point, no synchronisation) and flushed to the host buffers the reference
@@ -317,6 +352,7 @@ class CCVMSolver(ABC):
                     getattr(self, f"{name}_sample")[:, :, first + base:first + k] = host.permute(1, 2, 0)
                 base = k
         traj.advance(iterations - traj.step)
+        traj.check()
 
     def _begin_sampling(self, instance, batch_size, problem_size, iterations, evolution_step_size,
                         evolution_file):
@@ -423,8 +459,11 @@ class CCVMSolver(ABC):
     def _timer_stop(self, start, batch_size):
         """Per-instance solve time (dl_solver.py:933) -- with the device sync the
         reference forgets."""
+        if getattr(self, "_traj", None) is not None:
+            # a kernel-side failure of the run (status word) is recovered or raised here at the latest, inside the
+            # timed region: the steps a recovery repeats are part of the solve (the loops already verified
+            # before they clamped / copied the state, `_advance_with_samples`)
+            self._traj.check()
         self._sync()
         elapsed = time.time() - start
-        if getattr(self, "_traj", None) is not None:
-            self._traj.check()  # a kernel-side failure of the run (status word) raises here
         return elapsed / batch_size

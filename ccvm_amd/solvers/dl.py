@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from .. import engine
-from .base import CCVMSolver
+from . import composed
+from .base import CCVMSolver, builtin_hook
 
 DL_SCALING_MULTIPLIER = 0.2
 
@@ -27,6 +28,7 @@ DL_SCALING_MULTIPLIER = 0.2
 class DLSolver(CCVMSolver):
     _PARAMETER_KEYS = frozenset(["pump", "dt", "iterations", "noise_ratio", "feedback_scale"])
     _SAMPLED = ("c", "s")
+    _LOOP_HOOKS = {False: ("calculate_drift",), True: ("calculate_grads",)}  # dl_solver.py:529, :695
 
     def __init__(self, device, problem_category="boxqp", batch_size=1000, S=1):
         super().__init__(device)
@@ -35,7 +37,8 @@ class DLSolver(CCVMSolver):
         self._scaling_multiplier = DL_SCALING_MULTIPLIER
         self._method_selector(problem_category)
 
-    # ---- compatibility hooks (not used by the fused loop) ------------------------- #
+    # ---- the built-in hooks (the fused kernels contain them; the composed path calls them) ---- #
+    @builtin_hook
     def _calculate_grads_boxqp(self, c, s, lower_limit=0, upper_limit=1, S=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
         kw = dict(in_scale=ul, in_shift=up, f_q=-0.25 * ul, f_v=-ul / 2)
@@ -44,6 +47,7 @@ class DLSolver(CCVMSolver):
             engine.saturated_feedback(s, self.q_matrix, self.v_vector, S, **kw),
         )
 
+    @builtin_hook
     def _calculate_drift_boxqp(
         self, c, s, pump, rate, feedback_scale=100, lower_limit=0, upper_limit=1, S=1
     ):
@@ -78,8 +82,16 @@ class DLSolver(CCVMSolver):
             pump=pump, dt=dt, noise_ratio=noise_ratio, feedback_scale=feedback_scale, g=g,
             pump_rate_flag=pump_rate_flag,
         )
+        if self._composed_path(adam=False):  # calculate_drift was replaced: the hook is called per step
+            c, s = composed.dl_loop(
+                self, problem_size, batch_size, S, pump, dt, iterations, noise_ratio, feedback_scale,
+                pump_rate_flag, g, composed.Sampler(self, iterations, evolution_step_size, samples_taken))
+            return c.to(self.device), s.to(self.device)
         traj = self._new_trajectories("dl", batch_size, iterations, params)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
+        if not self._is_builtin("fit_to_constraints"):  # dl_solver.py:567 through the caller's hook
+            self._traj = None  # the scored state is whatever the hook returns, not the device arrays
+            return self.fit_to_constraints(self._to_caller(traj, "c"), -S, S), self._to_caller(traj, "s")
         traj.clamp("c", -S, S)  # dl_solver.py:567 -- fit_to_constraints with self.S
         return self._to_caller(traj, "c"), self._to_caller(traj, "s")
 

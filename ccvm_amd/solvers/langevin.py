@@ -14,7 +14,8 @@ where G' = G, or its Adam-preconditioned value in the ``_solve_adam`` variants
 (langevin_solver.py:519-540).  Both score (c + S)/(2S).
 """
 from .. import engine
-from .base import CCVMSolver
+from . import composed
+from .base import CCVMSolver, builtin_hook
 
 LANGEVIN_SCALING_MULTIPLIER = 0.05
 
@@ -22,6 +23,8 @@ LANGEVIN_SCALING_MULTIPLIER = 0.05
 class _LangevinFamily(CCVMSolver):
     _SAMPLED = ("c",)
     _USE_PUMP = False
+    # langevin_solver.py:412 + :423, :515 + :549; pumped_langevin_solver.py:287 + :297, :397 + :437
+    _LOOP_HOOKS = {False: ("calculate_drift", "fit_to_constraints"), True: ("calculate_grads", "fit_to_constraints")}
 
     def __init__(self, device, problem_category="boxqp", batch_size=1000):
         super().__init__(device)
@@ -29,6 +32,7 @@ class _LangevinFamily(CCVMSolver):
         self._scaling_multiplier = LANGEVIN_SCALING_MULTIPLIER
         self._method_selector(problem_category)
 
+    @builtin_hook
     def _calculate_grads_boxqp(self, c, lower_limit=0, upper_limit=1, S=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
         k = ul / 2
@@ -36,12 +40,17 @@ class _LangevinFamily(CCVMSolver):
             c, self.q_matrix, self.v_vector, S, in_scale=k, in_shift=up / 2, f_q=-k, f_v=-k
         )
 
-    def _run(self, batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
+    def _run(self, problem_size, batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
              feedback_scale, evolution_step_size, samples_taken, adam):
         params = dict(
             dt=dt, sigma=sigma, feedback_scale=feedback_scale, S=S, pump=pump,
             use_pump=self._USE_PUMP, pump_rate_flag=pump_rate_flag,
         )
+        if self._composed_path(adam):  # a hook this loop calls was replaced: called per step, from Python
+            c = composed.langevin_loop(
+                self, problem_size, batch_size, S, pump, dt, iterations, sigma, pump_rate_flag, feedback_scale,
+                self._USE_PUMP, adam, composed.Sampler(self, iterations, evolution_step_size, samples_taken))
+            return c.to(self.device)
         traj = self._new_trajectories("langevin", batch_size, iterations, params, adam=adam)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
         return self._to_caller(traj, "c")
@@ -67,6 +76,7 @@ class _LangevinFamily(CCVMSolver):
 class LangevinSolver(_LangevinFamily):
     _PARAMETER_KEYS = frozenset(["dt", "S", "iterations", "sigma", "feedback_scale"])
 
+    @builtin_hook
     def _calculate_drift_boxqp(self, c, lower_limit=0, upper_limit=1, S=1):
         return self._calculate_grads_boxqp(c, lower_limit, upper_limit, S)
 
@@ -83,7 +93,7 @@ class LangevinSolver(_LangevinFamily):
         evolution_step_size,
         samples_taken,
     ):
-        return self._run(batch_size, device, S, 0.0, dt, iterations, sigma, False, feedback_scale,
+        return self._run(problem_size, batch_size, device, S, 0.0, dt, iterations, sigma, False, feedback_scale,
                          evolution_step_size, samples_taken, None)
 
     def _solve_adam(
@@ -100,7 +110,7 @@ class LangevinSolver(_LangevinFamily):
         samples_taken,
         hyperparameters,
     ):
-        return self._run(batch_size, device, S, 0.0, dt, iterations, sigma, False, feedback_scale,
+        return self._run(problem_size, batch_size, device, S, 0.0, dt, iterations, sigma, False, feedback_scale,
                          evolution_step_size, samples_taken, hyperparameters)
 
     def __call__(
@@ -136,6 +146,7 @@ class PumpedLangevinSolver(_LangevinFamily):
     _PARAMETER_KEYS = frozenset(["pump", "dt", "S", "iterations", "sigma", "feedback_scale"])
     _USE_PUMP = True
 
+    @builtin_hook
     def _calculate_drift_boxqp(self, c, p, S, feedback_scale):
         lo, hi = self.solution_bounds
         return (-1 + p - c * c) * c + feedback_scale * self._calculate_grads_boxqp(c, lo, hi, S)
@@ -155,7 +166,7 @@ class PumpedLangevinSolver(_LangevinFamily):
         evolution_step_size,
         samples_taken,
     ):
-        return self._run(batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
+        return self._run(problem_size, batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
                          feedback_scale, evolution_step_size, samples_taken, None)
 
     def _solve_adam(
@@ -174,7 +185,7 @@ class PumpedLangevinSolver(_LangevinFamily):
         samples_taken,
         hyperparameters,
     ):
-        return self._run(batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
+        return self._run(problem_size, batch_size, device, S, pump, dt, iterations, sigma, pump_rate_flag,
                          feedback_scale, evolution_step_size, samples_taken, hyperparameters)
 
     def __call__(

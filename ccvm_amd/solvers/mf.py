@@ -17,7 +17,8 @@ API: reference ``ccvm_simulators/solvers/mf_solver.py`` -- constructor :20-25,
 the last update (:591-593), a reference quirk that is reproduced.
 """
 from .. import engine
-from .base import CCVMSolver
+from . import composed
+from .base import CCVMSolver, builtin_hook
 
 MF_SCALING_MULTIPLIER = 0.05
 
@@ -26,6 +27,8 @@ class MFSolver(CCVMSolver):
     _PARAMETER_KEYS = frozenset(["pump", "feedback_scale", "j", "S", "dt", "iterations"])
     _SAMPLED = ("mu", "sigma")
     _TRAILING_TAB = False
+    # mf_solver.py:554 + :561 (_solve), :703 + :709 (_solve_adam)
+    _LOOP_HOOKS = {False: ("fit_to_constraints", "calculate_drift"), True: ("fit_to_constraints", "calculate_grads")}
 
     def __init__(self, device, problem_category="boxqp", batch_size=1000):
         super().__init__(device)
@@ -33,7 +36,8 @@ class MFSolver(CCVMSolver):
         self._scaling_multiplier = MF_SCALING_MULTIPLIER
         self._method_selector(problem_category)
 
-    # ---- compatibility hooks (not used by the fused loop) ------------------------- #
+    # ---- the built-in hooks (the fused kernels contain them; the composed path calls them) ---- #
+    @builtin_hook
     def _calculate_grads_boxqp(self, mu_tilde, S, fs, lower_limit=0, upper_limit=1):
         ul, up = upper_limit - lower_limit, upper_limit + lower_limit
         return engine.saturated_feedback(
@@ -41,6 +45,7 @@ class MFSolver(CCVMSolver):
             in_scale=ul, in_shift=up, f_q=-fs * 0.25 * ul, f_v=-fs * ul / 2,
         )
 
+    @builtin_hook
     def _calculate_drift_boxqp(
         self, mu, mu_tilde, sigma, pump, j, g, S, fs, lower_limit=0, upper_limit=1
     ):
@@ -63,6 +68,11 @@ class MFSolver(CCVMSolver):
             pump=pump, dt=dt, j=j, feedback_scale=feedback_scale, g=g, S=S,
             pump_rate_flag=pump_rate_flag,
         )
+        if self._composed_path(adam):  # a hook this loop calls was replaced: called per step, from Python
+            out = composed.mf_loop(
+                self, problem_size, batch_size, S, pump, dt, iterations, j, feedback_scale, pump_rate_flag, g,
+                adam, composed.Sampler(self, iterations, evolution_step_size, samples_taken))
+            return tuple(t.to(self.device) for t in out)
         traj = self._new_trajectories("mf", batch_size, iterations, params, adam=adam)
         self._advance_with_samples(traj, iterations, evolution_step_size, samples_taken)
         return tuple(self._to_caller(traj, name) for name in ("mu", "mu_tilde", "sigma"))

@@ -127,5 +127,33 @@ for (ref_cls, our_cls), key in zip(((RDL, ODL), (RMF, OMF), (RL, OL), (RPL, OPL)
     report(f"{ref_cls.__name__}: setter, constructor and call-time errors", res[0] == res[1],
            "" if res[0] == res[1] else f"\n  ref {res[0]}\n  our {res[1]}")
 
+# a missing instance file: the same exception TYPE (the reference opens the file outside its try block,
+# problem_instance.py:154; its test_problem_instance.py:78-86 asserts FileNotFoundError)
+res = [outcome(lambda c=c: c(instance_type="test", file_path="/test_instances/invalid.in", device="cpu"))[0]
+       for c in (RefInstance, OurInstance)]
+report("missing instance file", res[0] == res[1] == "FileNotFoundError", f"({res})")
+
+# which hooks each loop CALLS: read off the reference's source (the `self.<hook>(` call sites inside _solve /
+# _solve_adam) against the table this package consults to decide whether a replaced hook matters
+# (CCVMSolver._LOOP_HOOKS).  A hook outside the tuple is never looked at, one inside forces the composed path.
+import inspect  # noqa: E402
+
+for ref_cls, our_cls in ((RDL, ODL), (RMF, OMF), (RL, OL), (RPL, OPL)):
+    for adam, fn in ((False, "_solve"), (True, "_solve_adam")):
+        called = set(re.findall(r"self\.(calculate_drift|calculate_grads|fit_to_constraints)\(",
+                                inspect.getsource(getattr(ref_cls, fn))))
+        ours = set(our_cls._LOOP_HOOKS[adam])
+        if ref_cls is RDL:  # DL calls fit_to_constraints once AFTER the loop (dl_solver.py:567): honoured by
+            called.discard("fit_to_constraints")  # DLSolver._solve on the fused path too, not a loop hook
+        report(f"{ref_cls.__name__}.{fn}: hooks on the loop's path", called == ours, f"(ref {called}, our {ours})")
+
+# a (1, N) row vector as V (the reference's test_mf_solver.py:255): the reference only broadcasts V, so it
+# works there; here the staging accepts any tensor of N values (engine.DeviceProblem) -- host-side part of that
+# contract: the shape check itself
+import ccvm_amd.engine as our_engine  # noqa: E402
+
+src = inspect.getsource(our_engine.DeviceProblem.__init__)
+report("DeviceProblem takes V by element count", "v_vector.numel() != self.n" in src and "reshape(-1)" in src)
+
 print("differences:", failures)
 sys.exit(1 if failures else 0)

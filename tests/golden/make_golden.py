@@ -121,6 +121,27 @@ def anchors():
     print("config 1", meta["best_objective_value"], meta["solution_performance"])
 
 
+def distribution_cases(seeds=(1234, 2345, 3456), batch=1000, iterations=1500):
+    """Distributional anchors for the FUSED noise mode ("success fractions / best objective
+    within sampling error"): the reference draws Normal.sample per step (dl_solver.py:538-547), the engine's default
+    generates its normals in the kernel, so the two can only agree in distribution.  For every solver the shipped
+    example configuration on tuningH020-100-0 (the example scripts' instance; seed 1234 of DL is the SURVEY 8c
+    anchor: 130.7142 @ 0.987): the objective value of every one of 3 x 1000 trajectories, nothing else."""
+    store, manifest = {}, {"cases": {}, "made_with": made_with(), "instance": INSTANCES["tuningH020"]}
+    for kind in SOLVERS:
+        for seed in seeds:
+            arrays, meta = run_case(kind, INSTANCES["tuningH020"], iterations, batch=batch, seed=seed)
+            name = f"{kind}_seed{seed}"
+            store[name] = arrays["objective_values"]
+            manifest["cases"][name] = {k: meta[k] for k in ("kind", "iterations", "batch", "seed", "params",
+                                                            "best_objective_value", "solution_performance",
+                                                            "scaled_by")}
+            print("distribution", name, meta["best_objective_value"], meta["solution_performance"]["optimal"])
+    np.savez_compressed(os.path.join(OUT, "distribution_anchors.npz"), **store)
+    with open(os.path.join(OUT, "distribution_anchors.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 def bounds_cases():
     """Non-default solution_bounds (the affine maps (u - l), (u + l) of every drift / grads function)."""
     store, manifest = {}, {"cases": {}}
@@ -377,6 +398,9 @@ def main():
     if "--only-anchors" in sys.argv:
         anchors()
         return
+    if "--only-distribution" in sys.argv:
+        distribution_cases()
+        return
     if "--only-bounds" in sys.argv:
         bounds_cases()
         return
@@ -425,6 +449,7 @@ def main():
             json.dump(dict(manifest, made_with=manifest.get("made_with") or made_with()), fh, indent=1, sort_keys=True)
 
     anchors()
+    distribution_cases()
     bounds_cases()
     vector_s_cases()
     full_s_cases()

@@ -16,7 +16,8 @@ if ROOT not in sys.path:
 STUB = textwrap.dedent("""
     import json, os, sys, time
     out = sys.argv[1]
-    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+            "HSA_ENABLE_IPC_MODE_LEGACY")
     with open(os.path.join(out, "rank%s.json" % os.environ["RANK"]), "w") as fh:
         json.dump({k: os.environ.get(k) for k in keys} | {"argv": sys.argv[2:]}, fh)
     mode = sys.argv[2]
@@ -46,6 +47,8 @@ def test_launcher_wires_the_distributed_environment(stub, capsys):
     assert all(s["WORLD_SIZE"] == "3" and s["LOCAL_WORLD_SIZE"] == "3" and s["MASTER_ADDR"] == "127.0.0.1" for s in seen)
     assert len({s["MASTER_PORT"] for s in seen}) == 1 and int(seen[0]["MASTER_PORT"]) > 0
     assert all(s["argv"] == ["ok", "--steps", "5"] for s in seen)
+    # dmabuf IPC for RCCL's intra-node transports on this pool (bench.IPC_ENV); an explicit caller value wins
+    assert all(s["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") for s in seen)
     assert capsys.readouterr().out.strip() == ""  # nothing but the ranks' own output on success
 
 
@@ -82,3 +85,15 @@ def test_gpu_count_without_the_hip_runtime(monkeypatch):
     src = open(os.path.join(ROOT, "bench.py")).read()
     launcher = src[src.index("def launch_ranks"):src.index("def profiled_counters")]
     assert "torch.cuda" not in launcher  # the launcher never asks the HIP runtime anything
+
+
+def test_strong_scaling_shards_cover_the_batch_and_are_never_empty():
+    """--global-batch G over N ranks: G // N rows each, the first G % N ranks one more (ceil-sized shards left
+    trailing ranks empty or negative, e.g. 9 rows on 8 ranks: ADVICE r3)."""
+    import bench
+
+    for total, world in ((9, 8), (8000, 8), (4096, 8), (4096, 3), (7, 7), (1000, 1), (13, 4)):
+        shards = [bench.shard_rows(total, world, r) for r in range(world)]
+        assert shards[0][0] == 0 and sum(n for _, n in shards) == total
+        assert all(n >= 1 for _, n in shards) and max(n for _, n in shards) - min(n for _, n in shards) <= 1
+        assert all(shards[r][0] + shards[r][1] == shards[r + 1][0] for r in range(world - 1))

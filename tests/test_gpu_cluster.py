@@ -270,6 +270,40 @@ def test_time_out_recovery_in_replay_mode_and_under_sampling(monkeypatch, tmp_pa
     assert torch.equal(got_samples, want_samples)
 
 
+@pytest.mark.parametrize("kind", ["dl", "mf", "langevin"])
+def test_time_out_recovery_before_the_state_is_clamped_or_copied(monkeypatch, kind):
+    """the solvers verify (and recover) BEFORE they clamp the state or hand copies to the caller.  The
+    fault through the public API with device="cpu" and NO evolution sampling: DL's c is clamped after the recovery
+    (dl_solver.py:567), and the host copies of every variable are those of the repeated steps -- everything equals
+    the `nocluster` run bit for bit."""
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, synthetic_instance
+
+    def solve():
+        cls = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver}[kind]
+        solver = cls(device="cpu", batch_size=64)
+        solver.noise_seed = 77
+        inst = synthetic_instance(300)
+        inst.optimal_sol = 1.0
+        solver.parameter_key = {300: dict(EXAMPLE_PARAMS[kind], iterations=40)}
+        inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+        return solver(instance=inst)
+
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "nocluster")
+    want = solve()
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
+        got = solve()
+    assert set(got.variables) == set(want.variables)
+    for name in want.variables:
+        assert got.variables[name].device.type == "cpu"
+        assert torch.equal(got.variables[name], want.variables[name]), name
+    assert torch.equal(got.objective_values, want.objective_values)
+    if kind == "dl":  # most amplitudes end ON the clamp: an unclamped c after a recovery would show here
+        assert float(got.variables["problem_variables"].abs().max()) <= 1.0
+
+
 @pytest.mark.parametrize("kind,adam,n", [("langevin", None, 500), ("mf", "second_moment", 500), ("dl", None, 500),
                                          ("langevin", None, 768), ("dl", None, 640), ("pl", None, 700)])
 def test_cluster_soak_is_deterministic(cluster, kind, adam, n):

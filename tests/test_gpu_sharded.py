@@ -41,6 +41,8 @@ def _unsharded(kind, n, batch):
 ])
 def test_sharded_engine_equals_unsharded(tmp_path, backend, world, kind, n, batch):
     port, out = str(_free_port()), str(tmp_path / "sharded.pt")
+    # dmabuf IPC (the host driver of this pool supports nothing else: RCCL's set-up fails with "hipIpcGetMemHandle:
+    # invalid argument" under the legacy mode); bench.py's launcher and ranks set the same (bench.IPC_ENV)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_gpu_worker.py"), backend, str(r),
                                str(world), port, kind, str(n), str(batch), out], env=env,
@@ -54,3 +56,35 @@ def test_sharded_engine_equals_unsharded(tmp_path, backend, world, kind, n, batc
     assert torch.equal(got["objective_values"], ref.objective_values.cpu())
     assert torch.equal(got["problem_variables"], ref.variables["problem_variables"].cpu())
     assert got["best"] == ref.best_objective_value
+
+
+@pytest.mark.parametrize("extra,scaling", [([], "weak"), (["--global-batch", "4096"], "strong"),
+                                           (["--workload", "pl_n2000_b512", "--post", "adam", "--global-batch", "1025"],
+                                            "strong")])
+def test_bench_multi_rank_line(extra, scaling):
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` exactly as the driver runs it, the two ranks sharing the
+    one GPU of the box (CCVM_BENCH_SHARE_GPU=1: collectives over gloo): the launcher starts its ranks, rank 0
+    prints ONE JSON line with the contract's fields, both ranks were seen by the all-gather, and the timed region
+    holds no collective (per-rank times are reported, the job's time is their maximum)."""
+    import json
+
+    env = dict(os.environ, CCVM_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "20",
+                          "--warmup", "5", "--spinup-ms", "20", *extra], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["scaling"] == scaling and line["unit"] == "row-steps/s" and line["higher_is_better"] is True
+    assert line["value"] > 0 and line["value"] == pytest.approx(
+        20 * line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3 * 20), rel=1e-6)
+    per_rank = line["ms_per_step_per_rank"]
+    assert len(per_rank) == 2 and line["ms_per_step"] == pytest.approx(max(per_rank))
+    assert sum(line["config"]["rows_per_rank"]) == line["config"]["global_batch"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("mfma", "latency", "issue") and 0 < roof["frac"] < 1 and roof["achieved"] > 0
+    assert line["check"]["objective_values_finite"] is True
+    assert "cpu_baseline" not in line  # rank 0 at N = 1 only

@@ -250,6 +250,34 @@ def test_slab_time_out_falls_back_to_the_tile_kernel(monkeypatch, kind, n, b, t)
     assert bool(torch.isfinite(good.compact("c")).all()) and good.fallbacks == 0
 
 
+def test_time_out_cool_down(monkeypatch):
+    """after a recovered time-out NEW trajectories on the device stay off the cluster / slab kernels for
+    $CCVM_AMD_EXCHANGE_COOLDOWN seconds instead of each paying its own ~1 s bounded wait; then they come back."""
+    import time
+
+    from ccvm_amd import engine
+
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "slab")
+    monkeypatch.setenv("CCVM_AMD_EXCHANGE_COOLDOWN", "4")
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    first = _run_engine("dl", 1000, 32, 3, None, 21, 0)
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
+        first.check()
+    t0 = time.monotonic()
+    second = _run_engine("dl", 1000, 32, 3, None, 21, 0)   # the fault is still armed, yet no exchange kernel runs
+    assert second.no_exchange and second._snap is None
+    second.check()
+    assert second.fallbacks == 0 and time.monotonic() - t0 < 1.0
+    assert torch.equal(second.compact("c"), first.compact("c"))
+    monkeypatch.delenv("CCVM_AMD_FAULT")
+    time.sleep(max(0.0, 4.2 - (time.monotonic() - t0)))
+    third = _run_engine("dl", 1000, 32, 3, None, 21, 0)
+    assert not third.no_exchange and third._snap is not None  # back on the slab kernel
+    third.check()
+    assert third.fallbacks == 0
+    engine._exchange_blocked_until.clear()
+
+
 def _state_of(traj):
     return {k: traj.compact(k).cpu() for k in traj.state}
 

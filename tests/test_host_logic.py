@@ -147,8 +147,17 @@ def test_instance_validation_and_scaling():
         ProblemInstance(solution_bounds=(1.0, 1.0))
     with pytest.raises(Exception, match="No file path specified"):
         ProblemInstance().load_instance()
-    with pytest.raises(Exception, match="Error reading instance file"):
-        ProblemInstance(file_path="/nonexistent/file.in")
+    # a missing file is FileNotFoundError, as in the reference (problem_instance.py:154 opens the file outside its
+    # try block; its test_problem_instance.py:78-86 asserts the type); a malformed one "Error reading instance file"
+    with pytest.raises(FileNotFoundError):
+        ProblemInstance(file_path="/test_instances/invalid.in")
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".in") as bad:
+        bad.write("not\ta\theader\n")
+        bad.flush()
+        with pytest.raises(Exception, match="Error reading instance file"):
+            ProblemInstance(file_path=bad.name)
     inst = ProblemInstance.from_arrays(torch.full((2, 2), 8.0), torch.tensor([4.0, 2.0]))
     inst.scale_coefs(2.0)
     inst.scale_coefs(torch.tensor(2.0))
