@@ -159,6 +159,16 @@ class CCVMSolver(ABC):
         fn = getattr(self, name, None)
         return getattr(fn, "__self__", None) is self and getattr(fn.__func__, "_ccvm_builtin", False)
 
+    def __copy__(self):
+        """A shallow copy (solve_sharded makes one per rank) whose built-in hooks are bound to the COPY: the hook
+        attributes are bound methods, and one still bound to the original would read as replaced."""
+        new = object.__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        for name in ("calculate_drift", "calculate_grads", "change_variables", "fit_to_constraints"):
+            if self._is_builtin(name):
+                setattr(new, name, getattr(new, f"_{name}_boxqp"))
+        return new
+
     def _replaced_on_path(self, adam):
         """Names of the hooks the selected loop calls that are not the built-ins."""
         return [name for name in self._LOOP_HOOKS[bool(adam)] if not self._is_builtin(name)]

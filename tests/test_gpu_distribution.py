@@ -51,9 +51,11 @@ def _engine_values(kind, params, batch):
     return np.concatenate(values), g.instance["optimal_sol"]
 
 
-def _gaps(values, optimal):
-    """Optimality gap in percent as solution.py:87-146 defines it (relative to the value found)."""
-    return (optimal - values) * 100.0 / np.abs(values)
+def _gaps(objective_values, optimal):
+    """Optimality gap in percent as solution.py:87-146 defines it: the objective values are energies of the
+    minimisation form, the value found is their negative, the gap is relative to the value found."""
+    found = -objective_values
+    return (optimal - found) * 100.0 / np.abs(found)
 
 
 @pytest.mark.parametrize("kind", ["dl", "mf", "langevin", "pl"])
@@ -80,7 +82,8 @@ def test_fused_mode_results_are_distributed_like_the_reference(kind):
     ks = stats.ks_2samp(np.round(g_got, 3), np.round(g_want, 3))
     assert ks.pvalue > 1e-3, f"{kind}: KS statistic {ks.statistic:.4f}, p = {ks.pvalue:.2e}"
     # the best value found over thousands of trajectories is the same optimum
-    assert abs(float(got.max()) - float(want.max())) <= 1e-4 * abs(float(want.max()))
+    assert abs(float(got.min()) - float(want.min())) <= 1e-4 * abs(float(want.min()))
+    assert 0.0 < float((g_want <= 5.0).mean())  # (the thresholds really discriminate: not everything outside)
 
 
 def test_dl_example_anchor_success_fraction():
@@ -94,4 +97,4 @@ def test_dl_example_anchor_success_fraction():
     p0 = anchor["solution_performance"]["optimal"]
     sigma = math.sqrt(p0 * (1 - p0) * (1 / len(got) + 1 / anchor["batch"]))
     assert abs(p - p0) <= 3 * sigma, f"engine {p:.4f} vs anchor {p0} (sigma {sigma:.4f})"
-    assert abs(float(got.max()) - anchor["best_objective_value"]) <= 1e-4 * anchor["best_objective_value"]
+    assert abs(float((-got).max()) - anchor["best_objective_value"]) <= 1e-4 * anchor["best_objective_value"]
