@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1

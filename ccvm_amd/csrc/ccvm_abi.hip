@@ -15,6 +15,7 @@
 #include "ccvm_cluster.h"
 #include "ccvm_kernels.h"
 #include "ccvm_persist_launch.h"
+#include "ccvm_ptile.h"
 #include "ccvm_schedule.h"
 #include "ccvm_slab.h"
 
@@ -97,6 +98,8 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 //                             =nocluster: neither of the two kernels whose workgroups exchange data (cluster, slab):
 //                             every size above 256 on the per-step tile kernel
 //   CCVM_AMD_KERNEL=slab      the column-slab small-batch kernel wherever it has a plan; =noslab: never
+//   CCVM_AMD_KERNEL=ptile     the persistent streamed-Q tile kernel wherever it applies (ccvm_ptile.h); =noptile: never
+//                             (=tile and =nocluster switch it off too: its workgroups wait for each other)
 //   CCVM_AMD_SLAB_CGRP=1|2|4|8, CCVM_AMD_SLAB_RG=n   force its member width (4 CGRP columns) / row groups per cluster
 //   CCVM_AMD_SLAB_DELAY=n     fetch delay of its clusters that span XCDs, x 64 cycles (timing only)
 //   CCVM_AMD_GEOMETRY=cus,xcds  plan for this chip instead of the device's
@@ -118,6 +121,7 @@ struct Tuning {
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
     int slab_delay = -1;             // >= 0: the fetch delay of clusters that span XCDs (x 64 cycles), else slab_fabric_delay
+    int ptile = CLUSTER_DEFAULT;     // persistent streamed-Q tile kernel: 1 wherever it applies, 0 never, -1: see want_ptile
     ChipGeometry chip{0, 0};  // 0: ask the device
 };
 
@@ -126,7 +130,9 @@ Tuning read_tuning() {
     if (const char* e = std::getenv("CCVM_AMD_KERNEL")) {
         t.force_tile = !std::strcmp(e, "tile");
         if (!std::strcmp(e, "cluster")) { t.cluster = 1; t.slab = 0; }
-        if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = t.slab = 0;  // no cross-workgroup kernel at all
+        if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = t.slab = t.ptile = 0;  // no cross-workgroup kernel at all
+        if (!std::strcmp(e, "ptile")) t.ptile = 1;
+        if (!std::strcmp(e, "noptile")) t.ptile = 0;
         if (!std::strcmp(e, "slab")) t.slab = 1;
         if (!std::strcmp(e, "noslab")) t.slab = 0;
     }
@@ -337,9 +343,13 @@ size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
     return 2 * (size_t)cluster_count(B, N) * cluster_rows(N) * planes * round_up(N, 128) * CL_XE;
 }
+// the persistent tile kernel's flag lines (ccvm_ptile.h): one 128-byte line of step counters per row block
+size_t ptile_flag_bytes(int B, int N) {
+    return N > CL_MAX_N ? (size_t)((B + BM - 1) / BM) * PT_FLAG_WORDS * sizeof(unsigned) : 0;
+}
 // the exchange area of a workspace serves whichever persistent path a call takes
 size_t exchange_bytes(int B, int N, int planes) {
-    return std::max(cluster_exchange_bytes(B, N, planes), slab_exchange_bytes(B, N, planes));
+    return std::max(std::max(cluster_exchange_bytes(B, N, planes), slab_exchange_bytes(B, N, planes)), ptile_flag_bytes(B, N));
 }
 // every cluster inside one XCD and all of them on the chip at once: ceil(clusters / XCDs) x members <= CUs per XCD
 bool cluster_resident_pinned(int B, int N, const ChipGeometry& chip) {
@@ -512,6 +522,55 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
     return CCVM_OK;
 }
 
+// ---- persistent streamed-Q tile kernel (ccvm_ptile.h): the 32 x 128 tile grid kept resident over a chunk --------
+// Applies where the per-step kernel would run 32 x 128 tiles (`a` = the launch plan of base_args) as ONE round of
+// workgroups that fills at least three quarters of the chip (every workgroup resident: its workgroups wait for each
+// other), DL and Langevin / pumped Langevin steps without Adam and without per-variable saturation, chunks of at
+// least two steps.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
+// 16 x 16 = 256) are such shapes.
+bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int nsteps) {
+    if (!tun.ptile || adam || vs || a.ks != 1 || a.N <= CL_MAX_N) return false;
+    const ChipGeometry chip = chip_of(tun);
+    const int grid = a.nrb * a.ncb;
+    if (grid > chip.cus || a.ncb > PT_FLAG_WORDS) return false;
+    if (tun.ptile > 0) return true;
+    return nsteps >= 2 && 4 * grid >= 3 * chip.cus;
+}
+__global__ void ptile_flags_kernel(unsigned* flags, int words, unsigned step0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) flags[i] = step0;  // every workgroup has "completed" the steps before this launch
+}
+// `area`: what follows the schedule table in the workspace ([flag lines][...][status line])
+template <int MODE>
+int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], const ccvm_noise* nz, float* table,
+              void* area, unsigned* status, int step0, int done, int k, const Tuning& tun, hipStream_t st,
+              const char* fn) {
+    PtileArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.Q = a.Q; pa.V = a.V; pa.qsum = a.qsum; pa.table = table;
+    pa.x0[0] = x0[0]; pa.x0[1] = x0[1]; pa.x1[0] = x1[0]; pa.x1[1] = x1[1];
+    pa.flags = static_cast<unsigned*>(area);
+    pa.status = status;
+    pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
+    if (pa.replay) {
+        pa.w0 = nz->w0 + (size_t)done * a.N * a.B;
+        pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * a.B : nullptr;
+    }
+    pa.B = a.B; pa.N = a.N; pa.ld = a.ld; pa.nrb = a.nrb; pa.ncb = a.ncb; pa.xr = a.xr; pa.xc = a.xc;
+    pa.par = done & 1;  // launches of a call alternate the buffers like its steps
+    pa.step0 = step0 + done; pa.nsteps = k;
+    pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+    pa.spin_limit = 1u << 19;  // ~1 us per poll
+    pa.drop = tun.cluster_drop;
+    const int words = a.nrb * PT_FLAG_WORDS;
+    hipLaunchKernelGGL(ptile_flags_kernel, dim3((words + 255) / 256), dim3(256), 0, st, pa.flags, words,
+                       (unsigned)pa.step0);
+    if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
+    else ptile_launch_lv(pa, st);
+    CCVM_CHECK_LAUNCH(fn);
+    return CCVM_OK;
+}
+
 template <int MODE, bool ADAM>
 int launch_persist(const PersistArgs& a, hipStream_t st, const char* name) {
     if constexpr (MODE == MODE_DL) persist_launch_dl(a, st);
@@ -619,6 +678,11 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
+        if (solver != 1 && want_ptile(a, tun, ad, per_variable_s && solver != 0, TABLE_STEPS)) {
+            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
+                          solver, a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
+            return CCVM_OK;
+        }
         std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
                       solver, ad ? "true" : "false", a.ks, (per_variable_s && solver != 0) ? "true" : "false",
                       a.nrb * a.ncb, WG_THREADS, a.xr, a.xc);
@@ -654,7 +718,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
                 void* stream) {
     const char* fn = "ccvm_dl_run";
     Tuning tun = read_tuning();
-    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = tun.ptile = 0;
     if (!Q || !V || !c || !s || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -762,6 +826,27 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
+    if (nsteps > 0 && want_ptile(a, tun, false, false, nsteps)) {
+        // whole chunks in one launch each, the tile grid resident, the state handed over between the workgroups of a
+        // row block inside the launch (ccvm_ptile.h)
+        char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        unsigned* status = reinterpret_cast<unsigned*>(after + table_bytes() + exchange_bytes(B, N, 2));
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
+                       step0 + done, k};
+            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
+                return rc;
+        }
+        if (nsteps & 1) {
+            if (hipMemcpyAsync(c, bufc[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(s, bufs[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
+        }
+        return CCVM_OK;
+    }
     int cur = 0;
     for (int i = step0; i < step0 + nsteps; ++i) {
         const double frac = (double)(i + 1) / (double)T;
@@ -798,7 +883,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
                 const ccvm_noise* nz, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_mf_run";
     Tuning tun = read_tuning();
-    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = tun.ptile = 0;
     if (!Q || !V || !mu || !sigma || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -1055,7 +1140,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_langevin_run";
     Tuning tun = read_tuning();
-    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = 0;
+    if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = tun.ptile = 0;
     if (!Q || !V || !c || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
@@ -1212,6 +1297,24 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             CCVM_CHECK_LAUNCH(fn);
         }
         if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
+        return CCVM_OK;
+    }
+    if (want_ptile(a, tun, use_adam, s_cols != nullptr, nsteps)) {
+        // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h)
+        unsigned* status = reinterpret_cast<unsigned*>(after + table_bytes() + exchange_bytes(B, N, 1));
+        AdamSched asc;
+        std::memset(&asc, 0, sizeof(asc));
+        float* const none[2] = {nullptr, nullptr};
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
+                       step0 + done, k, asc};
+            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
+                return rc;
+        }
+        if ((nsteps & 1) && hipMemcpyAsync(c, buf[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy-back failed", fn);
         return CCVM_OK;
     }
     if (use_adam) {

@@ -486,12 +486,12 @@ class Trajectories:
             return unpack(self.state[name], self.b, self.n)
 
     def _exchange_kernel(self):
-        """Would a run call of this shape launch a kernel whose workgroups wait for each other (column-cluster /
-        column-slab: ccvm_describe_launch under the current tuning environment)?"""
+        """Would a run call of this shape launch a kernel whose workgroups wait for each other (column-cluster,
+        column-slab, persistent tile: ccvm_describe_launch under the current tuning environment)?"""
         buf = ctypes.create_string_buffer(512)
         rc = self.lib.ccvm_describe_launch(self._SOLVER_ID[self.kind], self.b, self.n, 1 if self.adam.enabled else 0,
                                            1 if self.s_cols is not None else 0, buf, 512)
-        return rc == 0 and (b"cluster_kernel" in buf.value or b"slab_kernel" in buf.value)
+        return rc == 0 and any(k in buf.value for k in (b"cluster_kernel", b"slab_kernel", b"ptile_kernel"))
 
     def _snapshot(self):
         """Everything a repeat of the coming steps needs: the state arrays (one device-to-device copy each), the

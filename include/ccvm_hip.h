@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 7
+#define CCVM_ABI_VERSION 8  /* 8: workspaces above N = 768 carry the persistent tile kernel's flag lines */
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -64,7 +64,7 @@ typedef enum ccvm_noise_mode {
  * 2 % of a 20-step call).  Without the flag every call zeroes them itself. */
 #define CCVM_RUN_WS_PADDED 1
 /* CCVM_RUN_NO_EXCHANGE: run this call on kernels whose workgroups do not wait for each other (the per-step tile kernel,
- * or the row-owner persistent kernel for N <= 256), never on the column-cluster / column-slab persistent kernels.  What
+ * or the row-owner persistent kernel for N <= 256), never on the column-cluster / column-slab / persistent-tile kernels.  What
  * a caller sets to repeat a chunk whose status word reported a time-out (ccvm_status_offset): same noise, same
  * result up to the summation order of the contraction. */
 #define CCVM_RUN_NO_EXCHANGE 2
@@ -165,7 +165,8 @@ size_t ccvm_workspace_bytes(int solver, int B, int N);
  * of a 128-byte line whose first 4 bytes are the run's status word; (size_t)-1 for the other entries.  The caller
  * zeroes the LINE once (a fresh workspace: simplest is to zero the whole workspace) and may read the status word after
  * synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of a persistent path whose workgroups exchange data
- * (column-cluster kernel, 256 < N <= 768; column-slab kernel, small batches above N = 256) gave up because its
+ * (column-cluster kernel, 256 < N <= 768; column-slab kernel, small batches above N = 256; persistent tile kernel, full
+ * grids of 32 x 128 tiles above N = 768) gave up because its
  * workgroups could not become resident (another process holding the GPU for ~1 s) -- the state arrays are then
  * invalid: restore them and repeat the steps with CCVM_RUN_NO_EXCHANGE.  Run calls never clear the status word.  The
  * rest of the line is the library's: it records what the exchange area in front of it holds, so that a later call

@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 7
+    assert hip_lib.ccvm_abi_version() == 8
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
@@ -49,12 +49,13 @@ def test_layout_helpers_and_version(hip_lib):
     qs = 33 * 1024 * 4  # column sums of Q + 32 slice partials
     table = 4096 * 16 * 4  # schedule table of the persistent small-N path
     sync = 128  # the cluster path's launch status word (its own 128-byte line), last in the workspace
-    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table + sync
-    assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs + table + sync
-    assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == 2 * state + qs + table + sync
-    assert hip_lib.ccvm_status_offset(1, 1000, 1000) == 3 * state + qs + table
-    assert hip_lib.ccvm_status_offset(2, 1000, 1000) == 2 * state + qs + table
-    assert hip_lib.ccvm_status_offset(0, 1000, 1000) == 2 * state + qs + table
+    flags = 32 * 128  # the persistent tile kernel's flag line per row block of 32 (N > 768)
+    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == 2 * state + qs + table + flags + sync
+    assert hip_lib.ccvm_workspace_bytes(1, 1000, 1000) == 3 * state + qs + table + flags + sync
+    assert hip_lib.ccvm_workspace_bytes(2, 1000, 1000) == 2 * state + qs + table + flags + sync
+    assert hip_lib.ccvm_status_offset(1, 1000, 1000) == 3 * state + qs + table + flags
+    assert hip_lib.ccvm_status_offset(2, 1000, 1000) == 2 * state + qs + table + flags
+    assert hip_lib.ccvm_status_offset(0, 1000, 1000) == 2 * state + qs + table + flags
     assert hip_lib.ccvm_status_offset(3, 1000, 1000) == ctypes.c_size_t(-1).value
     # 256 < N <= 512: + the cluster path's two exchange buffers of 8-byte {value, tag} packets
     state5, qs5 = 1024 * 512 * 4, 33 * 512 * 4
@@ -68,8 +69,8 @@ def test_layout_helpers_and_version(hip_lib):
     assert hip_lib.ccvm_workspace_bytes(5, 1000, 1000) == qs
     assert hip_lib.ccvm_workspace_bytes(9, 1000, 1000) == 0
     # per-variable saturation: room for the row-scaled copy of Q (MF, Langevin only)
-    assert hip_lib.ccvm_workspace_bytes_cols(1, 1000, 1000) == 3 * state + qs + table + sync + 1024 * 1024 * 4
-    assert hip_lib.ccvm_workspace_bytes_cols(2, 1000, 1000) == 2 * state + qs + table + sync + 1024 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes_cols(1, 1000, 1000) == 3 * state + qs + table + flags + sync + 1024 * 1024 * 4
+    assert hip_lib.ccvm_workspace_bytes_cols(2, 1000, 1000) == 2 * state + qs + table + flags + sync + 1024 * 1024 * 4
     assert hip_lib.ccvm_workspace_bytes_cols(0, 1000, 1000) == hip_lib.ccvm_workspace_bytes(0, 1000, 1000)
 
 
@@ -90,7 +91,8 @@ def test_describe_launch_names_the_instantiation(hip_lib):
     """Host-only: which kernel a run of this shape launches (what rocprofv3 prints for it)."""
     buf = ctypes.create_string_buffer(256)
     want = {
-        (0, 1000, 1000, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 256 x 512",
+        (0, 1000, 1000, 0): "ccvm::ptile_kernel<0> grid 256 x 512 threads (32 row blocks x 8 column blocks resident",
+        (2, 1000, 1000, 1): "ccvm::step_kernel<2, true, 0, 1, false, 0> grid 256 x 512",   # no Adam variant of the persistent tile kernel
         (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> grid 500 x 256",   # K split: one row set per workgroup
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
@@ -113,7 +115,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 756 x 512",   # 3 rounds of 32 x 64 tiles < 2 of 32 x 128
         (0, 256, 1000, 0): "ccvm::step_kernel<0, false, 0, 4, false, 0> grid 256 x 512",   # 32 x 32 tiles fill the chip
         (2, 512, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 192 x 512",
-        (2, 512, 2000, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 256 x 512",
+        (2, 512, 2000, 0): "ccvm::ptile_kernel<2> grid 256 x 512 threads (16 row blocks x 16 column blocks resident",
     }
     for (solver, b, n, adam), text in want.items():
         assert hip_lib.ccvm_describe_launch(solver, b, n, adam, 0, buf, 256) == 0

@@ -1,0 +1,128 @@
+"""GPU tests of the persistent streamed-Q tile kernel (ccvm_amd/csrc/ccvm_ptile.h): the 32 x 128 tile grid kept
+resident over a chunk of steps, the new state handed over between the workgroups of a row block INSIDE the launch
+(drained write-through stores, a flag line per row block, L1-bypassing LDS-DMA loads), the own K range written straight
+from the epilogue's registers into the LDS ring.  The reference's loop being replaced: dl_solver.py:523-553.
+
+What can go wrong is visibility (a reader streaming a peer's columns before they landed, or from a stale cache line), so
+the central check is BITWISE: a chunk run as one launch must equal the same chunk run one step per launch, where the
+kernel boundary guarantees visibility and the arithmetic is the same -- on an idle chip and with another stream keeping
+the chip busy.  Then every word against the oracle, chunking and sharding; the reference's own goldens at N = 1000 run through this
+family in tests/test_gpu_thick_goldens.py (family "ptile")."""
+import pytest
+import torch
+
+from test_gpu_cluster import _run_engine
+from test_gpu_slab import _check_against_oracle, _describe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def ptile(monkeypatch):
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "ptile")
+    monkeypatch.setenv("CCVM_AMD_KS", "1")  # (forced on grids the default policy gives to the finer tile shapes too)
+
+
+def _state(traj):
+    traj.check()
+    assert traj.fallbacks == 0
+    return {k: traj.compact(k).clone() for k in traj.state}
+
+
+def test_ptile_is_the_default_for_full_grids_of_wide_tiles(monkeypatch):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    for kind, n, b in (("dl", 1000, 1000), ("pl", 2000, 512), ("langevin", 1000, 1000), ("dl", 1024, 1024),
+                       ("dl", 900, 800)):
+        assert "ptile_kernel" in _describe(kind, b, n), (kind, n, b, _describe(kind, b, n))
+    # not: Adam variants, MF, grids of several rounds or of less than three quarters of the chip, the cluster sizes
+    for kind, n, b, adam in (("langevin", 1000, 1000, True), ("mf", 1000, 1000, False), ("dl", 1000, 2000, False),
+                             ("dl", 1000, 512, False), ("dl", 768, 1000, False), ("dl", 1500, 1000, False)):
+        assert "ptile_kernel" not in _describe(kind, b, n, adam), (kind, n, b)
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
+    assert "step_kernel" in _describe("dl", 1000, 1000)
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "tile")
+    assert "step_kernel" in _describe("dl", 1000, 1000)
+
+
+@pytest.mark.parametrize("busy", [False, True])
+@pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 1000, 60), ("pl", 2000, 512, 30), ("langevin", 1000, 1000, 40),
+                                        ("dl", 1030, 777, 20), ("dl", 900, 300, 25), ("pl", 3000, 150, 8)])
+def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t, busy):
+    """The hand-over inside the launch against kernel boundaries (same kernel, same arithmetic, one step per launch):
+    any stale or early read of a peer's columns shows as a difference.  `busy`: a second stream hammers the memory
+    system and the CUs' queues meanwhile (uneven load: the case idle chips hide)."""
+    assert "ptile_kernel" in _describe(kind, b, n)
+    stepwise = _state(_run_engine(kind, n, b, t, None, 9001, 3, chunks=[1] * t))
+    noise = None
+    if busy:
+        side = torch.cuda.Stream()
+        scratch = torch.empty((64 * 1024 * 1024,), dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                scratch.mul_(1.0001)
+        noise = (side, scratch)
+    whole = _state(_run_engine(kind, n, b, t, None, 9001, 3))
+    if noise:
+        noise[0].synchronize()
+    for name in whole:
+        assert bool(torch.isfinite(whole[name]).all()), name
+        assert torch.equal(whole[name], stepwise[name]), f"{kind} N={n} B={b}: {name} differs"
+
+
+@pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 1000, 12), ("pl", 2000, 512, 8), ("langevin", 1000, 1000, 12),
+                                        ("dl", 1001, 999, 6), ("pl", 1537, 400, 6), ("dl", 800, 33, 10),
+                                        ("langevin", 4000, 64, 3)])
+def test_ptile_matches_oracle(ptile, kind, n, b, t):
+    assert "ptile_kernel" in _describe(kind, b, n)
+    _check_against_oracle(kind, n, b, t, None)
+
+
+@pytest.mark.parametrize("kind,n,b", [("dl", 1000, 1000), ("pl", 2000, 512), ("langevin", 1100, 500)])
+def test_ptile_chunking_and_sharding_are_exact(ptile, kind, n, b):
+    t = 14
+    whole = _state(_run_engine(kind, n, b, t, None, 4242, 0))
+    parts = _state(_run_engine(kind, n, b, t, None, 4242, 0, chunks=[1, 5, 2, 6]))
+    odd = _state(_run_engine(kind, n, b, t, None, 4242, 0, chunks=[3, 3, 3, 5]))
+    for name in whole:
+        assert torch.equal(whole[name], parts[name]) and torch.equal(whole[name], odd[name]), name
+    cut = 357
+    lo = _state(_run_engine(kind, n, cut, t, None, 4242, 0))
+    hi = _state(_run_engine(kind, n, b - cut, t, None, 4242, cut))
+    for name in whole:
+        assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
+
+
+def test_ptile_close_to_the_per_step_kernel_at_the_headline_shape(monkeypatch):
+    """Default policy at DL N = 1000, B = 1000 over 300 steps (five launches' worth of hand-overs per row block and
+    step): the persistent kernel against the per-step kernel -- same noise, the K order of the contraction rotated."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    a = _state(_run_engine("dl", 1000, 1000, 300, None, 77, 0))
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
+    b = _state(_run_engine("dl", 1000, 1000, 300, None, 77, 0))
+    for name in a:
+        assert not torch.equal(a[name], b[name])
+        assert float((a[name] - b[name]).abs().max()) <= 3e-4 * max(1.0, float(b[name].abs().max())), name
+
+
+def test_ptile_soak_is_deterministic(ptile):
+    """6000 steps at the headline shape twice (two launches of 4096 / 1904 steps each, ~48 000 hand-overs per
+    workgroup): finite and identical."""
+    a = _state(_run_engine("dl", 1000, 1000, 6000, None, 5, 0))
+    b = _state(_run_engine("dl", 1000, 1000, 6000, None, 5, 0, chunks=[4096, 1, 1903]))
+    for name in a:
+        assert bool(torch.isfinite(a[name]).all()) and torch.equal(a[name], b[name]), name
+
+
+def test_ptile_time_out_falls_back_to_the_per_step_kernel(monkeypatch):
+    """Fault injection (CCVM_AMD_FAULT=cluster_drop: the last 8 workgroups leave at once, so their row blocks' peers
+    never see their flags): the producer waves' bounded waits give up, the launch ENDS with the status word set, the
+    engine restores its snapshot and repeats the steps on the per-step kernel with a warning."""
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
+    want = _run_engine("dl", 1000, 1000, 5, None, 21, 0).compact("c").cpu()
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "ptile")
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    traj = _run_engine("dl", 1000, 1000, 5, None, 21, 0)
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
+        got = traj.compact("c").cpu()
+    assert traj.fallbacks == 1 and traj.no_exchange
+    assert torch.equal(got, want)

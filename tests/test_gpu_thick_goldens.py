@@ -2,7 +2,7 @@
 over 100 steps, N = 1000 at batch 64 over 50; made by make_golden.py --only-thick from the reference in the build
 container) against every kernel family of the engine, through the public API in replay mode: the column-cluster
 kernel with three clusters and a ragged last one, the slab kernel with several row groups per cluster, both tile
-shapes of the per-step kernel at the headline size."""
+shapes of the per-step kernel and the persistent tile kernel at the headline size."""
 import math
 
 import pytest
@@ -14,11 +14,11 @@ from test_gpu_parity import ATOL_OBJ, ATOL_X, _run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "cluster", "slab", "tile", "tile2"])
+@pytest.fixture(params=["auto", "cluster", "slab", "ptile", "tile", "tile2"])
 def family(request, monkeypatch):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
-    if request.param in ("cluster", "slab"):
+    if request.param in ("cluster", "slab", "ptile"):
         monkeypatch.setenv("CCVM_AMD_KERNEL", request.param)
     elif request.param != "auto":
         monkeypatch.setenv("CCVM_AMD_KERNEL", "tile")
@@ -33,6 +33,8 @@ def test_every_kernel_family_matches_the_reference_at_real_batch_sizes(tag, case
     n = g.instance["problem_size"]
     if family == "cluster" and n > 768:
         pytest.skip("the column-cluster kernel serves N <= 768")
+    if family == "ptile" and (n <= 768 or meta["kind"] == "mf" or meta["adam"]):
+        pytest.skip("the persistent tile kernel serves DL / Langevin steps above N = 768")
     check_noise_checksum(meta, n, meta["batch"])
     sol = _run_case(g, meta)
     gate = math.sqrt(max(n, 20) / 20.0)

@@ -27,8 +27,10 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "persist_kernel<2" in _describe(hip_lib, 2, 4, 256)            # N <= 256: row owners, any batch
     assert "cluster_kernel<1" in _describe(hip_lib, 1, 1000, 500)
     assert "cluster_kernel<0" in _describe(hip_lib, 0, 1000, 768) and "spread" in _describe(hip_lib, 0, 1000, 768)
-    assert "step_kernel<0" in _describe(hip_lib, 0, 1000, 1000)
-    assert "step_kernel<2" in _describe(hip_lib, 2, 512, 2000)
+    assert "ptile_kernel<0>" in _describe(hip_lib, 0, 1000, 1000)           # one full round of 32 x 128 tiles: resident
+    assert "ptile_kernel<2>" in _describe(hip_lib, 2, 512, 2000)
+    assert "step_kernel<0" in _describe(hip_lib, 0, 2000, 1000)            # two rounds: one launch per step
+    assert "step_kernel<1" in _describe(hip_lib, 1, 1000, 1000)            # MF: no persistent tile variant
     d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
     assert "slab_kernel<0, 8, 128, false>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
     assert "XCDs" not in d
@@ -134,3 +136,22 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
             d = _describe(hip_lib, solver, 8192 if solver else 4096, 16 * nch, 1 if adam else 0)
             split = int(re.search(r"persist_kernel<\d, \w+, 64, 4, \d+, 4, (\d)>", d).group(1)) == 2
             assert split == (regs[(solver, adam, nch)] > 256), (solver, adam, nch, regs[(solver, adam, nch)], d)
+
+
+def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env):
+    """ccvm_ptile.h: its workgroups wait for each other, so the grid must fit the chip the policy plans for (CU masks,
+    partitions: CCVM_AMD_GEOMETRY), fill at least three quarters of it (below that the finer tile shapes win anyway),
+    and CCVM_AMD_KERNEL=tile / nocluster / noptile switch it off."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    assert "ptile_kernel" in _describe(hip_lib, 0, 1000, 1000) and "ptile_kernel" in _describe(hip_lib, 0, 800, 900)
+    assert "ptile_kernel" not in _describe(hip_lib, 0, 1000, 1100)         # 288 tiles: more than the chip holds
+    assert "ptile_kernel" not in _describe(hip_lib, 0, 512, 1000)          # half the chip: 32 x 64 tiles
+    for off in ("tile", "nocluster", "noptile"):
+        clean_env.setenv("CCVM_AMD_KERNEL", off)
+        assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000), off
+    clean_env.delenv("CCVM_AMD_KERNEL")
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "240,8")                         # a CU-masked chip: 256 workgroups do not fit
+    assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000)
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
+    assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000)
+    assert "ptile_kernel" in _describe(hip_lib, 0, 500, 1000)              # 16 x 8 = 128 workgroups fill that chip once
