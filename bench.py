@@ -489,7 +489,7 @@ def main():
     if rank == 0:
         na = 2 if kind == "dl" else 1
         launch = describe_launch(kind, b, n)
-        persistent = any(k in launch for k in ("persist_kernel", "cluster_kernel", "slab_kernel"))
+        persistent = any(k in launch for k in ("persist_kernel", "cluster_kernel", "slab_kernel", "ptile_kernel"))
         # a persistent launch runs up to 4096 steps (the schedule table of a run call, ccvm_abi.hip: TABLE_STEPS);
         # traj.advance(steps) in fused-noise mode is ONE run call = ceil(steps / 4096) launches
         launches = -(-args.steps // 4096) if persistent else args.steps

@@ -536,10 +536,8 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int ns
     if (tun.ptile > 0) return true;
     return nsteps >= 2 && 4 * grid >= 3 * chip.cus;
 }
-__global__ void ptile_flags_kernel(unsigned* flags, int words, unsigned step0) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < words) flags[i] = step0;  // every workgroup has "completed" the steps before this launch
-}
+// blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
+int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }
 // `area`: what follows the schedule table in the workspace ([flag lines][...][status line])
 template <int MODE>
 int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], const ccvm_noise* nz, float* table,
@@ -562,9 +560,7 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
     pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
     pa.spin_limit = 1u << 19;  // ~1 us per poll
     pa.drop = tun.cluster_drop;
-    const int words = a.nrb * PT_FLAG_WORDS;
-    hipLaunchKernelGGL(ptile_flags_kernel, dim3((words + 255) / 256), dim3(256), 0, st, pa.flags, words,
-                       (unsigned)pa.step0);
+    // (the flag lines were set to step0 by this chunk's schedule kernel: ptile_sched_grid)
     if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
     else ptile_launch_lv(pa, st);
     CCVM_CHECK_LAUNCH(fn);
@@ -835,8 +831,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
-                       step0 + done, k};
-            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                       step0 + done, k, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
+            hipLaunchKernelGGL(dl_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
             if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
                 return rc;
         }
@@ -1308,8 +1304,8 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
-                       step0 + done, k, asc};
-            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                       step0 + done, k, asc, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
+            hipLaunchKernelGGL(lv_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
             if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
                 return rc;
         }

@@ -15,6 +15,7 @@ namespace ccvm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{})
 template <typename F, int... I>
@@ -122,6 +123,27 @@ __device__ __forceinline__ void dl_update(const DlScalars& k, float c, float s, 
     const float ds = __builtin_fmaf(k.a_q, qs, fbk) + k.dt * ((k.pm_s - r2) * s);
     cn = c + __builtin_fmaf(diff, n0 * k.w_c, dc);
     sn = s + __builtin_fmaf(diff, n1 * k.w_s, ds);
+}
+
+// dl_update for TWO elements at once on gfx950's packed fp32 pipe (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two
+// IEEE operations per lane and instruction at the scalar forms' issue rate): the same operations in the same order
+// per element, so the results equal dl_update's bit for bit -- 24 instructions for two elements instead of 2 x 24.
+// Only for phases where no MFMA is in flight (packed VALU next to MFMAs is an anti-lever: cdna_hip_programming.md).
+__device__ __forceinline__ void dl_update2(const DlScalars& k, f32x2 c, f32x2 s, f32x2 qc, f32x2 qs, float vj,
+                                           f32x2 n0, f32x2 n1, f32x2& cn, f32x2& sn) {
+    const f32x2 c2 = c * c, s2 = s * s;
+    const f32x2 r2 = c2 + s2;
+    const f32x2 h = r2 + 0.5f;
+    f32x2 root;
+    root.x = __builtin_amdgcn_sqrtf(h.x);
+    root.y = __builtin_amdgcn_sqrtf(h.y);
+    const f32x2 diff = k.g2 * root;
+    const float fbk1 = k.a_v * vj;
+    const f32x2 fbk = {fbk1, fbk1}, aq = {k.a_q, k.a_q};
+    const f32x2 dc = __builtin_elementwise_fma(aq, qc, fbk) + k.dt * ((k.pm_c - r2) * c);
+    const f32x2 ds = __builtin_elementwise_fma(aq, qs, fbk) + k.dt * ((k.pm_s - r2) * s);
+    cn = c + __builtin_elementwise_fma(diff, n0 * k.w_c, dc);
+    sn = s + __builtin_elementwise_fma(diff, n1 * k.w_s, ds);
 }
 
 __device__ __forceinline__ void mf_update(const MfScalars& k, float mu, float sg, float fb, float n0,

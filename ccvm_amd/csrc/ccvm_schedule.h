@@ -16,12 +16,20 @@ __device__ __forceinline__ void adam_bias(const AdamSched& ad, int i, float* row
     row[13] = (ad.enabled && ad.use_v) ? (float)(1.0 / (1.0 - pow(ad.beta2, (double)(i + 1)))) : 1.0f;
 }
 
+// `flags` / `flag_words`: the persistent tile kernel's flag lines (ccvm_ptile.h), set to step0 by the same launch
+// ("every workgroup has completed the steps before this chunk"); NULL / 0 otherwise
+__device__ __forceinline__ void init_flags(unsigned* flags, int flag_words, int step0, int it) {
+    if (flags && it < flag_words) flags[it] = (unsigned)step0;
+}
 struct DlSched {
     double pump, dt, noise_ratio, feedback_scale, g, ul, Sd;
     int pump_rate_flag, T, step0, nsteps;
+    unsigned* flags;
+    int flag_words;
 };
 __global__ void dl_schedule_kernel(const DlSched p, float* table) {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    init_flags(p.flags, p.flag_words, p.step0, it);
     if (it >= p.nsteps) return;
     const int i = p.step0 + it;
     const double frac = (double)(i + 1) / (double)p.T;
@@ -77,9 +85,12 @@ struct LvSched {
     double dt, sigma, feedback_scale, S, pump, ul;
     int use_pump, pump_rate_flag, T, step0, nsteps;
     AdamSched ad;
+    unsigned* flags;
+    int flag_words;
 };
 __global__ void lv_schedule_kernel(const LvSched p, float* table) {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    init_flags(p.flags, p.flag_words, p.step0, it);
     if (it >= p.nsteps) return;
     const int i = p.step0 + it;
     LvScalars k;

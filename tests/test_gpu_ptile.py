@@ -71,7 +71,7 @@ def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t,
 
 @pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 1000, 12), ("pl", 2000, 512, 8), ("langevin", 1000, 1000, 12),
                                         ("dl", 1001, 999, 6), ("pl", 1537, 400, 6), ("dl", 800, 290, 10),
-                                        ("langevin", 4000, 257, 3)])
+                                        ("langevin", 4000, 200, 3)])
 def test_ptile_matches_oracle(ptile, kind, n, b, t):
     assert "ptile_kernel" in _describe(kind, b, n)
     _check_against_oracle(kind, n, b, t, None)

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) h[(size_t)i * ld + j] = rnd() * 0.01f;
     CK(hipMemcpy(Q, h.data(), (size_t)ld * ld * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(V, h.data(), ld * 4, hipMemcpyHostToDevice));
-    DlSched sc{8.0, 0.001, 10.0, 100.0, 0.05, 1.0, 2.6457513, 1, 100000, 0, std::min(steps, 4096)};
+    DlSched sc{8.0, 0.001, 10.0, 100.0, 0.05, 1.0, 2.6457513, 1, 100000, 0, std::min(steps, 4096), nullptr, 0};
     hipLaunchKernelGGL(dl_schedule_kernel, dim3((sc.nsteps + 255) / 256), dim3(256), 0, 0, sc, table);
 
     PtileArgs a;
