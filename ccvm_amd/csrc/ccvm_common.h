@@ -113,6 +113,11 @@ __device__ __forceinline__ float adam_precondition(const AdamScalars& ad, float 
     return ad.add_assign ? g + upd : upd;
 }
 
+// (Round 4 tried the two quadratures of ONE element as the halves of packed fp32 instructions -- 13 instructions
+// instead of 24, same operations: neutral to 2 % slower on every kernel family in a same-box A/B, and twice as slow
+// on the 32 x 32 split-K tiles (tools/ab_build.sh, gpurun_out/r04_ab_dlupdate.txt): the pair has to be assembled in
+// adjacent registers first, and the updates of these kernels are dependent-issue chains, not instruction-count
+// bound.  Pairs of ELEMENTS whose operands already sit in adjacent registers are another matter: dl_update2.)
 __device__ __forceinline__ void dl_update(const DlScalars& k, float c, float s, float qc, float qs, float vj,
                                           float n0, float n1, float& cn, float& sn) {
     const float c2 = c * c, s2 = s * s;
