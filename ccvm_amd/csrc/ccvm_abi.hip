@@ -525,8 +525,9 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
 // ---- persistent streamed-Q tile kernel (ccvm_ptile.h): the 32 x 128 tile grid kept resident over a chunk --------
 // Applies where the per-step kernel would run 32 x 128 tiles (`a` = the launch plan of base_args) as ONE round of
 // workgroups that fills at least three quarters of the chip (every workgroup resident: its workgroups wait for each
-// other), DL and Langevin / pumped Langevin steps without Adam and without per-variable saturation, chunks of at
-// least two steps.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
+// other), DL and Langevin / pumped Langevin steps without Adam and without per-variable saturation -- chunks of any
+// length, one step included: the kernel family fixes the summation order of a column's contraction, and a run's
+// result must not depend on how the caller chunks it.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
 // 16 x 16 = 256) are such shapes.
 bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int nsteps) {
     if (!tun.ptile || adam || vs || a.ks != 1 || a.N <= CL_MAX_N) return false;
@@ -534,7 +535,8 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int ns
     const int grid = a.nrb * a.ncb;
     if (grid > chip.cus || a.ncb > PT_FLAG_WORDS) return false;
     if (tun.ptile > 0) return true;
-    return nsteps >= 2 && 4 * grid >= 3 * chip.cus;
+    (void)nsteps;
+    return 4 * grid >= 3 * chip.cus;
 }
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
 int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }

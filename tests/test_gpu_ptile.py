@@ -92,6 +92,17 @@ def test_ptile_chunking_and_sharding_are_exact(ptile, kind, n, b):
         assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
 
 
+def test_default_policy_is_chunk_invariant_at_the_headline_shape(monkeypatch):
+    """A run's result must not depend on how the caller chunks it (evolution sampling, replay-noise staging): one-step
+    chunks take the persistent kernel too (the family fixes the summation order)."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    whole = _state(_run_engine("dl", 1000, 1000, 21, None, 99, 0))
+    parts = _state(_run_engine("dl", 1000, 1000, 21, None, 99, 0, chunks=[1, 1, 6, 1, 12]))
+    for name in whole:
+        assert torch.equal(whole[name], parts[name]), name
+
+
 def test_ptile_close_to_the_per_step_kernel_at_the_headline_shape(monkeypatch):
     """Default policy at DL N = 1000, B = 1000 over 300 steps (five launches' worth of hand-overs per row block and
     step): the persistent kernel against the per-step kernel -- same noise, the K order of the contraction rotated."""
