@@ -3,7 +3,7 @@
 #   usage: tools/bench_round.sh <round tag, e.g. r03>      (then tools/collect_profiles.sh <tag>)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -18,6 +18,8 @@ def family(kernel):
         return "S"
     if "cluster_kernel" in kernel:
         return "C"
+    if "ptile_kernel" in kernel:
+        return "P"
     return "T" + re.search(r"step_kernel<\d, \w+, 0, (\d)", kernel).group(1)
 
 
@@ -55,7 +57,7 @@ def markdown(tag):
     print(f"# Round {tag[1:].lstrip('0')}: the regime map (1x MI355X, default launch policy)\n")
     print("`python3 tools/regime_map.py`: run calls of the engine (fused noise; 128-4096 steps, about 60 ms each), best of 3, "
           "no profiler.  Cell = us per step, kernel family: R row-owner persistent, S column-slab persistent, C "
-          "column-cluster persistent, T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
+          "column-cluster persistent, P persistent tile (32 x 128 tiles resident over the chunk; round 4), T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
           "table: fraction of the fp32 MFMA peak (157.3 TFLOP/s; DL 4 N^2 B flop per step, the others 2 N^2 B).\n")
     for kind in KINDS:
         print(f"## {kind}\n")
