@@ -525,12 +525,13 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
 // ---- persistent streamed-Q tile kernel (ccvm_ptile.h): the 32 x 128 tile grid kept resident over a chunk --------
 // Applies where the per-step kernel would run 32 x 128 tiles (`a` = the launch plan of base_args) as ONE round of
 // workgroups that fills at least three quarters of the chip (every workgroup resident: its workgroups wait for each
-// other), DL and Langevin / pumped Langevin steps without Adam and without per-variable saturation -- chunks of any
+// other), every solver and Adam variant, without per-variable saturation -- chunks of any
 // length, one step included: the kernel family fixes the summation order of a column's contraction, and a run's
 // result must not depend on how the caller chunks it.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
 // 16 x 16 = 256) are such shapes.
 bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int nsteps) {
-    if (!tun.ptile || adam || vs || a.ks != 1 || a.N <= CL_MAX_N) return false;
+    (void)adam;  // every solver and Adam variant has an instantiation (DL has no Adam variant at all)
+    if (!tun.ptile || vs || a.ks != 1 || a.N <= CL_MAX_N) return false;
     const ChipGeometry chip = chip_of(tun);
     const int grid = a.nrb * a.ncb;
     if (grid > chip.cus || a.ncb > PT_FLAG_WORDS) return false;
@@ -541,12 +542,25 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int ns
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
 int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }
 // `area`: what follows the schedule table in the workspace ([flag lines][...][status line])
+void persist_adam(PersistArgs& pa, AdamSched& sc, const ccvm_adam* adam, bool use_adam);
+// `par`: which of the two input buffers the launch's first step reads.  MF: `st0` / `st1` = mu / sigma, `carry` = the
+// normals of the launch's first step (mf_prepare_kernel).
 template <int MODE>
 int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], const ccvm_noise* nz, float* table,
               void* area, unsigned* status, int step0, int done, int k, const Tuning& tun, hipStream_t st,
-              const char* fn) {
+              const char* fn, int par, const ccvm_adam* adam = nullptr, float* st0 = nullptr, float* st1 = nullptr,
+              const float* carry = nullptr) {
     PtileArgs pa;
     std::memset(&pa, 0, sizeof(pa));
+    pa.st0 = st0; pa.st1 = st1; pa.carry = carry;
+    const bool use_adam = adam && adam->enabled;
+    if (use_adam) {
+        PersistArgs tmp;
+        std::memset(&tmp, 0, sizeof(tmp));
+        AdamSched unused;
+        persist_adam(tmp, unused, adam, true);
+        pa.ad = tmp.ad; pa.am = tmp.am; pa.av = tmp.av;
+    }
     pa.Q = a.Q; pa.V = a.V; pa.qsum = a.qsum; pa.table = table;
     pa.x0[0] = x0[0]; pa.x0[1] = x0[1]; pa.x1[0] = x1[0]; pa.x1[1] = x1[1];
     pa.flags = static_cast<unsigned*>(area);
@@ -557,14 +571,15 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
         pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * a.B : nullptr;
     }
     pa.B = a.B; pa.N = a.N; pa.ld = a.ld; pa.nrb = a.nrb; pa.ncb = a.ncb; pa.xr = a.xr; pa.xc = a.xc;
-    pa.par = done & 1;  // launches of a call alternate the buffers like its steps
+    pa.par = par;
     pa.step0 = step0 + done; pa.nsteps = k;
     pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
     pa.spin_limit = 1u << 19;  // ~1 us per poll
     pa.drop = tun.cluster_drop;
     // (the flag lines were set to step0 by this chunk's schedule kernel: ptile_sched_grid)
     if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
-    else ptile_launch_lv(pa, st);
+    else if constexpr (MODE == MODE_MF) ptile_launch_mf(pa, use_adam, st);
+    else ptile_launch_lv(pa, use_adam, st);
     CCVM_CHECK_LAUNCH(fn);
     return CCVM_OK;
 }
@@ -676,9 +691,9 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
-        if (solver != 1 && want_ptile(a, tun, ad, per_variable_s && solver != 0, TABLE_STEPS)) {
-            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
-                          solver, a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
+        if (want_ptile(a, tun, ad, per_variable_s && solver != 0, TABLE_STEPS)) {
+            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
+                          solver, ad ? "true" : "false", a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
             return CCVM_OK;
         }
         std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",
@@ -835,7 +850,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
             hipLaunchKernelGGL(dl_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
-            if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
+            if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn,
+                                         done & 1)))  // launches of a call alternate the buffers like its steps
                 return rc;
         }
         if (nsteps & 1) {
@@ -1075,14 +1091,6 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (!(nz->flags & CCVM_RUN_WS_PADDED) && hipMemsetAsync(ws, 0, 3 * state * sizeof(float), st) != hipSuccess)
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
-    // measured amplitude of the first step of this chunk (mf_solver.py:551-554)
-    {
-        const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(step0))) / sdt);
-        hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], carry, B, N,
-                           ld, k0, (float)S_eff, s_cols, nz->seed, nz->row_offset, step0, replay ? nz->w0 : nullptr);
-        CCVM_CHECK_LAUNCH(fn);
-    }
-
     StepArgs a;
     base_args(a, Q, V, B, N, ld, tun, 4);
     a.in_scale = (float)(ul / S_eff);
@@ -1092,6 +1100,45 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st);
         a.s_cols = s_cols;
     }
+    // measured amplitude of the first step of a chunk (mf_solver.py:551-554), and that step's normals
+    auto prepare = [&](int first_step, int done) {
+        const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(first_step))) / sdt);
+        hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], carry, B, N,
+                           ld, k0, (float)S_eff, s_cols, nz->seed, nz->row_offset, first_step,
+                           replay ? nz->w0 + (size_t)done * N * B : nullptr);
+    };
+    if (want_ptile(a, tun, use_adam, s_cols != nullptr, nsteps)) {
+        // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h): the exchanged plane is the measured
+        // amplitude; mu, sigma and the Adam moments stay in the workgroups' registers for the launch
+        char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
+        float* table = reinterpret_cast<float*>(after);
+        unsigned* status = reinterpret_cast<unsigned*>(after + table_bytes() + exchange_bytes(B, N, 1));
+        PersistArgs pa_ad;
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
+        AdamSched asc;
+        persist_adam(pa_ad, asc, adam, use_adam);
+        float* const none[2] = {nullptr, nullptr};
+        int last_k = 0;
+        for (int done = 0; done < nsteps; done += TABLE_STEPS) {
+            const int k = std::min(TABLE_STEPS, nsteps - done);
+            prepare(step0 + done, done);
+            MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc,
+                       reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
+            hipLaunchKernelGGL(mf_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
+            if ((rc = run_ptile<MODE_MF>(a, mt, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn, 0,
+                                         adam, mu, sigma, carry)))
+                return rc;
+            last_k = k;
+        }
+        // the measured amplitude fed to the LAST step (mf_solver.py:591-593): the buffer that step read
+        if (mu_tilde_out && hipMemcpyAsync(mu_tilde_out, mt[(last_k - 1) & 1], state * sizeof(float),
+                                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CCVM_E_HIP, "%s: copy of mu_tilde failed", fn);
+        return CCVM_OK;
+    }
+    prepare(step0, 0);
+    CCVM_CHECK_LAUNCH(fn);
+
     a.carry = carry;
     a.st0 = mu;
     a.st1 = sigma;
@@ -1300,15 +1347,18 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (want_ptile(a, tun, use_adam, s_cols != nullptr, nsteps)) {
         // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h)
         unsigned* status = reinterpret_cast<unsigned*>(after + table_bytes() + exchange_bytes(B, N, 1));
+        PersistArgs pa_ad;  // (the Adam schedule constants in the persistent kernels' form)
+        std::memset(&pa_ad, 0, sizeof(pa_ad));
         AdamSched asc;
-        std::memset(&asc, 0, sizeof(asc));
+        persist_adam(pa_ad, asc, adam, use_adam);
         float* const none[2] = {nullptr, nullptr};
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
             hipLaunchKernelGGL(lv_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
-            if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn)))
+            if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st,
+                                               fn, done & 1, adam)))
                 return rc;
         }
         if ((nsteps & 1) && hipMemcpyAsync(c, buf[1], state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)

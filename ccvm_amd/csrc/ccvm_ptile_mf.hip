@@ -1,0 +1,10 @@
+// Persistent streamed-Q tile kernel: MODE_MF instantiations (with and without the Adam preconditioner; see ccvm_ptile.h).
+#define CCVM_STEP_KERNEL_ONLY
+#include "ccvm_ptile.h"
+
+namespace ccvm {
+void ptile_launch_mf(const PtileArgs& a, bool adam, hipStream_t st) {
+    if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_MF, true>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((ptile_kernel<MODE_MF, false>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
+}
+}  // namespace ccvm

@@ -52,9 +52,12 @@ struct MfSched {
     double pump, dt, j, feedback_scale, g, S, ul;
     int pump_rate_flag, T, step0, nsteps;
     AdamSched ad;
+    unsigned* flags;
+    int flag_words;
 };
 __global__ void mf_schedule_kernel(const MfSched p, float* table) {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    init_flags(p.flags, p.flag_words, p.step0, it);
     if (it >= p.nsteps) return;
     const int i = p.step0 + it;
     const double sdt = sqrt(p.dt);

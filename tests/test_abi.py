@@ -91,8 +91,9 @@ def test_describe_launch_names_the_instantiation(hip_lib):
     """Host-only: which kernel a run of this shape launches (what rocprofv3 prints for it)."""
     buf = ctypes.create_string_buffer(256)
     want = {
-        (0, 1000, 1000, 0): "ccvm::ptile_kernel<0> grid 256 x 512 threads (32 row blocks x 8 column blocks resident",
-        (2, 1000, 1000, 1): "ccvm::step_kernel<2, true, 0, 1, false, 0> grid 256 x 512",   # no Adam variant of the persistent tile kernel
+        (0, 1000, 1000, 0): "ccvm::ptile_kernel<0, false> grid 256 x 512 threads (32 row blocks x 8 column blocks resident",
+        (2, 1000, 1000, 1): "ccvm::ptile_kernel<2, true> grid 256 x 512",
+        (1, 1000, 1000, 0): "ccvm::ptile_kernel<1, false> grid 256 x 512",
         (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> grid 500 x 256",   # K split: one row set per workgroup
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
@@ -115,7 +116,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 756 x 512",   # 3 rounds of 32 x 64 tiles < 2 of 32 x 128
         (0, 256, 1000, 0): "ccvm::step_kernel<0, false, 0, 4, false, 0> grid 256 x 512",   # 32 x 32 tiles fill the chip
         (2, 512, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 192 x 512",
-        (2, 512, 2000, 0): "ccvm::ptile_kernel<2> grid 256 x 512 threads (16 row blocks x 16 column blocks resident",
+        (2, 512, 2000, 0): "ccvm::ptile_kernel<2, false> grid 256 x 512 threads (16 row blocks x 16 column blocks resident",
     }
     for (solver, b, n, adam), text in want.items():
         assert hip_lib.ccvm_describe_launch(solver, b, n, adam, 0, buf, 256) == 0

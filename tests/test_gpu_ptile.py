@@ -11,7 +11,7 @@ family in tests/test_gpu_thick_goldens.py (family "ptile")."""
 import pytest
 import torch
 
-from test_gpu_cluster import _run_engine
+from test_gpu_cluster import _ADAMS, _run_engine
 from test_gpu_slab import _check_against_oracle, _describe
 
 pytestmark = pytest.mark.gpu
@@ -31,12 +31,13 @@ def _state(traj):
 
 def test_ptile_is_the_default_for_full_grids_of_wide_tiles(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
-    for kind, n, b in (("dl", 1000, 1000), ("pl", 2000, 512), ("langevin", 1000, 1000), ("dl", 1024, 1024),
-                       ("dl", 900, 800)):
-        assert "ptile_kernel" in _describe(kind, b, n), (kind, n, b, _describe(kind, b, n))
-    # not: Adam variants, MF, grids of several rounds or of less than three quarters of the chip, the cluster sizes
-    for kind, n, b, adam in (("langevin", 1000, 1000, True), ("mf", 1000, 1000, False), ("dl", 1000, 2000, False),
-                             ("dl", 1000, 512, False), ("dl", 768, 1000, False), ("dl", 1500, 1000, False)):
+    for kind, n, b, adam in (("dl", 1000, 1000, False), ("pl", 2000, 512, False), ("langevin", 1000, 1000, False),
+                             ("dl", 1024, 1024, False), ("dl", 900, 800, False), ("mf", 1000, 1000, False),
+                             ("langevin", 1000, 1000, True), ("mf", 1000, 900, True)):
+        assert "ptile_kernel" in _describe(kind, b, n, adam), (kind, n, b, _describe(kind, b, n, adam))
+    # not: grids of several rounds or of less than three quarters of the chip, the cluster kernel's sizes
+    for kind, n, b, adam in (("dl", 1000, 2000, False), ("dl", 1000, 512, False), ("dl", 768, 1000, False),
+                             ("dl", 1500, 1000, False), ("mf", 1000, 2000, True)):
         assert "ptile_kernel" not in _describe(kind, b, n, adam), (kind, n, b)
     monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
     assert "step_kernel" in _describe("dl", 1000, 1000)
@@ -45,14 +46,17 @@ def test_ptile_is_the_default_for_full_grids_of_wide_tiles(monkeypatch):
 
 
 @pytest.mark.parametrize("busy", [False, True])
-@pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 1000, 60), ("pl", 2000, 512, 30), ("langevin", 1000, 1000, 40),
-                                        ("dl", 1030, 777, 20), ("dl", 900, 300, 25), ("pl", 3000, 150, 8)])
-def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t, busy):
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("dl", 1000, 1000, 60, None), ("pl", 2000, 512, 30, None), ("langevin", 1000, 1000, 40, None),
+    ("dl", 1030, 777, 20, None), ("dl", 900, 300, 25, None), ("pl", 3000, 150, 8, None),
+    ("mf", 1000, 1000, 40, None), ("mf", 1100, 333, 20, "second_moment"), ("langevin", 1000, 1000, 30, "add_assign"),
+    ("pl", 2000, 512, 16, "first_moment_only"), ("mf", 2000, 512, 12, "add_assign")])
+def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t, adam, busy):
     """The hand-over inside the launch against kernel boundaries (same kernel, same arithmetic, one step per launch):
     any stale or early read of a peer's columns shows as a difference.  `busy`: a second stream hammers the memory
     system and the CUs' queues meanwhile (uneven load: the case idle chips hide)."""
-    assert "ptile_kernel" in _describe(kind, b, n)
-    stepwise = _state(_run_engine(kind, n, b, t, None, 9001, 3, chunks=[1] * t))
+    assert "ptile_kernel" in _describe(kind, b, n, adam is not None)
+    stepwise = _state(_run_engine(kind, n, b, t, _ADAMS[adam], 9001, 3, chunks=[1] * t))
     noise = None
     if busy:
         side = torch.cuda.Stream()
@@ -61,7 +65,7 @@ def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t,
             for _ in range(40):
                 scratch.mul_(1.0001)
         noise = (side, scratch)
-    whole = _state(_run_engine(kind, n, b, t, None, 9001, 3))
+    whole = _state(_run_engine(kind, n, b, t, _ADAMS[adam], 9001, 3))
     if noise:
         noise[0].synchronize()
     for name in whole:
@@ -69,25 +73,30 @@ def test_one_launch_equals_one_step_per_launch_bit_for_bit(ptile, kind, n, b, t,
         assert torch.equal(whole[name], stepwise[name]), f"{kind} N={n} B={b}: {name} differs"
 
 
-@pytest.mark.parametrize("kind,n,b,t", [("dl", 1000, 1000, 12), ("pl", 2000, 512, 8), ("langevin", 1000, 1000, 12),
-                                        ("dl", 1001, 999, 6), ("pl", 1537, 400, 6), ("dl", 800, 290, 10),
-                                        ("langevin", 4000, 200, 3)])
-def test_ptile_matches_oracle(ptile, kind, n, b, t):
-    assert "ptile_kernel" in _describe(kind, b, n)
-    _check_against_oracle(kind, n, b, t, None)
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("dl", 1000, 1000, 12, None), ("pl", 2000, 512, 8, None), ("langevin", 1000, 1000, 12, None),
+    ("dl", 1001, 999, 6, None), ("pl", 1537, 400, 6, None), ("dl", 800, 290, 10, None), ("langevin", 4000, 200, 3, None),
+    ("mf", 1000, 1000, 12, None), ("mf", 1001, 999, 8, "second_moment"), ("mf", 900, 290, 10, "first_moment_only"),
+    ("langevin", 1000, 1000, 10, "second_moment"), ("pl", 1537, 400, 6, "add_assign"), ("mf", 2000, 300, 5, "add_assign")])
+def test_ptile_matches_oracle(ptile, kind, n, b, t, adam):
+    assert "ptile_kernel" in _describe(kind, b, n, adam is not None)
+    _check_against_oracle(kind, n, b, t, adam)
 
 
-@pytest.mark.parametrize("kind,n,b", [("dl", 1000, 1000), ("pl", 2000, 512), ("langevin", 1100, 500)])
-def test_ptile_chunking_and_sharding_are_exact(ptile, kind, n, b):
+@pytest.mark.parametrize("kind,n,b,adam", [("dl", 1000, 1000, None), ("pl", 2000, 512, None), ("langevin", 1100, 500, None),
+                                           ("mf", 1000, 1000, None), ("mf", 1000, 1000, "second_moment"),
+                                           ("langevin", 1000, 900, "add_assign")])
+def test_ptile_chunking_and_sharding_are_exact(ptile, kind, n, b, adam):
     t = 14
-    whole = _state(_run_engine(kind, n, b, t, None, 4242, 0))
-    parts = _state(_run_engine(kind, n, b, t, None, 4242, 0, chunks=[1, 5, 2, 6]))
-    odd = _state(_run_engine(kind, n, b, t, None, 4242, 0, chunks=[3, 3, 3, 5]))
+    hp = _ADAMS[adam]
+    whole = _state(_run_engine(kind, n, b, t, hp, 4242, 0))
+    parts = _state(_run_engine(kind, n, b, t, hp, 4242, 0, chunks=[1, 5, 2, 6]))
+    odd = _state(_run_engine(kind, n, b, t, hp, 4242, 0, chunks=[3, 3, 3, 5]))
     for name in whole:
         assert torch.equal(whole[name], parts[name]) and torch.equal(whole[name], odd[name]), name
     cut = 357
-    lo = _state(_run_engine(kind, n, cut, t, None, 4242, 0))
-    hi = _state(_run_engine(kind, n, b - cut, t, None, 4242, cut))
+    lo = _state(_run_engine(kind, n, cut, t, hp, 4242, 0))
+    hi = _state(_run_engine(kind, n, b - cut, t, hp, 4242, cut))
     for name in whole:
         assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
 

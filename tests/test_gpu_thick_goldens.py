@@ -33,8 +33,8 @@ def test_every_kernel_family_matches_the_reference_at_real_batch_sizes(tag, case
     n = g.instance["problem_size"]
     if family == "cluster" and n > 768:
         pytest.skip("the column-cluster kernel serves N <= 768")
-    if family == "ptile" and (n <= 768 or meta["kind"] == "mf" or meta["adam"]):
-        pytest.skip("the persistent tile kernel serves DL / Langevin steps above N = 768")
+    if family == "ptile" and n <= 768:
+        pytest.skip("the persistent tile kernel serves sizes above N = 768")
     check_noise_checksum(meta, n, meta["batch"])
     sol = _run_case(g, meta)
     gate = math.sqrt(max(n, 20) / 20.0)

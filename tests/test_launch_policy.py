@@ -27,10 +27,10 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "persist_kernel<2" in _describe(hip_lib, 2, 4, 256)            # N <= 256: row owners, any batch
     assert "cluster_kernel<1" in _describe(hip_lib, 1, 1000, 500)
     assert "cluster_kernel<0" in _describe(hip_lib, 0, 1000, 768) and "spread" in _describe(hip_lib, 0, 1000, 768)
-    assert "ptile_kernel<0>" in _describe(hip_lib, 0, 1000, 1000)           # one full round of 32 x 128 tiles: resident
-    assert "ptile_kernel<2>" in _describe(hip_lib, 2, 512, 2000)
+    assert "ptile_kernel<0, false>" in _describe(hip_lib, 0, 1000, 1000)    # one full round of 32 x 128 tiles: resident
+    assert "ptile_kernel<2, false>" in _describe(hip_lib, 2, 512, 2000)
+    assert "ptile_kernel<1, false>" in _describe(hip_lib, 1, 1000, 1000)    # every solver
     assert "step_kernel<0" in _describe(hip_lib, 0, 2000, 1000)            # two rounds: one launch per step
-    assert "step_kernel<1" in _describe(hip_lib, 1, 1000, 1000)            # MF: no persistent tile variant
     d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
     assert "slab_kernel<0, 8, 128, false>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
     assert "XCDs" not in d

@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
         b.abl = abl;
         b.dbg = stamps ? dbg : nullptr;
         hipLaunchKernelGGL(set_words, dim3(16), dim3(256), 0, 0, flags, 4096, 0u);
-        hipLaunchKernelGGL((ptile_kernel<MODE_DL, true>), dim3(grid), dim3(WG_THREADS), 0, 0, b);
+        hipLaunchKernelGGL((ptile_kernel<MODE_DL, false, true>), dim3(grid), dim3(WG_THREADS), 0, 0, b);
     };
     auto timed = [&](int abl) {
         for (int i = 0; i < 3; ++i) run(abl, false);
