@@ -35,6 +35,11 @@ CASES = [
     ("extra_mf_n640_b1000_adam", "mf", 640, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
     ("extra_pl_n768_b1000", "pl", 768, 1000, 400, None, None, 3e-4, 1e-5),
     ("extra_dl_n700_b1000", "dl", 700, 1000, 400, None, None, 3e-4, 1e-5),
+    # the persistent tile kernel's other solvers at the headline size (round 4): MF (mu, sigma in registers, the measured
+    # amplitude handed over) and the Adam variants
+    ("extra_mf_n1000_b1000", "mf", 1000, 1000, 400, None, None, 3e-4, 1e-5),
+    ("extra_mf_n1000_b1000_adam", "mf", 1000, 1000, 200, None, ADAM_A, 3e-4, 1e-5),
+    ("extra_langevin_n1000_b1000_adam", "langevin", 1000, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
 ]
 
 
@@ -94,7 +99,14 @@ def test_long_trajectory_matches_oracle_at_baseline_shape(label, kind, n, b, t, 
         fields = ["problem_variables"]
     t_oracle = time.time() - t0
 
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    buf = ctypes.create_string_buffer(512)
+    _lib.load().ccvm_describe_launch({"dl": 0, "mf": 1}.get(kind, 2), b, n, 1 if adam else 0, 0, buf, 512)
     entry = {"case": label, "solver": kind, "N": n, "batch": b, "iterations": t, "post_processor": post,
+             "kernel": buf.value.decode().split(" grid")[0],
              "adam": bool(adam), "noise": "replay (torch CPU stream, reference order)", "fields": {},
              "oracle_s": round(t_oracle, 2), "engine_call_s": round(t_engine, 2)}
     worst_x = 0.0
