@@ -529,15 +529,41 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
 // length, one step included: the kernel family fixes the summation order of a column's contraction, and a run's
 // result must not depend on how the caller chunks it.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
 // 16 x 16 = 256) are such shapes.
+// Batches of several rounds: the rows of a batch never meet, so the batch is cut into SLICES of whole row blocks, each
+// a resident grid of its own, run one after the other over all the steps of the chunk (`slices` launches per chunk
+// instead of one per step).  Priced like choose_ks prices the per-step shapes: a resident round costs 0.91 of a
+// per-step round of 32 x 128 tiles (30.9 against 34.0 us at the headline shape); taken where that beats the
+// per-step plan (DL N = 1000: B = 2000 two slices, 67.2 -> 61.9 us per step; B = 4000 four).
+struct PtilePlan {
+    int slices = 0;  // 0: not this kernel
+    int rbs = 0;     // row blocks per slice (the last one may hold fewer)
+};
+constexpr double PTILE_ROUND_COST = 0.91;
+PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs) {
+    PtilePlan p;
+    if (!tun.ptile || vs || a.N <= CL_MAX_N) return p;
+    const ChipGeometry chip = chip_of(tun);
+    const int nrb = (a.B + BM - 1) / BM, ncb = (a.N + BN - 1) / BN;
+    if (ncb > PT_FLAG_WORDS || ncb > chip.cus) return p;
+    const int fit = chip.cus / ncb;  // row blocks one resident grid holds
+    const int slices = (nrb + fit - 1) / fit;
+    if (slices == 1) {
+        if (a.ks != 1) return p;
+        if (tun.ptile < 0 && 4 * nrb * ncb < 3 * chip.cus) return p;
+    } else if (tun.ptile < 0) {
+        static const double rel[3] = {1.0, 0.54, 0.37};  // choose_ks
+        const int tiles = a.nrb * a.ncb;
+        const double step_cost = rel[a.ks == 1 ? 0 : a.ks == 2 ? 1 : 2] * ((tiles + chip.cus - 1) / chip.cus);
+        if (PTILE_ROUND_COST * slices >= 0.97 * step_cost) return p;
+    }
+    p.slices = slices;
+    p.rbs = (nrb + slices - 1) / slices;
+    return p;
+}
 bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int nsteps) {
     (void)adam;  // every solver and Adam variant has an instantiation (DL has no Adam variant at all)
-    if (!tun.ptile || vs || a.ks != 1 || a.N <= CL_MAX_N) return false;
-    const ChipGeometry chip = chip_of(tun);
-    const int grid = a.nrb * a.ncb;
-    if (grid > chip.cus || a.ncb > PT_FLAG_WORDS) return false;
-    if (tun.ptile > 0) return true;
     (void)nsteps;
-    return 4 * grid >= 3 * chip.cus;
+    return plan_ptile(a, tun, vs).slices > 0;
 }
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
 int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }
@@ -550,37 +576,54 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
               void* area, unsigned* status, int step0, int done, int k, const Tuning& tun, hipStream_t st,
               const char* fn, int par, const ccvm_adam* adam = nullptr, float* st0 = nullptr, float* st1 = nullptr,
               const float* carry = nullptr) {
-    PtileArgs pa;
-    std::memset(&pa, 0, sizeof(pa));
-    pa.st0 = st0; pa.st1 = st1; pa.carry = carry;
+    const PtilePlan plan = plan_ptile(a, tun, false);
     const bool use_adam = adam && adam->enabled;
-    if (use_adam) {
-        PersistArgs tmp;
-        std::memset(&tmp, 0, sizeof(tmp));
-        AdamSched unused;
-        persist_adam(tmp, unused, adam, true);
-        pa.ad = tmp.ad; pa.am = tmp.am; pa.av = tmp.av;
+    const int nrb_all = (a.B + BM - 1) / BM;
+    for (int rb0 = 0; rb0 < nrb_all; rb0 += plan.rbs) {
+        // one slice of whole row blocks: rows [r0, r0 + rows), a resident grid of its own over the k steps
+        const int r0 = rb0 * BM, rows = std::min(a.B - r0, plan.rbs * BM);
+        const size_t off = (size_t)r0 * a.ld;
+        StepArgs g = a;
+        g.B = rows;
+        g.ks = 1;
+        set_grid(g, tun);
+        PtileArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.st0 = st0 ? st0 + off : nullptr;
+        pa.st1 = st1 ? st1 + off : nullptr;
+        pa.carry = carry ? carry + off : nullptr;
+        if (use_adam) {
+            PersistArgs tmp;
+            std::memset(&tmp, 0, sizeof(tmp));
+            AdamSched unused;
+            persist_adam(tmp, unused, adam, true);
+            pa.ad = tmp.ad;
+            pa.am = tmp.am ? tmp.am + off : nullptr;
+            pa.av = tmp.av ? tmp.av + off : nullptr;
+        }
+        pa.Q = a.Q; pa.V = a.V; pa.qsum = a.qsum; pa.table = table;
+        pa.x0[0] = x0[0] + off; pa.x0[1] = x0[1] + off;
+        pa.x1[0] = x1[0] ? x1[0] + off : nullptr; pa.x1[1] = x1[1] ? x1[1] + off : nullptr;
+        // (the flag lines of ALL row blocks were set to step0 by this chunk's schedule kernel: ptile_sched_grid)
+        pa.flags = static_cast<unsigned*>(area) + (size_t)rb0 * PT_FLAG_WORDS;
+        pa.status = status;
+        pa.seed = nz->seed; pa.row_offset = nz->row_offset + r0; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
+        pa.wld = a.B;
+        if (pa.replay) {
+            pa.w0 = nz->w0 + (size_t)done * a.N * a.B + r0;
+            pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * a.B + r0 : nullptr;
+        }
+        pa.B = rows; pa.N = a.N; pa.ld = a.ld; pa.nrb = g.nrb; pa.ncb = g.ncb; pa.xr = g.xr; pa.xc = g.xc;
+        pa.par = par;
+        pa.step0 = step0 + done; pa.nsteps = k;
+        pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        pa.spin_limit = 1u << 19;  // ~1 us per poll
+        pa.drop = tun.cluster_drop;
+        if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
+        else if constexpr (MODE == MODE_MF) ptile_launch_mf(pa, use_adam, st);
+        else ptile_launch_lv(pa, use_adam, st);
+        CCVM_CHECK_LAUNCH(fn);
     }
-    pa.Q = a.Q; pa.V = a.V; pa.qsum = a.qsum; pa.table = table;
-    pa.x0[0] = x0[0]; pa.x0[1] = x0[1]; pa.x1[0] = x1[0]; pa.x1[1] = x1[1];
-    pa.flags = static_cast<unsigned*>(area);
-    pa.status = status;
-    pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
-    if (pa.replay) {
-        pa.w0 = nz->w0 + (size_t)done * a.N * a.B;
-        pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * a.B : nullptr;
-    }
-    pa.B = a.B; pa.N = a.N; pa.ld = a.ld; pa.nrb = a.nrb; pa.ncb = a.ncb; pa.xr = a.xr; pa.xc = a.xc;
-    pa.par = par;
-    pa.step0 = step0 + done; pa.nsteps = k;
-    pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
-    pa.spin_limit = 1u << 19;  // ~1 us per poll
-    pa.drop = tun.cluster_drop;
-    // (the flag lines were set to step0 by this chunk's schedule kernel: ptile_sched_grid)
-    if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
-    else if constexpr (MODE == MODE_MF) ptile_launch_mf(pa, use_adam, st);
-    else ptile_launch_lv(pa, use_adam, st);
-    CCVM_CHECK_LAUNCH(fn);
     return CCVM_OK;
 }
 
@@ -691,9 +734,17 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
-        if (want_ptile(a, tun, ad, per_variable_s && solver != 0, TABLE_STEPS)) {
+        if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0); plan.slices == 1) {
             std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
                           solver, ad ? "true" : "false", a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
+            return CCVM_OK;
+        } else if (plan.slices > 1) {
+            StepArgs g = a;
+            g.B = plan.rbs * BM;
+            g.ks = 1;
+            set_grid(g, tun);
+            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> %d slices of the batch one after the other, grid %d x %d threads each (up to %d row blocks x %d column blocks resident), up to %d steps per launch",
+                          solver, ad ? "true" : "false", plan.slices, g.nrb * g.ncb, WG_THREADS, g.nrb, g.ncb, TABLE_STEPS);
             return CCVM_OK;
         }
         std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",

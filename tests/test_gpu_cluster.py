@@ -25,13 +25,19 @@ def cluster(monkeypatch):
     monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
 
 
-def _run_engine(kind, n, b, t, adam, seed, row_offset, chunks=None, replay_generator=None):
+def _run_engine(kind, n, b, t, adam, seed, row_offset, chunks=None, replay_global_batch=None):
+    """`replay_global_batch`: replay mode instead of the fused generator -- rows [row_offset, row_offset + b) of the
+    blocks a run of that many rows draws from a generator seeded with `seed`."""
     from ccvm_amd import engine
     from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
 
     q, v, _ = scaled_qv(n, kind)
     p = dict(EXAMPLE_PARAMS[kind])
-    noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=row_offset)
+    if replay_global_batch:
+        noise = engine.NoiseSpec(mode="replay", row_offset=row_offset, global_batch=replay_global_batch,
+                                 generator=torch.Generator().manual_seed(seed))
+    else:
+        noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=row_offset)
     prob = engine.DeviceProblem(q, v)
     if kind == "dl":
         traj = engine.Trajectories(prob, b, "dl", t, dict(p, g=0.05), (0.0, 1.0), noise)

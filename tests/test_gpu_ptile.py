@@ -23,6 +23,9 @@ def ptile(monkeypatch):
     monkeypatch.setenv("CCVM_AMD_KS", "1")  # (forced on grids the default policy gives to the finer tile shapes too)
 
 
+_SOLVER = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
+
+
 def _state(traj):
     traj.check()
     assert traj.fallbacks == 0
@@ -35,9 +38,14 @@ def test_ptile_is_the_default_for_full_grids_of_wide_tiles(monkeypatch):
                              ("dl", 1024, 1024, False), ("dl", 900, 800, False), ("mf", 1000, 1000, False),
                              ("langevin", 1000, 1000, True), ("mf", 1000, 900, True)):
         assert "ptile_kernel" in _describe(kind, b, n, adam), (kind, n, b, _describe(kind, b, n, adam))
-    # not: grids of several rounds or of less than three quarters of the chip, the cluster kernel's sizes
-    for kind, n, b, adam in (("dl", 1000, 2000, False), ("dl", 1000, 512, False), ("dl", 768, 1000, False),
-                             ("dl", 1500, 1000, False), ("mf", 1000, 2000, True)):
+    # batches of several rounds that cut into well-filled resident grids: slices of the batch, one after the other
+    for kind, n, b, adam, slices in (("dl", 1000, 2000, False, 2), ("dl", 1000, 4000, False, 4), ("pl", 2000, 1000, False, 2),
+                                     ("mf", 1000, 2000, True, 2), ("langevin", 1500, 2000, False, 3)):
+        assert f"ptile_kernel<{_SOLVER[kind]}, {str(adam).lower()}> {slices} slices" in _describe(kind, b, n, adam), (kind, n, b)
+    # not: grids of less than three quarters of the chip, batches whose slices would leave CUs idle (the finer
+    # per-step tile shapes cost less there), the cluster kernel's sizes
+    for kind, n, b, adam in (("dl", 1000, 1500, False), ("dl", 1000, 2500, False), ("dl", 1000, 512, False),
+                             ("dl", 768, 1000, False), ("dl", 1500, 1000, False), ("mf", 1000, 1056, True)):
         assert "ptile_kernel" not in _describe(kind, b, n, adam), (kind, n, b)
     monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
     assert "step_kernel" in _describe("dl", 1000, 1000)
@@ -99,6 +107,42 @@ def test_ptile_chunking_and_sharding_are_exact(ptile, kind, n, b, adam):
     hi = _state(_run_engine(kind, n, b - cut, t, hp, 4242, cut))
     for name in whole:
         assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
+
+
+@pytest.mark.parametrize("kind,n,b,adam,cut", [
+    ("dl", 1000, 2000, None, 1024), ("mf", 1000, 2000, "second_moment", 1024), ("pl", 2000, 1000, "add_assign", 512),
+    ("langevin", 1500, 2000, None, 672), ("dl", 1001, 2999, None, 1024), ("mf", 1000, 3000, None, 2048)])
+@pytest.mark.parametrize("replay", [False, True])
+def test_sliced_batches_are_the_rows_of_their_slices(monkeypatch, kind, n, b, adam, cut, replay):
+    """Batches of several rounds run as slices of whole row blocks, each a resident grid of its own over the whole
+    chunk (default policy).  Rows never meet, so the run must equal, bit for bit: itself one step per launch (every
+    slice handed over at kernel boundaries), and separate trajectories of the rows below and above a slice boundary
+    (fused generator: the global row index keys the stream; replay: the columns of the unsharded run's blocks)."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    assert "slices" in _describe(kind, b, n, adam is not None)
+    t, hp = 9, _ADAMS[adam]
+    gb = b if replay else None
+    whole = _state(_run_engine(kind, n, b, t, hp, 1717, 0, replay_global_batch=gb))
+    stepwise = _state(_run_engine(kind, n, b, t, hp, 1717, 0, chunks=[1] * t, replay_global_batch=gb))
+    for name in whole:
+        assert bool(torch.isfinite(whole[name]).all()), name
+        assert torch.equal(whole[name], stepwise[name]), f"{kind} N={n} B={b}: {name} differs from the stepwise run"
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "ptile")  # (the parts alone may fall to other shapes by default)
+    monkeypatch.setenv("CCVM_AMD_KS", "1")
+    lo = _state(_run_engine(kind, n, cut, t, hp, 1717, 0, replay_global_batch=gb))
+    hi = _state(_run_engine(kind, n, b - cut, t, hp, 1717, cut, replay_global_batch=gb))
+    for name in whole:
+        assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam", [("dl", 1000, 2000, 5, None), ("mf", 1000, 2000, 5, "second_moment"),
+                                             ("pl", 2000, 1000, 4, None), ("dl", 1001, 2999, 3, None)])
+def test_sliced_batches_match_oracle(monkeypatch, kind, n, b, t, adam):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    assert "slices" in _describe(kind, b, n, adam is not None)
+    _check_against_oracle(kind, n, b, t, adam)
 
 
 def test_default_policy_is_chunk_invariant_at_the_headline_shape(monkeypatch):

@@ -30,7 +30,8 @@ def test_families_on_the_nominal_chip(hip_lib, clean_env):
     assert "ptile_kernel<0, false>" in _describe(hip_lib, 0, 1000, 1000)    # one full round of 32 x 128 tiles: resident
     assert "ptile_kernel<2, false>" in _describe(hip_lib, 2, 512, 2000)
     assert "ptile_kernel<1, false>" in _describe(hip_lib, 1, 1000, 1000)    # every solver
-    assert "step_kernel<0" in _describe(hip_lib, 0, 2000, 1000)            # two rounds: one launch per step
+    assert "ptile_kernel<0, false> 2 slices" in _describe(hip_lib, 0, 2000, 1000)  # two rounds: two resident slices of the batch
+    assert "step_kernel<0, false, 0, 2" in _describe(hip_lib, 0, 1500, 1000)  # 1.5 rounds: 32 x 64 tiles, one launch per step
     d = _describe(hip_lib, 0, 32, 1000)                                    # small batch: slab, one cluster per XCD
     assert "slab_kernel<0, 8, 128, false>" in d and "8 clusters of 32 workgroups x 32 columns, 4 rows each" in d
     assert "XCDs" not in d
@@ -141,7 +142,9 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
 def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env):
     """ccvm_ptile.h: its workgroups wait for each other, so the grid must fit the chip the policy plans for (CU masks,
     partitions: CCVM_AMD_GEOMETRY), fill at least three quarters of it (below that the finer tile shapes win anyway),
-    and CCVM_AMD_KERNEL=tile / nocluster / noptile switch it off."""
+    and CCVM_AMD_KERNEL=tile / nocluster / noptile switch it off.  A batch of several rounds is cut into slices of whole
+    row blocks, each a resident grid of its own, where that is priced below the per-step plan (a resident round = 0.91
+    of a per-step round of 32 x 128 tiles)."""
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
     assert "ptile_kernel" in _describe(hip_lib, 0, 1000, 1000) and "ptile_kernel" in _describe(hip_lib, 0, 800, 900)
     assert "ptile_kernel" not in _describe(hip_lib, 0, 1000, 1100)         # 288 tiles: more than the chip holds
@@ -153,5 +156,5 @@ def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env
     clean_env.setenv("CCVM_AMD_GEOMETRY", "240,8")                         # a CU-masked chip: 256 workgroups do not fit
     assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000)
     clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
-    assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000)
+    assert "ptile_kernel<0, false> 2 slices" in _describe(hip_lib, 0, 1000, 1000)  # two resident grids of 16 x 8
     assert "ptile_kernel" in _describe(hip_lib, 0, 500, 1000)              # 16 x 8 = 128 workgroups fill that chip once
