@@ -493,6 +493,10 @@ def main():
         # a persistent launch runs up to 4096 steps (the schedule table of a run call, ccvm_abi.hip: TABLE_STEPS);
         # traj.advance(steps) in fused-noise mode is ONE run call = ceil(steps / 4096) launches
         launches = -(-args.steps // 4096) if persistent else args.steps
+        # (a batch of several rounds on the persistent tile kernel: its slices of rows are launches of their own, each
+        # over all the steps -- a "step" of the batch below is a step of every slice)
+        sliced = re.search(r"(\d+) slices of the batch", launch)
+        slices = int(sliced.group(1)) if sliced else 1
         steps_per_launch = args.steps / launches
         flops_per_step = 2.0 * na * n * n * b
         bytes_per_step = (16.0 if kind in ("dl", "mf") else 8.0) * n * b + 4.0 * n * n
@@ -508,12 +512,12 @@ def main():
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
             "frac_wall": flops_per_step / (wall_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "traffic": None,  # HBM bytes need separate rocprofv3 --pmc passes: see "profiled"
-            "algorithmic_bytes": bytes_per_step * steps_per_launch,
-            "algorithmic_flops": flops_per_step * steps_per_launch,
+            "algorithmic_bytes": ((bytes_per_step - 4.0 * n * n) / slices + 4.0 * n * n) * steps_per_launch,
+            "algorithmic_flops": flops_per_step * steps_per_launch / slices,
             "kernel": launch,
             "steps_per_launch": steps_per_launch,
-            "launches": launches,
-            "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch,
+            "launches": launches * slices,
+            "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch / slices,
             "avg_step_us": gpu_ms_per_step * 1e3,
             "timing": "HIP events on the launch stream around the timed region / launches in it",
             "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "

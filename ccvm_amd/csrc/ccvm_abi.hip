@@ -122,6 +122,7 @@ struct Tuning {
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
     int slab_delay = -1;             // >= 0: the fetch delay of clusters that span XCDs (x 64 cycles), else slab_fabric_delay
     int ptile = CLUSTER_DEFAULT;     // persistent streamed-Q tile kernel: 1 wherever it applies, 0 never, -1: see want_ptile
+    int split = CLUSTER_DEFAULT;     // batches cut into a part of whole resident grids and the rest: 1 wherever a cut exists, 0 never, -1: see split_rows
     ChipGeometry chip{0, 0};  // 0: ask the device
 };
 
@@ -136,6 +137,7 @@ Tuning read_tuning() {
         if (!std::strcmp(e, "slab")) t.slab = 1;
         if (!std::strcmp(e, "noslab")) t.slab = 0;
     }
+    if (const char* e = std::getenv("CCVM_AMD_SPLIT")) t.split = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("CCVM_AMD_SLAB_CGRP")) t.slab_cgrp = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_SLAB_RG")) t.slab_rg = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_SLAB_DELAY")) t.slab_delay = std::atoi(e);
@@ -531,15 +533,16 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
 // 16 x 16 = 256) are such shapes.
 // Batches of several rounds: the rows of a batch never meet, so the batch is cut into SLICES of whole row blocks, each
 // a resident grid of its own, run one after the other over all the steps of the chunk (`slices` launches per chunk
-// instead of one per step).  Priced like choose_ks prices the per-step shapes: a resident round costs 0.91 of a
-// per-step round of 32 x 128 tiles (30.9 against 34.0 us at the headline shape); taken where that beats the
-// per-step plan (DL N = 1000: B = 2000 two slices, 67.2 -> 61.9 us per step; B = 4000 four).
+// instead of one per step).  Priced like choose_ks prices the per-step shapes, in per-step rounds of 32 x 128 tiles of
+// the same solver: a resident round costs 0.91 (DL: 30.9 against 34.0 us at N = 1000), 0.76 (MF: 16.3 / 21.4) or 0.82
+// (Langevin: 15.9 / 19.5) of one, a round of 32 x 64 tiles 0.54 / 0.49 / 0.48; taken where that beats the per-step
+// plan (DL N = 1000: B = 2000 two slices, 67.5 -> 62.6 us per step; MF 41.7 -> 32.7; profiles/r04_sliced_batches.txt:
+// every measured point on the side the model puts it, ties included).
 struct PtilePlan {
     int slices = 0;  // 0: not this kernel
     int rbs = 0;     // row blocks per slice (the last one may hold fewer)
 };
-constexpr double PTILE_ROUND_COST = 0.91;
-PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs) {
+PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     PtilePlan p;
     if (!tun.ptile || vs || a.N <= CL_MAX_N) return p;
     const ChipGeometry chip = chip_of(tun);
@@ -551,19 +554,57 @@ PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs) {
         if (a.ks != 1) return p;
         if (tun.ptile < 0 && 4 * nrb * ncb < 3 * chip.cus) return p;
     } else if (tun.ptile < 0) {
-        static const double rel[3] = {1.0, 0.54, 0.37};  // choose_ks
+        static const double resident[3] = {0.91, 0.76, 0.82};                        // MODE_DL, MODE_MF, MODE_LANGEVIN
+        static const double rel[3][3] = {{1.0, 0.54, 0.37}, {1.0, 0.49, 0.37}, {1.0, 0.48, 0.37}};  // KS = 1, 2, 4
+        const int m = mode == MODE_MF ? 1 : mode == MODE_LANGEVIN ? 2 : 0;
         const int tiles = a.nrb * a.ncb;
-        const double step_cost = rel[a.ks == 1 ? 0 : a.ks == 2 ? 1 : 2] * ((tiles + chip.cus - 1) / chip.cus);
-        if (PTILE_ROUND_COST * slices >= 0.97 * step_cost) return p;
+        const double step_cost = rel[m][a.ks == 1 ? 0 : a.ks == 2 ? 1 : 2] * ((tiles + chip.cus - 1) / chip.cus);
+        if (resident[m] * slices >= 0.97 * step_cost) return p;
     }
     p.slices = slices;
     p.rbs = (nrb + slices - 1) / slices;
     return p;
 }
-bool want_ptile(const StepArgs& a, const Tuning& tun, bool adam, bool vs, int nsteps) {
-    (void)adam;  // every solver and Adam variant has an instantiation (DL has no Adam variant at all)
-    (void)nsteps;
-    return plan_ptile(a, tun, vs).slices > 0;
+bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
+    return plan_ptile(a, tun, vs, mode).slices > 0;  // (every solver and Adam variant has an instantiation)
+}
+// ---- batches cut in two (N > 768) -------------------------------------------------------------------------------
+// The rows of a batch never meet, so a batch that overflows its last resident grid a little -- B = 1100 at N = 1000:
+// 35 row blocks, three rounds of 32 x 64 tiles per step, 50.9 us -- runs as two calls on the same stream: the rows that
+// fill whole resident grids (1024: one launch per chunk, 30.9 us per step) and the rest under its own plan (76 rows:
+// the column-slab kernel).  Decided on the per-step estimates of the plans involved (us; fits of
+// profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Fused noise only (replay
+// blocks are pitched by the batch: parity mode keeps one plan per batch), no saturation arrays.
+double plan_us(int mode, int B, int N, const Tuning& tun) {
+    const bool two = mode == MODE_DL;
+    const double mf = mode == MODE_MF ? 1.0 : 0.0;
+    if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return sp.est_us;
+    StepArgs a;
+    base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
+    if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices)
+        return pp.slices * (two ? 0.0281 * N + 2.8 : 0.0145 * N + 1.4 + 0.4 * mf);
+    // per-step kernel: rounds of workgroups plus what a launch costs once (a lone round of 32 x 64 tiles 19.4 us at
+    // N = 1000, three rounds 51.4)
+    const int cus = chip_of(tun).cus, rounds = (a.nrb * a.ncb + cus - 1) / cus;
+    if (a.ks == 1) return rounds * (two ? 0.0267 * N + 7.3 : 0.0122 * N + 7.3 + 1.9 * mf);
+    if (a.ks == 2) return rounds * (two ? 0.0142 * N + 2.8 : 0.0088 * N + 1.2 + 1.0 * mf) + (two ? 2.4 : 1.6);
+    return rounds * (two ? 0.0072 * N + 3.9 : 0.0047 * N + 3.1 + 0.5 * mf);
+}
+// rows of the first part (a multiple of 64: the parts' pitched arrays and workspaces tile the batch's), 0: no cut
+int split_rows(int mode, int B, int N, const Tuning& tun) {
+    if (!tun.split || !tun.ptile || tun.force_tile || N <= CL_MAX_N) return 0;
+    if (tun.split < 0 && (tun.ptile > 0 || tun.ks || tun.slab > 0)) return 0;  // a forced family: one plan per batch
+    const ChipGeometry chip = chip_of(tun);
+    const int ncb = (N + BN - 1) / BN;
+    if (ncb > PT_FLAG_WORDS || ncb > chip.cus) return 0;
+    const int rows_fit = chip.cus / ncb * BM;  // rows of one resident grid
+    const int cut = (B / rows_fit) * rows_fit / 64 * 64;
+    if (cut <= 0 || cut >= B) return 0;
+    if (tun.split > 0) return cut;
+    return plan_us(mode, cut, N, tun) + plan_us(mode, B - cut, N, tun) < 0.93 * plan_us(mode, B, N, tun) ? cut : 0;
+}
+__global__ void status_merge_kernel(unsigned* whole, unsigned* part) {
+    if (*part) { *whole = *part; *part = 0u; }
 }
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
 int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }
@@ -576,7 +617,7 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
               void* area, unsigned* status, int step0, int done, int k, const Tuning& tun, hipStream_t st,
               const char* fn, int par, const ccvm_adam* adam = nullptr, float* st0 = nullptr, float* st1 = nullptr,
               const float* carry = nullptr) {
-    const PtilePlan plan = plan_ptile(a, tun, false);
+    const PtilePlan plan = plan_ptile(a, tun, false, MODE);
     const bool use_adam = adam && adam->enabled;
     const int nrb_all = (a.B + BM - 1) / BM;
     for (int rb0 = 0; rb0 < nrb_all; rb0 += plan.rbs) {
@@ -660,7 +701,10 @@ const char* ccvm_last_error(void) { return g_err; }
 int ccvm_ld(int N) { return N <= 0 ? 0 : round_up(N, 128); }
 int ccvm_rows(int B) { return B <= 0 ? 0 : round_up(B, 64); }
 
-size_t ccvm_workspace_bytes(int solver, int B, int N) {
+}  // extern "C"
+namespace {
+// a run's workspace without the parts of a cut batch (below)
+size_t workspace_plain(int solver, int B, int N) {
     const size_t ld = (size_t)ccvm_ld(N), rows = (size_t)ccvm_rows(B);
     const size_t state = rows * ld * sizeof(float);
     const size_t qs = qsum_area_bytes(N);  // column sums of Q (+ their slice partials)
@@ -678,9 +722,27 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     }
 }
 
+size_t part_offset(size_t bytes) { return (bytes + 255) / 256 * 256; }
+}  // namespace
+extern "C" {
+
+// A batch that split_rows cuts in two carries the workspaces of its parts behind its own (whose layout, status word
+// included, stays what it is without the cut: a call in replay mode or after a time-out runs uncut).
+size_t ccvm_workspace_bytes(int solver, int B, int N) {
+    const size_t plain = workspace_plain(solver, B, N);
+    if (solver < 0 || solver > 2 || B <= 0 || N <= 0) return plain;
+    Tuning tun = read_tuning();
+    if (tun.split < 0) tun.split = 1;  // (whatever the estimates say at run time: room for the cut)
+    tun.ptile = tun.ptile ? -1 : 0;
+    tun.ks = 0;
+    tun.slab = tun.slab ? -1 : 0;
+    const int cut = split_rows(solver, B, N, tun);
+    return cut ? part_offset(plain) + part_offset(workspace_plain(solver, cut, N)) + workspace_plain(solver, B - cut, N) : plain;
+}
+
 size_t ccvm_status_offset(int solver, int B, int N) {
     if (solver < 0 || solver > 2) return (size_t)-1;
-    return ccvm_workspace_bytes(solver, B, N) - cluster_sync_bytes(B);
+    return workspace_plain(solver, B, N) - cluster_sync_bytes(B);
 }
 
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
@@ -707,6 +769,15 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
+    if (const int cut = per_variable_s ? 0 : split_rows(solver, B, N, tun)) {
+        // (fused noise; a replay call runs the batch uncut: describe it with CCVM_AMD_SPLIT=0)
+        char first[512], rest[512];
+        int rc;
+        if ((rc = ccvm_describe_launch(solver, cut, N, adam, 0, first, sizeof(first)))) return rc;
+        if ((rc = ccvm_describe_launch(solver, B - cut, N, adam, 0, rest, sizeof(rest)))) return rc;
+        std::snprintf(buf, buf_len, "batch cut in two: rows 0-%d %s | rows %d-%d %s", cut - 1, first, cut, B - 1, rest);
+        return CCVM_OK;
+    }
     if (const SlabPlan sp = want_persist(N, tun) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
         // the fourth template argument: launches of 512 steps or more of clusters that span XCDs calibrate their
         // fetch delay (ccvm_slab.h: slab_calibrates); shorter launches of the same shape run the `false` variant
@@ -734,7 +805,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
-        if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0); plan.slices == 1) {
+        if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0, solver); plan.slices == 1) {
             std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
                           solver, ad ? "true" : "false", a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
             return CCVM_OK;
@@ -790,9 +861,28 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     if ((rc = check_noise(fn, nz, true))) return rc;
     if (!aligned16(Q) || !aligned16(c) || !aligned16(s) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, c, s and workspace must be 16-byte aligned", fn);
-    if (ws_bytes < ccvm_workspace_bytes(0, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
+    if (ws_bytes < workspace_plain(0, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     if (!(p->upper > p->lower) || !(p->dt > 0)) return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0", fn);
     hipStream_t st = (hipStream_t)stream;
+
+    if (const int cut = (nsteps > 0 && nz->mode != CCVM_NOISE_REPLAY) ? split_rows(MODE_DL, B, N, tun) : 0;
+        cut && ws_bytes >= ccvm_workspace_bytes(0, B, N)) {
+        // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
+        char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(0, B, N));
+        unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ccvm_status_offset(0, B, N));
+        for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
+            const int rows = r0 ? B - cut : cut;
+            ccvm_noise n = *nz;
+            n.row_offset += r0;
+            const size_t off = (size_t)r0 * ld, bytes = workspace_plain(0, rows, N);
+            if ((rc = ccvm_dl_run(Q, V, c + off, s + off, rows, N, ld, step0, nsteps, T, p, &n, part_ws, bytes, stream))) return rc;
+            hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, st, status,
+                               reinterpret_cast<unsigned*>(part_ws + ccvm_status_offset(0, rows, N)));
+            CCVM_CHECK_LAUNCH(fn);
+            part_ws += part_offset(bytes);
+        }
+        return CCVM_OK;
+    }
 
     const size_t state = (size_t)ccvm_rows(B) * ld;
     float* bufc[2] = {c, static_cast<float*>(ws)};
@@ -890,7 +980,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
-    if (nsteps > 0 && want_ptile(a, tun, false, false, nsteps)) {
+    if (nsteps > 0 && want_ptile(a, tun, MODE_DL, false)) {
         // whole chunks in one launch each, the tile grid resident, the state handed over between the workgroups of a
         // row block inside the launch (ccvm_ptile.h)
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
@@ -958,7 +1048,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (!aligned16(Q) || !aligned16(mu) || !aligned16(sigma) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, mu, sigma and workspace must be 16-byte aligned", fn);
     const float* s_cols = p->s_cols;
-    if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(1, B, N) : ccvm_workspace_bytes(1, B, N)))
+    if (ws_bytes < workspace_plain(1, B, N) + (s_cols ? (size_t)ld * ld * sizeof(float) : 0))
         return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     const float* s_full = p->s_full;
     if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0) || !(p->j > 0))
@@ -971,6 +1061,33 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
+
+    if (const int cut = (nz->mode != CCVM_NOISE_REPLAY && !s_cols && !s_full) ? split_rows(MODE_MF, B, N, tun) : 0;
+        cut && ws_bytes >= ccvm_workspace_bytes(1, B, N)) {
+        // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
+        char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(1, B, N));
+        unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ccvm_status_offset(1, B, N));
+        for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
+            const int rows = r0 ? B - cut : cut;
+            const size_t off = (size_t)r0 * ld, bytes = workspace_plain(1, rows, N);
+            ccvm_noise n = *nz;
+            n.row_offset += r0;
+            ccvm_adam ad;
+            if (adam) {
+                ad = *adam;
+                if (ad.m) ad.m += off;
+                if (ad.v) ad.v += off;
+            }
+            if ((rc = ccvm_mf_run(Q, V, mu + off, sigma + off, mu_tilde_out ? mu_tilde_out + off : nullptr, rows, N, ld, step0,
+                                  nsteps, T, p, adam ? &ad : nullptr, &n, part_ws, bytes, stream)))
+                return rc;
+            hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, st, status,
+                               reinterpret_cast<unsigned*>(part_ws + ccvm_status_offset(1, rows, N)));
+            CCVM_CHECK_LAUNCH(fn);
+            part_ws += part_offset(bytes);
+        }
+        return CCVM_OK;
+    }
 
     const size_t state = (size_t)ccvm_rows(B) * ld;
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
@@ -1046,7 +1163,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
-        pa.Q = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        pa.Q = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(1, B, N), st) : Q;
         pa.V = V; pa.qsum = qsum; pa.x0 = mu; pa.x1 = sigma; pa.xt = mu_tilde_out; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = replay;
         pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
@@ -1079,7 +1196,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(after);
         SlabArgs sa;
         unsigned xid;
-        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(1, B, N), st) : Q;
         if (slab_base(sa, xid, sp, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun, 1))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         sa.x0 = mu; sa.x1 = sigma; sa.xt = mu_tilde_out;
@@ -1112,7 +1229,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         float* table = reinterpret_cast<float*>(after);
         ClusterArgs ca;
         unsigned xid;
-        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st) : Q;
+        const float* q_used = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(1, B, N), st) : Q;
         if (cluster_base(ca, xid, q_used, V, qsum, B, N, ld, nz, table, after + table_bytes(), step0, st, tun))
             return fail(CCVM_E_HIP, "%s: memset failed", fn);
         ca.x0 = mu; ca.x1 = sigma; ca.xt = mu_tilde_out;
@@ -1148,7 +1265,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     a.in_shift = (float)up;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum, p->qsum))) return rc;
     if (s_cols) {
-        a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(1, B, N), st);
+        a.Q = scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(1, B, N), st);
         a.s_cols = s_cols;
     }
     // measured amplitude of the first step of a chunk (mf_solver.py:551-554), and that step's normals
@@ -1158,7 +1275,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
                            ld, k0, (float)S_eff, s_cols, nz->seed, nz->row_offset, first_step,
                            replay ? nz->w0 + (size_t)done * N * B : nullptr);
     };
-    if (want_ptile(a, tun, use_adam, s_cols != nullptr, nsteps)) {
+    if (want_ptile(a, tun, MODE_MF, s_cols != nullptr)) {
         // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h): the exchanged plane is the measured
         // amplitude; mu, sigma and the Adam moments stay in the workgroups' registers for the launch
         char* after = static_cast<char*>(ws) + 3 * state * sizeof(float) + qsum_area_bytes(N);
@@ -1246,7 +1363,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (!aligned16(Q) || !aligned16(c) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, c and workspace must be 16-byte aligned", fn);
     const float* s_cols = p->s_cols;
-    if (ws_bytes < (s_cols ? ccvm_workspace_bytes_cols(2, B, N) : ccvm_workspace_bytes(2, B, N)))
+    if (ws_bytes < workspace_plain(2, B, N) + (s_cols ? (size_t)ld * ld * sizeof(float) : 0))
         return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     const float* s_full = p->s_full;
     if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0))
@@ -1257,6 +1374,33 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
+
+    if (const int cut = (nz->mode != CCVM_NOISE_REPLAY && !s_cols && !s_full) ? split_rows(MODE_LANGEVIN, B, N, tun) : 0;
+        cut && ws_bytes >= ccvm_workspace_bytes(2, B, N)) {
+        // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
+        char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(2, B, N));
+        unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ccvm_status_offset(2, B, N));
+        for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
+            const int rows = r0 ? B - cut : cut;
+            const size_t off = (size_t)r0 * ld, bytes = workspace_plain(2, rows, N);
+            ccvm_noise n = *nz;
+            n.row_offset += r0;
+            ccvm_adam ad;
+            if (adam) {
+                ad = *adam;
+                if (ad.m) ad.m += off;
+                if (ad.v) ad.v += off;
+            }
+            if ((rc = ccvm_langevin_run(Q, V, c + off, rows, N, ld, step0, nsteps, T, p, adam ? &ad : nullptr, &n, part_ws, bytes,
+                                        stream)))
+                return rc;
+            hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, st, status,
+                               reinterpret_cast<unsigned*>(part_ws + ccvm_status_offset(2, rows, N)));
+            CCVM_CHECK_LAUNCH(fn);
+            part_ws += part_offset(bytes);
+        }
+        return CCVM_OK;
+    }
 
     // workspace: [c' = exchange buffer 0][exchange buffer 1][column sums of Q][schedule table][cluster sync]
     const size_t state = (size_t)ccvm_rows(B) * ld;
@@ -1271,7 +1415,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
     if (s_cols) {
-        a.Q = scaled_rows(Q, s_cols, N, ld, ws, ccvm_workspace_bytes(2, B, N), st);
+        a.Q = scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(2, B, N), st);
         a.s_cols = s_cols;
     }
     char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
@@ -1395,7 +1539,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         if (exchange_commit(ca.status, xid, step0 + nsteps, st)) return fail(CCVM_E_HIP, "%s: launch failed", fn);
         return CCVM_OK;
     }
-    if (want_ptile(a, tun, use_adam, s_cols != nullptr, nsteps)) {
+    if (want_ptile(a, tun, MODE_LANGEVIN, s_cols != nullptr)) {
         // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h)
         unsigned* status = reinterpret_cast<unsigned*>(after + table_bytes() + exchange_bytes(B, N, 1));
         PersistArgs pa_ad;  // (the Adam schedule constants in the persistent kernels' form)

@@ -158,7 +158,10 @@ int ccvm_unpack(const float* src, int src_ld,
 /* Bytes of caller-provided scratch a call needs (ping-pong state, the MF measured-amplitude
  * buffers, column sums of Q, schedule table; for 256 < N <= 768 the column-cluster path's exchange
  * buffers of 8-byte {value, tag} packets, and the column-slab path's for small batches above N = 256; a status
- * line).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
+ * line; above N = 768, for a batch larger than one resident grid of the persistent tile kernel, behind all that the
+ * workspaces of the two parts a run call may cut the batch into -- the rows of whole resident grids and the rest, run
+ * as two calls on the same stream, fused noise only; a call given less than this but enough for the uncut batch runs
+ * uncut).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
  * 2 ccvm_langevin_run, 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);
 /* Byte offset, inside the workspace of ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2),
@@ -167,7 +170,8 @@ size_t ccvm_workspace_bytes(int solver, int B, int N);
  * synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of a persistent path whose workgroups exchange data
  * (column-cluster kernel, 256 < N <= 768; column-slab kernel, small batches above N = 256; persistent tile kernel, full
  * grids of 32 x 128 tiles above N = 768) gave up because its
- * workgroups could not become resident (another process holding the GPU for ~1 s) -- the state arrays are then
+ * workgroups could not become resident (another process holding the GPU for ~1 s; in a cut batch: in either part) -- the
+ * state arrays are then
  * invalid: restore them and repeat the steps with CCVM_RUN_NO_EXCHANGE.  Run calls never clear the status word.  The
  * rest of the line is the library's: it records what the exchange area in front of it holds, so that a later call
  * on the same workspace with later steps does not clear the area again. */

@@ -44,8 +44,8 @@ def test_ptile_is_the_default_for_full_grids_of_wide_tiles(monkeypatch):
         assert f"ptile_kernel<{_SOLVER[kind]}, {str(adam).lower()}> {slices} slices" in _describe(kind, b, n, adam), (kind, n, b)
     # not: grids of less than three quarters of the chip, batches whose slices would leave CUs idle (the finer
     # per-step tile shapes cost less there), the cluster kernel's sizes
-    for kind, n, b, adam in (("dl", 1000, 1500, False), ("dl", 1000, 2500, False), ("dl", 1000, 512, False),
-                             ("dl", 768, 1000, False), ("dl", 1500, 1000, False), ("mf", 1000, 1056, True)):
+    for kind, n, b, adam in (("dl", 1000, 1500, False), ("dl", 1000, 1300, False), ("dl", 1000, 512, False),
+                             ("dl", 768, 1000, False), ("dl", 1500, 1000, False), ("dl", 1200, 1000, False)):
         assert "ptile_kernel" not in _describe(kind, b, n, adam), (kind, n, b)
     monkeypatch.setenv("CCVM_AMD_KERNEL", "noptile")
     assert "step_kernel" in _describe("dl", 1000, 1000)
@@ -143,6 +143,71 @@ def test_sliced_batches_match_oracle(monkeypatch, kind, n, b, t, adam):
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
     assert "slices" in _describe(kind, b, n, adam is not None)
     _check_against_oracle(kind, n, b, t, adam)
+
+
+_CUT = [("dl", 1000, 1100, None, 1024), ("mf", 1000, 1500, "second_moment", 1024), ("langevin", 1000, 2500, None, 2048),
+        ("pl", 2000, 640, "add_assign", 512), ("dl", 1100, 1000, None, 896), ("mf", 1000, 1200, None, 1024),
+        ("dl", 1000, 1030, None, 1024)]
+
+
+@pytest.mark.parametrize("kind,n,b,adam,cut", _CUT)
+def test_batches_cut_in_two_are_their_parts(monkeypatch, kind, n, b, adam, cut):
+    """split_rows (ccvm_abi.hip): a batch that overflows its last resident grid a little runs as two calls, the rows
+    of whole resident grids and the rest under its own plan, each with the workspace of its own behind the batch's.
+    Bit for bit the two trajectories run separately (the global row index keys the noise), however it is chunked."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    d = _describe(kind, b, n, adam is not None)
+    assert d.startswith(f"batch cut in two: rows 0-{cut - 1} ccvm::ptile_kernel"), d
+    t, hp = 11, _ADAMS[adam]
+    whole = _state(_run_engine(kind, n, b, t, hp, 606, 5))
+    parts = _state(_run_engine(kind, n, b, t, hp, 606, 5, chunks=[1, 4, 1, 5]))
+    lo = _state(_run_engine(kind, n, cut, t, hp, 606, 5))
+    hi = _state(_run_engine(kind, n, b - cut, t, hp, 606, 5 + cut))
+    for name in whole:
+        assert bool(torch.isfinite(whole[name]).all()), name
+        assert torch.equal(whole[name], parts[name]), f"{kind} N={n} B={b}: {name} depends on the chunks"
+        assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam", [("dl", 1000, 1100, 6, None), ("mf", 1000, 1500, 4, "second_moment"),
+                                             ("pl", 2000, 640, 4, "add_assign"), ("dl", 1100, 1000, 5, None)])
+def test_batches_cut_in_two_match_oracle(monkeypatch, kind, n, b, t, adam):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    assert "cut in two" in _describe(kind, b, n, adam is not None)
+    _check_against_oracle(kind, n, b, t, adam)
+
+
+def test_replay_runs_of_a_cut_shape_stay_uncut(monkeypatch):
+    """Replay blocks are pitched by the batch, so parity mode keeps one plan per batch: the same result with the cut
+    switched off, and close to the fused-mode plan's arithmetic (the oracle check above)."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    a = _state(_run_engine("dl", 1000, 1100, 5, None, 12, 0, replay_global_batch=1100))
+    monkeypatch.setenv("CCVM_AMD_SPLIT", "0")
+    b = _state(_run_engine("dl", 1000, 1100, 5, None, 12, 0, replay_global_batch=1100))
+    for name in a:
+        assert torch.equal(a[name], b[name]), name
+
+
+def test_time_out_in_a_part_of_a_cut_batch_recovers_the_whole_batch(monkeypatch):
+    """Fault injection in a cut batch: the parts' status words are merged into the batch's, the engine restores its
+    snapshot and repeats the steps uncut on the per-step kernel."""
+    monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "nocluster")
+    want = _run_engine("dl", 1000, 1100, 5, None, 21, 0).compact("c").cpu()
+    monkeypatch.delenv("CCVM_AMD_KERNEL")
+    assert "cut in two" in _describe("dl", 1100, 1000)
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    traj = _run_engine("dl", 1000, 1100, 5, None, 21, 0)
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
+        got = traj.compact("c").cpu()
+    assert traj.fallbacks == 1 and traj.no_exchange
+    assert torch.equal(got, want)
+    monkeypatch.delenv("CCVM_AMD_FAULT")
+    again = _run_engine("dl", 1000, 1100, 5, None, 21, 0)  # (the parts' status words were cleared by the merge)
+    assert again.fallbacks == 0 and not torch.equal(again.compact("c").cpu(), want)
 
 
 def test_default_policy_is_chunk_invariant_at_the_headline_shape(monkeypatch):

@@ -8,15 +8,15 @@ import re
 import pytest
 
 
-def _describe(hip_lib, solver, b, n, adam=0):
-    buf = ctypes.create_string_buffer(512)
-    assert hip_lib.ccvm_describe_launch(solver, b, n, adam, 0, buf, 512) == 0
+def _describe(hip_lib, solver, b, n, adam=0, per_variable_s=0):
+    buf = ctypes.create_string_buffer(1024)
+    assert hip_lib.ccvm_describe_launch(solver, b, n, adam, per_variable_s, buf, 1024) == 0
     return buf.value.decode()
 
 
 @pytest.fixture
 def clean_env(monkeypatch):
-    for var in ("CCVM_AMD_KERNEL", "CCVM_AMD_GEOMETRY", "CCVM_AMD_SLAB_CGRP", "CCVM_AMD_SLAB_RG", "CCVM_AMD_KS"):
+    for var in ("CCVM_AMD_KERNEL", "CCVM_AMD_GEOMETRY", "CCVM_AMD_SLAB_CGRP", "CCVM_AMD_SLAB_RG", "CCVM_AMD_KS", "CCVM_AMD_SPLIT"):
         monkeypatch.delenv(var, raising=False)
     return monkeypatch
 
@@ -63,6 +63,35 @@ def test_tile_shape_follows_the_rounds_a_cu_runs(hip_lib, clean_env):
     assert ks(0, 2000, 1000) == 1 and ks(0, 500, 1500) == 1
     clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")                                      # half a chip: N = 1000 is two rounds
     assert ks(0, 1000, 1000) == 1 and ks(0, 1000, 700) == 2                             # 192 tiles: 2 rounds; 352: 3 x 0.54
+
+
+def test_batches_cut_in_two(hip_lib, clean_env):
+    """split_rows (N > 768): a batch that overflows its last resident grid a little runs as the rows of whole resident
+    grids plus the rest under its own plan, where the plans' estimates say so; never with a forced family, a
+    per-variable saturation, or where slices of the batch already fill the chip."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    d = _describe(hip_lib, 0, 1100, 1000)
+    assert d.startswith("batch cut in two: rows 0-1023 ccvm::ptile_kernel<0, false> grid 256 x") and "| rows 1024-1099 ccvm::slab_kernel<0" in d
+    assert "rows 1024-1499 ccvm::step_kernel<1, true, 0, 2" in _describe(hip_lib, 1, 1500, 1000, adam=1)
+    d = _describe(hip_lib, 2, 2500, 1000)
+    assert "rows 0-2047 ccvm::ptile_kernel<2, false> 2 slices" in d and "| rows 2048-2499 ccvm::step_kernel<2" in d
+    assert "rows 0-511 ccvm::ptile_kernel<0, false>" in _describe(hip_lib, 0, 640, 2000)
+    for solver, b, n in ((0, 2000, 1000), (0, 1800, 1000), (0, 1000, 1000), (0, 1000, 1500), (0, 900, 1000), (2, 3000, 1000)):
+        assert "cut in two" not in _describe(hip_lib, solver, b, n), (solver, b, n)
+    assert "cut in two" not in _describe(hip_lib, 2, 1100, 1000, per_variable_s=1)
+    for env in ({"CCVM_AMD_KERNEL": "noptile"}, {"CCVM_AMD_KERNEL": "tile"}, {"CCVM_AMD_KERNEL": "ptile"}, {"CCVM_AMD_KS": "2"},
+                {"CCVM_AMD_SPLIT": "0"}):
+        for k, v in env.items():
+            clean_env.setenv(k, v)
+        assert "cut in two" not in _describe(hip_lib, 0, 1100, 1000), env
+        for k in env:
+            clean_env.delenv(k)
+    # the workspace carries the parts' workspaces behind its own, whose layout (status word included) is that of the
+    # uncut batch -- with room for the cut whatever the estimates will say
+    plain = hip_lib.ccvm_status_offset(0, 1100, 1000) + 128
+    assert hip_lib.ccvm_workspace_bytes(0, 1100, 1000) >= plain + hip_lib.ccvm_workspace_bytes(0, 1024, 1000) + hip_lib.ccvm_workspace_bytes(0, 76, 1000)
+    assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == hip_lib.ccvm_status_offset(0, 1000, 1000) + 128
+    assert hip_lib.ccvm_workspace_bytes(0, 1100, 500) == hip_lib.ccvm_status_offset(0, 1100, 500) + 128
 
 
 @pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])
@@ -147,14 +176,22 @@ def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env
     of a per-step round of 32 x 128 tiles)."""
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
     assert "ptile_kernel" in _describe(hip_lib, 0, 1000, 1000) and "ptile_kernel" in _describe(hip_lib, 0, 800, 900)
-    assert "ptile_kernel" not in _describe(hip_lib, 0, 1000, 1100)         # 288 tiles: more than the chip holds
+    d = _describe(hip_lib, 0, 1000, 1100)                                  # 32 x 9 = 288 tiles: more than the chip holds
+    assert d.startswith("batch cut in two: rows 0-895 ccvm::ptile_kernel<0, false> grid 252 x") and "| rows 896-999 ccvm::step_kernel<0, false, 0, 4" in d
+    clean_env.setenv("CCVM_AMD_SPLIT", "0")
+    assert _describe(hip_lib, 0, 1000, 1100).startswith("ccvm::step_kernel<0, false, 0, 2")
+    clean_env.delenv("CCVM_AMD_SPLIT")
     assert "ptile_kernel" not in _describe(hip_lib, 0, 512, 1000)          # half the chip: 32 x 64 tiles
     for off in ("tile", "nocluster", "noptile"):
         clean_env.setenv("CCVM_AMD_KERNEL", off)
         assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000), off
     clean_env.delenv("CCVM_AMD_KERNEL")
     clean_env.setenv("CCVM_AMD_GEOMETRY", "240,8")                         # a CU-masked chip: 256 workgroups do not fit
+    d = _describe(hip_lib, 0, 1000, 1000)                                  # 30 row blocks resident, the last 40 rows apart
+    assert d.startswith("batch cut in two: rows 0-959 ccvm::ptile_kernel<0, false> grid 240 x") and "| rows 960-999 ccvm::slab_kernel" in d
+    clean_env.setenv("CCVM_AMD_SPLIT", "0")
     assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000)
+    clean_env.delenv("CCVM_AMD_SPLIT")
     clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
     assert "ptile_kernel<0, false> 2 slices" in _describe(hip_lib, 0, 1000, 1000)  # two resident grids of 16 x 8
     assert "ptile_kernel" in _describe(hip_lib, 0, 500, 1000)              # 16 x 8 = 128 workgroups fill that chip once
