@@ -358,8 +358,8 @@ def describe_launch(kind, b, n):
 
     from ccvm_amd import _lib
 
-    buf = ctypes.create_string_buffer(512)
-    _lib.check(_lib.load().ccvm_describe_launch(SOLVER_ID[kind], b, n, 0, 0, buf, 512), "ccvm_describe_launch")
+    buf = ctypes.create_string_buffer(1024)
+    _lib.check(_lib.load().ccvm_describe_launch(SOLVER_ID[kind], b, n, 0, 0, buf, 1024), "ccvm_describe_launch")
     return buf.value.decode()
 
 
@@ -525,7 +525,13 @@ def main():
             "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
             "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
-        roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3, wall_ms_per_step * 1e3))
+        if launch.startswith("batch cut in two"):
+            # two run plans one after the other (rows of whole resident grids + the rest): the line prices the step of
+            # the whole batch against the MFMA peak; there is no single "launch" to quote
+            for key in ("algorithmic_bytes", "algorithmic_flops", "steps_per_launch", "launches", "avg_launch_us"):
+                roofline[key] = None
+        else:
+            roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3, wall_ms_per_step * 1e3))
         out = {
             "metric": metric,
             "value": args.steps * global_rows / elapsed,

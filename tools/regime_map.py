@@ -6,12 +6,15 @@ import json, os, re, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NS = (100, 256, 300, 500, 640, 768, 1000, 1500, 2000)
-BS = (1, 8, 32, 64, 128, 256, 384, 512, 768, 1000, 2000, 4000)
+BS = (1, 8, 32, 64, 128, 256, 384, 512, 768, 1000, 1100, 1500, 2000, 4000)
 KINDS = ("dl", "langevin", "mf")
 PATH = os.path.join("gpurun_out", "regime_map.jsonl")
 
 
 def family(kernel):
+    if kernel.startswith("batch cut in two"):
+        first, rest = kernel[len("batch cut in two: "):].split(" | ")
+        return family(first.split(" ", 2)[2]) + "+" + family(rest.split(" ", 2)[2])
     if "persist_kernel" in kernel:
         return "R"
     if "slab_kernel" in kernel:
@@ -19,7 +22,8 @@ def family(kernel):
     if "cluster_kernel" in kernel:
         return "C"
     if "ptile_kernel" in kernel:
-        return "P"
+        sliced = re.search(r"(\d+) slices", kernel)
+        return "P" + (sliced.group(1) if sliced else "")
     return "T" + re.search(r"step_kernel<\d, \w+, 0, (\d)", kernel).group(1)
 
 
@@ -57,7 +61,7 @@ def markdown(tag):
     print(f"# Round {tag[1:].lstrip('0')}: the regime map (1x MI355X, default launch policy)\n")
     print("`python3 tools/regime_map.py`: run calls of the engine (fused noise; 128-4096 steps, about 60 ms each), best of 3, "
           "no profiler.  Cell = us per step, kernel family: R row-owner persistent, S column-slab persistent, C "
-          "column-cluster persistent, P persistent tile (32 x 128 tiles resident over the chunk; round 4), T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
+          "column-cluster persistent, P persistent tile (32 x 128 tiles resident over the chunk; round 4; Pk: k slices of the batch one after the other; X+Y: the batch cut in two, rows of whole resident grids + the rest), T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
           "table: fraction of the fp32 MFMA peak (157.3 TFLOP/s; DL 4 N^2 B flop per step, the others 2 N^2 B).\n")
     for kind in KINDS:
         print(f"## {kind}\n")
