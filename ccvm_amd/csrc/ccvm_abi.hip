@@ -568,7 +568,7 @@ PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
 bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
     return plan_ptile(a, tun, vs, mode).slices > 0;  // (every solver and Adam variant has an instantiation)
 }
-// ---- batches cut in two (N > 768) -------------------------------------------------------------------------------
+// ---- batches cut in two (N > 768, and the cluster kernel's N <= 512) -------------------------------------------------------------------------------
 // The rows of a batch never meet, so a batch that overflows its last resident grid a little -- B = 1100 at N = 1000:
 // 35 row blocks, three rounds of 32 x 64 tiles per step, 50.9 us -- runs as two calls on the same stream: the rows that
 // fill whole resident grids (1024: one launch per chunk, 30.9 us per step) and the rest under its own plan (76 rows:
@@ -579,6 +579,15 @@ double plan_us(int mode, int B, int N, const Tuning& tun) {
     const bool two = mode == MODE_DL;
     const double mf = mode == MODE_MF ? 1.0 : 0.0;
     if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return sp.est_us;
+    if (want_cluster(B, N, tun, mode, false)) {
+        // rounds of resident clusters; a round by K (cluster kernel: measured at B = 1000)
+        static const double round_us[4][3] = {{7.9, 4.27, 3.77}, {10.1, 5.38, 4.87}, {18.1, 9.6, 8.9}, {21.8, 11.4, 10.7}};
+        const ChipGeometry chip = chip_of(tun);
+        const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
+        const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
+        const int k = round_up(N, 128) / 128 - 3;  // K = 384, 512, 640, 768
+        return (count + per_round - 1) / per_round * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
+    }
     StepArgs a;
     base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
     if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices)
@@ -592,12 +601,23 @@ double plan_us(int mode, int B, int N, const Tuning& tun) {
 }
 // rows of the first part (a multiple of 64: the parts' pitched arrays and workspaces tile the batch's), 0: no cut
 int split_rows(int mode, int B, int N, const Tuning& tun) {
-    if (!tun.split || !tun.ptile || tun.force_tile || N <= CL_MAX_N) return 0;
-    if (tun.split < 0 && (tun.ptile > 0 || tun.ks || tun.slab > 0)) return 0;  // a forced family: one plan per batch
+    if (!tun.split || tun.force_tile) return 0;
+    if (tun.split < 0 && (tun.ptile > 0 || tun.ks || tun.slab > 0 || tun.cluster > 0)) return 0;  // a forced family: one plan per batch
     const ChipGeometry chip = chip_of(tun);
-    const int ncb = (N + BN - 1) / BN;
-    if (ncb > PT_FLAG_WORDS || ncb > chip.cus) return 0;
-    const int rows_fit = chip.cus / ncb * BM;  // rows of one resident grid
+    int rows_fit;  // rows of one resident grid
+    if (N > CL_MAX_N) {
+        const int ncb = (N + BN - 1) / BN;
+        if (!tun.ptile || ncb > PT_FLAG_WORDS || ncb > chip.cus) return 0;
+        rows_fit = chip.cus / ncb * BM;
+    } else if (N >= CL_MIN_N && round_up(N, 128) <= CL_LDS_K) {
+        // the cluster kernel's 32-row clusters, each inside an XCD (N = 500, B = 1100: 35 clusters of 8 run in two
+        // rounds, 9.8 us per step for Langevin; 32 resident clusters + 76 rows on the slab kernel: 6.7)
+        const int G = (N + CL_COLS - 1) / CL_COLS;
+        if (!tun.cluster || chip.xcds != 8 || chip.cus / chip.xcds < G) return 0;
+        rows_fit = chip.xcds * (chip.cus / chip.xcds / G) * cluster_rows(N);
+    } else {
+        return 0;
+    }
     const int cut = (B / rows_fit) * rows_fit / 64 * 64;
     if (cut <= 0 || cut >= B) return 0;
     if (tun.split > 0) return cut;
@@ -736,6 +756,7 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     tun.ptile = tun.ptile ? -1 : 0;
     tun.ks = 0;
     tun.slab = tun.slab ? -1 : 0;
+    tun.cluster = tun.cluster ? -1 : 0;
     const int cut = split_rows(solver, B, N, tun);
     return cut ? part_offset(plain) + part_offset(workspace_plain(solver, cut, N)) + workspace_plain(solver, B - cut, N) : plain;
 }

@@ -147,7 +147,10 @@ def test_sliced_batches_match_oracle(monkeypatch, kind, n, b, t, adam):
 
 _CUT = [("dl", 1000, 1100, None, 1024), ("mf", 1000, 1500, "second_moment", 1024), ("langevin", 1000, 2500, None, 2048),
         ("pl", 2000, 640, "add_assign", 512), ("dl", 1100, 1000, None, 896), ("mf", 1000, 1200, None, 1024),
-        ("dl", 1000, 1030, None, 1024)]
+        ("dl", 1000, 1030, None, 1024),
+        # the cluster kernel's sizes (N <= 512): the rows of the resident clusters, then the rest
+        ("langevin", 500, 1100, None, 1024), ("dl", 500, 1100, None, 1024), ("mf", 500, 1100, "second_moment", 1024),
+        ("pl", 300, 1600, "add_assign", 1536), ("mf", 500, 2100, None, 2048)]
 
 
 @pytest.mark.parametrize("kind,n,b,adam,cut", _CUT)
@@ -158,7 +161,7 @@ def test_batches_cut_in_two_are_their_parts(monkeypatch, kind, n, b, adam, cut):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
     d = _describe(kind, b, n, adam is not None)
-    assert d.startswith(f"batch cut in two: rows 0-{cut - 1} ccvm::ptile_kernel"), d
+    assert d.startswith(f"batch cut in two: rows 0-{cut - 1} ccvm::{'ptile' if n > 768 else 'cluster'}_kernel"), d
     t, hp = 11, _ADAMS[adam]
     whole = _state(_run_engine(kind, n, b, t, hp, 606, 5))
     parts = _state(_run_engine(kind, n, b, t, hp, 606, 5, chunks=[1, 4, 1, 5]))
@@ -171,7 +174,8 @@ def test_batches_cut_in_two_are_their_parts(monkeypatch, kind, n, b, adam, cut):
 
 
 @pytest.mark.parametrize("kind,n,b,t,adam", [("dl", 1000, 1100, 6, None), ("mf", 1000, 1500, 4, "second_moment"),
-                                             ("pl", 2000, 640, 4, "add_assign"), ("dl", 1100, 1000, 5, None)])
+                                             ("pl", 2000, 640, 4, "add_assign"), ("dl", 1100, 1000, 5, None),
+                                             ("dl", 500, 1100, 12, None), ("mf", 500, 1100, 12, "second_moment")])
 def test_batches_cut_in_two_match_oracle(monkeypatch, kind, n, b, t, adam):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)

@@ -76,6 +76,12 @@ def test_batches_cut_in_two(hip_lib, clean_env):
     d = _describe(hip_lib, 2, 2500, 1000)
     assert "rows 0-2047 ccvm::ptile_kernel<2, false> 2 slices" in d and "| rows 2048-2499 ccvm::step_kernel<2" in d
     assert "rows 0-511 ccvm::ptile_kernel<0, false>" in _describe(hip_lib, 0, 640, 2000)
+    # the cluster kernel's sizes up to N = 512: 8 x floor(32 / G) resident clusters of 32 rows, then the rest
+    d = _describe(hip_lib, 2, 1100, 500)
+    assert d.startswith("batch cut in two: rows 0-1023 ccvm::cluster_kernel<2, false, 4, false>") and "| rows 1024-1099 ccvm::slab_kernel<2" in d
+    assert "rows 0-1535 ccvm::cluster_kernel<1, true, 3" in _describe(hip_lib, 1, 1600, 300, adam=1)
+    for solver, b, n in ((2, 1500, 500), (2, 2000, 500), (2, 1000, 500), (0, 1100, 640), (2, 1100, 256)):
+        assert "cut in two" not in _describe(hip_lib, solver, b, n), (solver, b, n)
     for solver, b, n in ((0, 2000, 1000), (0, 1800, 1000), (0, 1000, 1000), (0, 1000, 1500), (0, 900, 1000), (2, 3000, 1000)):
         assert "cut in two" not in _describe(hip_lib, solver, b, n), (solver, b, n)
     assert "cut in two" not in _describe(hip_lib, 2, 1100, 1000, per_variable_s=1)
@@ -91,7 +97,8 @@ def test_batches_cut_in_two(hip_lib, clean_env):
     plain = hip_lib.ccvm_status_offset(0, 1100, 1000) + 128
     assert hip_lib.ccvm_workspace_bytes(0, 1100, 1000) >= plain + hip_lib.ccvm_workspace_bytes(0, 1024, 1000) + hip_lib.ccvm_workspace_bytes(0, 76, 1000)
     assert hip_lib.ccvm_workspace_bytes(0, 1000, 1000) == hip_lib.ccvm_status_offset(0, 1000, 1000) + 128
-    assert hip_lib.ccvm_workspace_bytes(0, 1100, 500) == hip_lib.ccvm_status_offset(0, 1100, 500) + 128
+    assert hip_lib.ccvm_workspace_bytes(0, 1100, 640) == hip_lib.ccvm_status_offset(0, 1100, 640) + 128
+    assert hip_lib.ccvm_workspace_bytes(0, 1100, 500) > hip_lib.ccvm_status_offset(0, 1100, 500) + 128
 
 
 @pytest.mark.parametrize("geometry", ["64,2", "128,4", "256,1", "240,8", "32,1", "304,8"])
