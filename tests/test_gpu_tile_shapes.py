@@ -48,6 +48,9 @@ def test_every_tile_shape_matches_oracle(monkeypatch, ks, kind, n, b, t, adam):
 def test_default_tile_shapes_match_oracle(monkeypatch, kind, n, b, t, adam, ks):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
+    # (the shapes of a WHOLE batch: some of these batches are cut in two by default since round 4 -- MF N = 1300,
+    # B = 1000 into a resident grid of the persistent tile kernel plus 232 rows -- which tests/test_gpu_ptile.py covers)
+    monkeypatch.setenv("CCVM_AMD_SPLIT", "0")
     assert _ks(kind, b, n, adam is not None) == ks, _describe(kind, b, n, adam is not None)
     _check_against_oracle(kind, n, b, t, adam)
 
