@@ -166,7 +166,8 @@ int ccvm_unpack(const float* src, int src_ld,
 size_t ccvm_workspace_bytes(int solver, int B, int N);
 /* Byte offset, inside the workspace of ccvm_dl_run (solver 0) / ccvm_mf_run (1) / ccvm_langevin_run (2),
  * of a 128-byte line whose first 4 bytes are the run's status word; (size_t)-1 for the other entries.  The caller
- * zeroes the LINE once (a fresh workspace: simplest is to zero the whole workspace) and may read the status word after
+ * zeroes the WHOLE workspace once when it is fresh (the parts of a cut batch keep lines of their own behind the
+ * batch's workspace) and may read the status word after
  * synchronising the stream: 0 = ok; 1 = a bounded in-kernel wait of a persistent path whose workgroups exchange data
  * (column-cluster kernel, 256 < N <= 768; column-slab kernel, small batches above N = 256; persistent tile kernel, full
  * grids of 32 x 128 tiles above N = 768) gave up because its

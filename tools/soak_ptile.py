@@ -1,11 +1,15 @@
 """Soak of the persistent tile kernel's in-launch hand-over (developer tool): random (solver, Adam variant, N, B, steps,
 chunking, row offset) with the family forced; every case runs once as whole launches and once in random chunks (one-step
 chunks included: there the kernel boundary publishes the state) and must agree BIT FOR BIT, with a second stream
-hammering memory half of the time.   python tools/soak_ptile.py [seconds]"""
+hammering memory half of the time.   python tools/soak_ptile.py [seconds]
+SOAK_MODE=batches: the DEFAULT policy over batches of up to ~4 resident grids instead (slices of the batch, batches cut in
+two, the plans of the remainders; the cluster kernel's sizes included)."""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("CCVM_AMD_KERNEL", "ptile")
-os.environ.setdefault("CCVM_AMD_KS", "1")
+BATCHES = os.environ.get("SOAK_MODE") == "batches"
+if not BATCHES:
+    os.environ.setdefault("CCVM_AMD_KERNEL", "ptile")
+    os.environ.setdefault("CCVM_AMD_KS", "1")
 import torch
 import bench
 
@@ -24,6 +28,12 @@ while time.time() < t_end:
     nrb = rng.randint(1, max(1, 256 // ncb))
     b = max(1, nrb * 32 - rng.choice([0, 0, 1, 7, 24, 31]))
     t = rng.choice([2, 3, 8, 17, 40, 120, 400 if n <= 1100 else 60])
+    if BATCHES:
+        n = rng.choice([300, 384, 500, 512, 1000, 1000, 1024, 1100, 1200, 1500, 2000])
+        fit = 256 // ((n + 127) // 128) * 32 if n > 768 else 8 * (32 // ((n + 63) // 64)) * 32
+        b = rng.choice([fit + rng.randint(1, 400), 2 * fit + rng.randint(-40, 300), rng.randint(fit, 4 * fit + 200),
+                        3 * fit, 4 * fit + rng.randint(1, 64)])
+        t = rng.choice([2, 3, 8, 17, 40])
     chunks, left = [], t
     while left > 0:
         k = min(left, rng.choice([1, 1, 2, 5, 9, 33, t]))
