@@ -57,6 +57,12 @@ WORKLOADS = {
     # mid-size batches: the per-step tile kernel with 32 x 32 split-K tiles (a quarter of the chip or less with wider ones)
     "dl_n1000_b256": ("dl", 1000, 256),
     "langevin_n1000_b256": ("langevin", 1000, 256),
+    # the per-GPU shapes of configs 4 / 5 under strong scaling on 4 and 2 GPUs (--global-batch 8000 / 4096): batches of
+    # several rounds, run as slices of the batch on the persistent tile kernel (ccvm_abi.hip: plan_ptile)
+    "dl_n1000_b2000": ("dl", 1000, 2000),
+    "dl_n1000_b4000": ("dl", 1000, 4000),
+    "pl_n2000_b1024": ("pl", 2000, 1024),
+    "pl_n2000_b2048": ("pl", 2000, 2048),
 }
 SOLVER_ID = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
 SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example scripts' S (workloads.py)
