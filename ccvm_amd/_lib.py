@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -42,6 +42,7 @@ class EngineUnavailable(RuntimeError):
 
 RUN_WS_PADDED = 1  # ccvm_noise.flags: the workspace's scratch arrays still have zero padding (see ccvm_hip.h)
 RUN_NO_EXCHANGE = 2  # ccvm_noise.flags: no kernel whose workgroups wait for each other (cluster / slab)
+RUN_FORWARD = 4  # ccvm_noise.flags: this workspace has never run a step behind the call's first one (see ccvm_hip.h)
 
 
 class Noise(Structure):
@@ -79,6 +80,7 @@ class DlParams(Structure):
         ("pump_rate_flag", c_int32),
         ("reserved", c_int32),
         ("qsum", c_void_p),
+        ("schedule", c_void_p),
     ]
 
 
@@ -114,6 +116,7 @@ class LangevinParams(Structure):
         ("s_cols", c_void_p),
         ("qsum", c_void_p),
         ("s_full", c_void_p),
+        ("schedule", c_void_p),
     ]
 
 
@@ -157,6 +160,9 @@ SIGNATURES = {
     "ccvm_workspace_bytes_cols": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_status_offset": (c_size_t, [c_int, c_int, c_int]),
     "ccvm_column_sums": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "ccvm_schedule_bytes": (c_size_t, [c_int, c_int]),
+    "ccvm_dl_schedule": (c_int, [POINTER(DlParams), c_int, _P, _P]),
+    "ccvm_langevin_schedule": (c_int, [POINTER(LangevinParams), POINTER(Adam), c_int, _P, _P]),
     "ccvm_describe_launch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_size_t]),
     "ccvm_dl_run": (
         c_int,

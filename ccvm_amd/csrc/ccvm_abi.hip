@@ -626,6 +626,21 @@ int split_rows(int mode, int B, int N, const Tuning& tun) {
 __global__ void status_merge_kernel(unsigned* whole, unsigned* part) {
     if (*part) { *whole = *part; *part = 0u; }
 }
+// ---- schedule rows made once per run by the caller (ccvm_dl_schedule / ccvm_langevin_schedule) ------------------
+// A run call of a persistent path is then ONE launch: no schedule kernel in front of it (2 us + the 4-8 us a short
+// kernel cannot hide of the next one's dispatch: 9 of the 657 us of a 20-step call at the headline shape).  The
+// persistent tile kernel's flag lines must hold no step number beyond the call's first step: set here unless the
+// caller says the workspace has only ever run earlier steps (CCVM_RUN_FORWARD).
+__global__ void flags_init_kernel(unsigned* flags, int words, unsigned step0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) flags[i] = step0;
+}
+const float* given_rows(const float* schedule, const ccvm_noise* nz, int first, unsigned* flags, int words, hipStream_t st) {
+    if (!schedule) return nullptr;
+    if (flags && !(nz->flags & CCVM_RUN_FORWARD))
+        hipLaunchKernelGGL(flags_init_kernel, dim3((words + 255) / 256), dim3(256), 0, st, flags, words, (unsigned)first);
+    return schedule + (size_t)first * TABLE_WORDS;
+}
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
 int ptile_sched_grid(int k, int nrb) { return (std::max(k, nrb * PT_FLAG_WORDS) + 255) / 256; }
 // `area`: what follows the schedule table in the workspace ([flag lines][...][status line])
@@ -633,7 +648,7 @@ void persist_adam(PersistArgs& pa, AdamSched& sc, const ccvm_adam* adam, bool us
 // `par`: which of the two input buffers the launch's first step reads.  MF: `st0` / `st1` = mu / sigma, `carry` = the
 // normals of the launch's first step (mf_prepare_kernel).
 template <int MODE>
-int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], const ccvm_noise* nz, float* table,
+int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], const ccvm_noise* nz, const float* table,
               void* area, unsigned* status, int step0, int done, int k, const Tuning& tun, hipStream_t st,
               const char* fn, int par, const ccvm_adam* adam = nullptr, float* st0 = nullptr, float* st1 = nullptr,
               const float* carry = nullptr) {
@@ -770,6 +785,45 @@ size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
     const size_t ld = (size_t)ccvm_ld(N);
     const size_t base = ccvm_workspace_bytes(solver, B, N);
     return (solver == 1 || solver == 2) ? base + ld * ld * sizeof(float) : base;
+}
+
+size_t ccvm_schedule_bytes(int solver, int T) {
+    return (solver == 0 || solver == 2) && T > 0 ? (size_t)T * TABLE_WORDS * sizeof(float) : 0;
+}
+
+// The rows of a whole run, by the kernels that make them per chunk inside the run calls (same device code, same bits).
+int ccvm_dl_schedule(const ccvm_dl_params* p, int T, float* table, void* stream) {
+    const char* fn = "ccvm_dl_schedule";
+    if (!p || !table || T <= 0) return fail(CCVM_E_INVALID, "%s: NULL argument or T <= 0", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0)) return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0", fn);
+    const double ul = p->upper - p->lower;
+    const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
+    DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T, 0, T};
+    hipLaunchKernelGGL(dl_schedule_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, sc, table);
+    CCVM_CHECK_LAUNCH(fn);
+    return CCVM_OK;
+}
+
+int ccvm_langevin_schedule(const ccvm_langevin_params* p, const ccvm_adam* adam, int T, float* table, void* stream) {
+    const char* fn = "ccvm_langevin_schedule";
+    if (!p || !table || T <= 0) return fail(CCVM_E_INVALID, "%s: NULL argument or T <= 0", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->s_cols || p->s_full || p->S > 0))
+        return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0", fn);
+    const double S_eff = (p->s_cols || p->s_full) ? 1.0 : p->S;  // see ccvm_mf_run
+    const double ul = p->upper - p->lower;
+    const bool use_adam = adam && adam->enabled;
+    AdamSched asc;
+    std::memset(&asc, 0, sizeof(asc));
+    if (use_adam) {
+        asc.enabled = 1;
+        asc.beta1 = adam->beta1;
+        asc.beta2 = adam->beta2;
+        asc.use_v = adam->beta2 != 1.0;
+    }
+    LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T, 0, T, asc};
+    hipLaunchKernelGGL(lv_schedule_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, sc, table);
+    CCVM_CHECK_LAUNCH(fn);
+    return CCVM_OK;
 }
 
 int ccvm_column_sums(const float* Q, int N, int ld, float* qsum, void* ws, size_t ws_bytes, void* stream) {
@@ -936,8 +990,13 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             pa.step0 = step0 + done;
+            pa.table = rows;
             pa.nsteps = k;
             if (pa.replay) {
                 pa.w0 = nz->w0 + (size_t)done * N * B;
@@ -961,8 +1020,13 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             sa.step0 = step0 + done;
+            sa.table = rows;
             sa.nsteps = k;
             if (sa.replay) {
                 sa.w0 = nz->w0 + (size_t)done * N * B;
@@ -988,8 +1052,13 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             ca.step0 = step0 + done;
+            ca.table = rows;
             ca.nsteps = k;
             if (ca.replay) {
                 ca.w0 = nz->w0 + (size_t)done * N * B;
@@ -1011,8 +1080,12 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            hipLaunchKernelGGL(dl_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
-            if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn,
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(dl_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
+            if ((rc = run_ptile<MODE_DL>(a, bufc, bufs, nz, rows, after + table_bytes(), status, step0, done, k, tun, st, fn,
                                          done & 1)))  // launches of a call alternate the buffers like its steps
                 return rc;
         }
@@ -1496,8 +1569,13 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             pa.step0 = step0 + done;
+            pa.table = rows;
             pa.nsteps = k;
             if (pa.replay) pa.w0 = nz->w0 + (size_t)done * N * B;
             rc = use_adam ? launch_persist<MODE_LANGEVIN, true>(pa, st, fn)
@@ -1523,8 +1601,13 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             sa.step0 = step0 + done;
+            sa.table = rows;
             sa.nsteps = k;
             if (sa.replay) sa.w0 = nz->w0 + (size_t)done * N * B;
             slab_launch_lv(sa, sp, st);
@@ -1550,8 +1633,13 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             ca.step0 = step0 + done;
+            ca.table = rows;
             ca.nsteps = k;
             if (ca.replay) ca.w0 = nz->w0 + (size_t)done * N * B;
             cluster_launch_lv(ca, use_adam, st);
@@ -1572,8 +1660,12 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            hipLaunchKernelGGL(lv_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
-            if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st,
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(lv_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
+            if ((rc = run_ptile<MODE_LANGEVIN>(a, buf, none, nz, rows, after + table_bytes(), status, step0, done, k, tun, st,
                                                fn, done & 1, adam)))
                 return rc;
         }

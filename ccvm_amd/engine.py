@@ -395,6 +395,20 @@ class Trajectories:
                 if float(adam["beta2"]) != 1.0:
                     self.adam_v = zeros()
             self.adam = _adam_struct(adam, self.adam_m, self.adam_v)
+            # The schedule rows of the whole run, made once (DL, Langevin / pumped Langevin: ccvm_hip.h `schedule`):
+            # every run call of a persistent path is then one kernel launch instead of a schedule kernel plus the
+            # launch (9 of the 657 us of a 20-step call at the headline shape, a quarter of one at N = 100).
+            self._schedule = None
+            sched_bytes = self.lib.ccvm_schedule_bytes(self._SOLVER_ID[kind], self.t)
+            if sched_bytes and os.environ.get("CCVM_AMD_SCHEDULE", "1") != "0":
+                self._schedule = torch.empty((sched_bytes // 4,), dtype=torch.float32, device=self.device)
+                if kind == "dl":
+                    rc = self.lib.ccvm_dl_schedule(ctypes.byref(cp), self.t, _ptr(self._schedule), _stream_ptr())
+                else:
+                    rc = self.lib.ccvm_langevin_schedule(ctypes.byref(cp), ctypes.byref(self.adam), self.t,
+                                                         _ptr(self._schedule), _stream_ptr())
+                _lib.check(rc, "ccvm_schedule")
+                cp.schedule = self._schedule.data_ptr()
             size_of = self.lib.ccvm_workspace_bytes_cols if self.s_cols is not None else self.lib.ccvm_workspace_bytes
             ws_bytes = size_of(self._SOLVER_ID[kind], self.b, self.n)
             # zeroed: the workspace holds the run's status word (ccvm_status_offset), which run calls never clear
@@ -446,6 +460,10 @@ class Trajectories:
             nz.flags |= _lib.RUN_WS_PADDED
         if self.no_exchange:
             nz.flags |= _lib.RUN_NO_EXCHANGE
+        else:
+            # this object's run calls only ever move forward on its workspace (a recovered time-out goes back, and stays
+            # off the kernels that care: no_exchange)
+            nz.flags |= _lib.RUN_FORWARD
         tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
         if self.kind == "dl":
             rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,

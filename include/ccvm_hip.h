@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 8  /* 8: workspaces above N = 768 carry the persistent tile kernel's flag lines */
+#define CCVM_ABI_VERSION 9  /* 8: workspaces above N = 768 carry the persistent tile kernel's flag lines */
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -68,6 +68,11 @@ typedef enum ccvm_noise_mode {
  * a caller sets to repeat a chunk whose status word reported a time-out (ccvm_status_offset): same noise, same
  * result up to the summation order of the contraction. */
 #define CCVM_RUN_NO_EXCHANGE 2
+/* CCVM_RUN_FORWARD: the caller guarantees that this workspace has never run a step behind this call's first one (a
+ * trajectory advanced chunk by chunk on a workspace that started zeroed; NOT a re-run of earlier steps).  Only read
+ * together with a caller-made schedule table (`schedule` in the parameters): the persistent tile kernel's flag lines
+ * then need no initialising launch, and the run call of a persistent path is a single kernel launch. */
+#define CCVM_RUN_FORWARD 4
 
 typedef struct ccvm_noise {
     int32_t mode;        /* ccvm_noise_mode */
@@ -104,6 +109,10 @@ typedef struct ccvm_dl_params {
     int32_t reserved;
     const float* qsum;       /* column sums of Q from ccvm_column_sums (ld floats, device), or NULL: computed by
                                 every run call (two small kernels, ~15 us: worth passing for short chunks) */
+    const float* schedule;   /* the schedule rows of the WHOLE run from ccvm_dl_schedule (device, ccvm_schedule_bytes),
+                                made once with these parameters and the run calls' T, or NULL: the rows of a call's
+                                steps are made by a small kernel in front of every launch of a persistent path
+                                (~9 us per call at the headline shape: worth passing for short chunks) */
 } ccvm_dl_params;
 
 /* MF-CCVM: reference mf_solver.py:493-593 (_solve), :595-764 (_solve_adam),
@@ -139,6 +148,8 @@ typedef struct ccvm_langevin_params {
                                 pumped_langevin_solver.py:519-524); NULL = scalar S */
     const float* qsum;       /* as in ccvm_dl_params */
     const float* s_full;     /* as in ccvm_mf_params (langevin_solver.py:630-635, pumped_langevin_solver.py:519-524) */
+    const float* schedule;   /* as in ccvm_dl_params, from ccvm_langevin_schedule (made with the SAME ccvm_adam
+                                settings the run calls pass), or NULL */
 } ccvm_langevin_params;
 
 /* ---- library / layout ------------------------------------------------------- */
@@ -179,6 +190,15 @@ size_t ccvm_workspace_bytes(int solver, int B, int N);
 size_t ccvm_status_offset(int solver, int B, int N);
 /* The same plus room for the row-scaled copy of Q a run with per-variable saturation (s_cols) makes. */
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
+
+/* The per-step schedule scalars of a whole run (T steps: pump and noise ramps, dl_solver.py:524-527;
+ * pumped_langevin_solver.py:279-282; Adam bias corrections, langevin_solver.py:519-540), made once on the device in
+ * fp64 exactly as the run calls make them per chunk: pass `table` as `schedule` in the parameters of every run call of
+ * that run (same parameters, same T, same Adam settings).  ccvm_schedule_bytes: bytes of `table` for solver 0 (DL) and
+ * 2 (Langevin / pumped Langevin); 0 for the others (MF's rows depend on where a call ends: made per call). */
+size_t ccvm_schedule_bytes(int solver, int T);
+int ccvm_dl_schedule(const ccvm_dl_params* p, int T, float* table, void* stream);
+int ccvm_langevin_schedule(const ccvm_langevin_params* p, const ccvm_adam* adam, int T, float* table, void* stream);
 
 /* Column sums of Q (the constant term of the folded affine input map: (x a + b) @ Q = a (x @ Q) + b colsum(Q)),
  * deterministic two-pass reduction; qsum: ld floats.  Optional: pass the result in the run parameters' `qsum`

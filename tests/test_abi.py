@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 8
+    assert hip_lib.ccvm_abi_version() == 9
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
@@ -80,11 +80,18 @@ def test_struct_layouts_match_the_header():
 
     assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.Adam) == 4 + 4 + 3 * 8 + 2 * 8
-    assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8 + 8              # ... + qsum
+    assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8 + 8 + 8          # ... + qsum + schedule
     assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8 + 8 + 8          # ... + s_cols + qsum + s_full
-    assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8 + 8 + 8 + 8    # ... + s_cols + qsum + s_full
+    assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8 + 8 + 8 + 8 + 8  # ... + s_cols + qsum + s_full + schedule
     assert ctypes.sizeof(_lib.FinalizeParams) == 9 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.SolutionStats) == 4 + 7 * 4 + 4 + 4
+
+
+def test_schedule_table_sizes(hip_lib):
+    """The schedule rows of a whole run (ccvm_dl_schedule / ccvm_langevin_schedule): 16 words per step; MF makes its
+    rows per call (they depend on where the call ends)."""
+    assert hip_lib.ccvm_schedule_bytes(0, 1500) == 1500 * 64 == hip_lib.ccvm_schedule_bytes(2, 1500)
+    assert hip_lib.ccvm_schedule_bytes(1, 1500) == 0 and hip_lib.ccvm_schedule_bytes(0, 0) == 0
 
 
 def test_describe_launch_names_the_instantiation(hip_lib):
