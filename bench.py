@@ -46,6 +46,8 @@ WORKLOADS = {
     "mf_n500_b1000": ("mf", 500, 1000),
     "langevin_n500_b1000": ("langevin", 500, 1000),
     "pl_n2000_b512": ("pl", 2000, 512),
+    "langevin_n1000_b1000": ("langevin", 1000, 1000),  # the one-stream solvers at the headline's size
+    "mf_n1000_b1000": ("mf", 1000, 1000),
     # small batches (the reference runs any batch_size through the same einsum, dl_solver.py:145-153): the
     # column-slab kernel, Q resident in registers chip-wide (ccvm_amd/csrc/ccvm_slab.h)
     "dl_n1000_b1": ("dl", 1000, 1),

@@ -527,7 +527,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
 // ---- persistent streamed-Q tile kernel (ccvm_ptile.h): the 32 x 128 tile grid kept resident over a chunk --------
 // Applies where the per-step kernel would run 32 x 128 tiles (`a` = the launch plan of base_args) as ONE round of
 // workgroups that fills at least three quarters of the chip (every workgroup resident: its workgroups wait for each
-// other), every solver and Adam variant, without per-variable saturation -- chunks of any
+// other), every solver and Adam variant, scalar or per-variable saturation -- chunks of any
 // length, one step included: the kernel family fixes the summation order of a column's contraction, and a run's
 // result must not depend on how the caller chunks it.  The headline (DL N = 1000, B = 1000: 32 x 8 = 256) and config 5 per GPU (PL N = 2000, B = 512:
 // 16 x 16 = 256) are such shapes.
@@ -544,7 +544,8 @@ struct PtilePlan {
 };
 PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     PtilePlan p;
-    if (!tun.ptile || vs || a.N <= CL_MAX_N) return p;
+    (void)vs;  // per-variable saturation: a run-time form inside the kernel (Q = the row-scaled copy, as for the step kernel)
+    if (!tun.ptile || a.N <= CL_MAX_N) return p;
     const ChipGeometry chip = chip_of(tun);
     const int nrb = (a.B + BM - 1) / BM, ncb = (a.N + BN - 1) / BN;
     if (ncb > PT_FLAG_WORDS || ncb > chip.cus) return p;
@@ -678,6 +679,7 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
             pa.av = tmp.av ? tmp.av + off : nullptr;
         }
         pa.Q = a.Q; pa.V = a.V; pa.qsum = a.qsum; pa.table = table;
+        pa.s_cols = a.s_cols;
         pa.x0[0] = x0[0] + off; pa.x0[1] = x0[1] + off;
         pa.x1[0] = x1[0] ? x1[0] + off : nullptr; pa.x1[1] = x1[1] ? x1[1] + off : nullptr;
         // (the flag lines of ALL row blocks were set to step0 by this chunk's schedule kernel: ptile_sched_grid)
@@ -881,16 +883,18 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
         if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0, solver); plan.slices == 1) {
-            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
-                          solver, ad ? "true" : "false", a.nrb * a.ncb, WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
+            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s%s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
+                          solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", a.nrb * a.ncb,
+                          WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
             return CCVM_OK;
         } else if (plan.slices > 1) {
             StepArgs g = a;
             g.B = plan.rbs * BM;
             g.ks = 1;
             set_grid(g, tun);
-            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s> %d slices of the batch one after the other, grid %d x %d threads each (up to %d row blocks x %d column blocks resident), up to %d steps per launch",
-                          solver, ad ? "true" : "false", plan.slices, g.nrb * g.ncb, WG_THREADS, g.nrb, g.ncb, TABLE_STEPS);
+            std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s%s> %d slices of the batch one after the other, grid %d x %d threads each (up to %d row blocks x %d column blocks resident), up to %d steps per launch",
+                          solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", plan.slices,
+                          g.nrb * g.ncb, WG_THREADS, g.nrb, g.ncb, TABLE_STEPS);
             return CCVM_OK;
         }
         std::snprintf(buf, buf_len, "ccvm::step_kernel<%d, %s, 0, %d, %s, 0> grid %d x %d threads, XCD rectangle %d x %d, 1 step per launch",

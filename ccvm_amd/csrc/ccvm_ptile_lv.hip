@@ -5,7 +5,13 @@
 
 namespace ccvm {
 void ptile_launch_lv(const PtileArgs& a, bool adam, hipStream_t st) {
-    if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, true>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, false>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
+    const dim3 grid(a.nrb * a.ncb), block(WG_THREADS);
+    if (a.s_cols) {  // per-variable saturation
+        if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, true, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, false, false, true>), grid, block, 0, st, a);
+    } else {
+        if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((ptile_kernel<MODE_LANGEVIN, false>), grid, block, 0, st, a);
+    }
 }
 }  // namespace ccvm

@@ -4,7 +4,13 @@
 
 namespace ccvm {
 void ptile_launch_mf(const PtileArgs& a, bool adam, hipStream_t st) {
-    if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_MF, true>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((ptile_kernel<MODE_MF, false>), dim3(a.nrb * a.ncb), dim3(WG_THREADS), 0, st, a);
+    const dim3 grid(a.nrb * a.ncb), block(WG_THREADS);
+    if (a.s_cols) {  // per-variable saturation
+        if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_MF, true, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((ptile_kernel<MODE_MF, false, false, true>), grid, block, 0, st, a);
+    } else {
+        if (adam) hipLaunchKernelGGL((ptile_kernel<MODE_MF, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((ptile_kernel<MODE_MF, false>), grid, block, 0, st, a);
+    }
 }
 }  // namespace ccvm

@@ -214,6 +214,57 @@ def test_time_out_in_a_part_of_a_cut_batch_recovers_the_whole_batch(monkeypatch)
     assert again.fallbacks == 0 and not torch.equal(again.compact("c").cpu(), want)
 
 
+@pytest.mark.parametrize("kind,n,b,adam", [("mf", 1000, 1000, None), ("pl", 2000, 512, "second_moment"),
+                                           ("langevin", 1000, 2000, None), ("mf", 1100, 777, "add_assign")])
+def test_per_variable_saturation_on_the_persistent_tile_kernel(monkeypatch, kind, n, b, adam):
+    """S as a 1-D tensor of length N (mf_solver.py:834-839, langevin_solver.py:630-635): the row-scaled copy of Q
+    streamed instead of Q, 1 / S_j and the clamp bound per column in the epilogue -- against the per-step kernel's VS
+    instantiation (two summation orders: the stated tolerance), chunking bit-exact, and S_j = S for every column
+    against the scalar run (1 / S folded into Q's rows instead of the input map: the stated tolerance)."""
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+    from test_gpu_cluster import ATOL_X
+
+    monkeypatch.setenv("CCVM_AMD_KS", "1")
+    q, v, _ = scaled_qv(n, kind)
+    prob = engine.DeviceProblem(q, v)
+    sat = torch.rand(n, generator=torch.Generator().manual_seed(5)) * 2.0 + 0.25
+    hp, t = _ADAMS[adam], 12
+
+    def run(kernel, S, chunks):
+        monkeypatch.setenv("CCVM_AMD_KERNEL", kernel)
+        p = dict(EXAMPLE_PARAMS[kind], S=S)
+        if kind == "mf":
+            p["g"] = 0.01
+        else:
+            p["use_pump"] = kind == "pl"
+        traj = engine.Trajectories(prob, b, "mf" if kind == "mf" else "langevin", t, p, (0.0, 1.0),
+                                   engine.NoiseSpec(mode="fused", seed=8, row_offset=3), adam=hp)
+        assert ("ptile_kernel" in traj_describe(traj)) == (kernel == "ptile")
+        for k in chunks:
+            traj.advance(k)
+        return _state(traj)
+
+    def traj_describe(traj):
+        import ctypes
+        buf = ctypes.create_string_buffer(1024)
+        assert traj.lib.ccvm_describe_launch(traj._SOLVER_ID[traj.kind], traj.b, traj.n, 1 if hp else 0,
+                                             1 if traj.s_cols is not None else 0, buf, 1024) == 0
+        return buf.value.decode()
+
+    got = run("ptile", sat, [t])
+    parts = run("ptile", sat, [1, 4, 1, 6])
+    want = run("noptile", sat, [t])
+    for name in want:
+        assert torch.equal(got[name], parts[name]), name
+        scale = max(1.0, float(want[name].abs().max()))
+        assert float((got[name] - want[name]).abs().max()) <= ATOL_X * (n / 20.0) ** 0.5 * scale, (kind, name)
+    s0 = float(EXAMPLE_PARAMS[kind]["S"])
+    flat, scalar = run("ptile", torch.full((n,), s0), [t]), run("ptile", s0, [t])
+    for name in scalar:
+        assert float((flat[name] - scalar[name]).abs().max()) <= ATOL_X * (n / 20.0) ** 0.5 * max(1.0, float(scalar[name].abs().max())), name
+
+
 def test_default_policy_is_chunk_invariant_at_the_headline_shape(monkeypatch):
     """A run's result must not depend on how the caller chunks it (evolution sampling, replay-noise staging): one-step
     chunks take the persistent kernel too (the family fixes the summation order)."""

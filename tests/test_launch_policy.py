@@ -189,6 +189,9 @@ def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env
     assert _describe(hip_lib, 0, 1000, 1100).startswith("ccvm::step_kernel<0, false, 0, 2")
     clean_env.delenv("CCVM_AMD_SPLIT")
     assert "ptile_kernel" not in _describe(hip_lib, 0, 512, 1000)          # half the chip: 32 x 64 tiles
+    # per-variable saturation (MF, Langevin): the kernel's VS instantiation
+    assert "ptile_kernel<1, false, false, true> grid 256" in _describe(hip_lib, 1, 1000, 1000, per_variable_s=1)
+    assert "ptile_kernel<2, true, false, true> 2 slices" in _describe(hip_lib, 2, 2000, 1000, adam=1, per_variable_s=1)
     for off in ("tile", "nocluster", "noptile"):
         clean_env.setenv("CCVM_AMD_KERNEL", off)
         assert "step_kernel" in _describe(hip_lib, 0, 1000, 1000), off
