@@ -40,6 +40,10 @@ CASES = [
     ("extra_mf_n1000_b1000", "mf", 1000, 1000, 400, None, None, 3e-4, 1e-5),
     ("extra_mf_n1000_b1000_adam", "mf", 1000, 1000, 200, None, ADAM_A, 3e-4, 1e-5),
     ("extra_langevin_n1000_b1000_adam", "langevin", 1000, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
+    # the per-GPU shapes of configs 4 / 5 under strong scaling on 4 GPUs (--global-batch 8000 / 4096): batches of two
+    # rounds, run as two slices of the batch on the persistent tile kernel (replay blocks pitched by the whole batch)
+    ("scaling_dl_n1000_b2000", "dl", 1000, 2000, 300, None, None, 3e-4, 1e-5),
+    ("scaling_pl_n2000_b1024_adam_pp", "pl", 2000, 1024, 100, "adam", None, 3e-4, 1e-5),
 ]
 
 
