@@ -99,6 +99,7 @@ class MfParams(Structure):
         ("s_cols", c_void_p),
         ("qsum", c_void_p),
         ("s_full", c_void_p),
+        ("schedule", c_void_p),
     ]
 
 
@@ -162,6 +163,7 @@ SIGNATURES = {
     "ccvm_column_sums": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
     "ccvm_schedule_bytes": (c_size_t, [c_int, c_int]),
     "ccvm_dl_schedule": (c_int, [POINTER(DlParams), c_int, _P, _P]),
+    "ccvm_mf_schedule": (c_int, [POINTER(MfParams), POINTER(Adam), c_int, _P, _P]),
     "ccvm_langevin_schedule": (c_int, [POINTER(LangevinParams), POINTER(Adam), c_int, _P, _P]),
     "ccvm_describe_launch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_size_t]),
     "ccvm_dl_run": (

@@ -790,7 +790,7 @@ size_t ccvm_workspace_bytes_cols(int solver, int B, int N) {
 }
 
 size_t ccvm_schedule_bytes(int solver, int T) {
-    return (solver == 0 || solver == 2) && T > 0 ? (size_t)T * TABLE_WORDS * sizeof(float) : 0;
+    return solver >= 0 && solver <= 2 && T > 0 ? (size_t)T * TABLE_WORDS * sizeof(float) : 0;
 }
 
 // The rows of a whole run, by the kernels that make them per chunk inside the run calls (same device code, same bits).
@@ -802,6 +802,27 @@ int ccvm_dl_schedule(const ccvm_dl_params* p, int T, float* table, void* stream)
     const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
     DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T, 0, T};
     hipLaunchKernelGGL(dl_schedule_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, sc, table);
+    CCVM_CHECK_LAUNCH(fn);
+    return CCVM_OK;
+}
+
+int ccvm_mf_schedule(const ccvm_mf_params* p, const ccvm_adam* adam, int T, float* table, void* stream) {
+    const char* fn = "ccvm_mf_schedule";
+    if (!p || !table || T <= 0) return fail(CCVM_E_INVALID, "%s: NULL argument or T <= 0", fn);
+    if (!(p->upper > p->lower) || !(p->dt > 0) || !(p->s_cols || p->s_full || p->S > 0) || !(p->j > 0))
+        return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0, j > 0", fn);
+    const double S_eff = (p->s_cols || p->s_full) ? 1.0 : p->S;  // see ccvm_mf_run
+    const bool use_adam = adam && adam->enabled;
+    AdamSched asc;
+    std::memset(&asc, 0, sizeof(asc));
+    if (use_adam) {
+        asc.enabled = 1;
+        asc.beta1 = adam->beta1;
+        asc.beta2 = adam->beta2;
+        asc.use_v = adam->beta2 != 1.0;
+    }
+    MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, p->upper - p->lower, p->pump_rate_flag, T, 0, T, asc};
+    hipLaunchKernelGGL(mf_schedule_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, sc, table);
     CCVM_CHECK_LAUNCH(fn);
     return CCVM_OK;
 }
@@ -1275,8 +1296,13 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             pa.step0 = step0 + done;
+            pa.table = rows;
             pa.nsteps = k;
             pa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
             if (replay) pa.w0 = nz->w0 + (size_t)done * N * B;
@@ -1307,8 +1333,13 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             sa.step0 = step0 + done;
+            sa.table = rows;
             sa.nsteps = k;
             sa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
             if (replay) sa.w0 = nz->w0 + (size_t)done * N * B;
@@ -1340,8 +1371,13 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
             ca.step0 = step0 + done;
+            ca.table = rows;
             ca.nsteps = k;
             ca.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
             if (replay) ca.w0 = nz->w0 + (size_t)done * N * B;
@@ -1390,8 +1426,12 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             prepare(step0 + done, done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc,
                        reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            hipLaunchKernelGGL(mf_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
-            if ((rc = run_ptile<MODE_MF>(a, mt, none, nz, table, after + table_bytes(), status, step0, done, k, tun, st, fn, 0,
+            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            if (!rows) {
+                hipLaunchKernelGGL(mf_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
+                rows = table;
+            }
+            if ((rc = run_ptile<MODE_MF>(a, mt, none, nz, rows, after + table_bytes(), status, step0, done, k, tun, st, fn, 0,
                                          adam, mu, sigma, carry)))
                 return rc;
             last_k = k;

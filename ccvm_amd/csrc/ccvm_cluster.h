@@ -700,7 +700,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     s0[s][i] = mun;
                     s1[s][i] = sgn;
                     // the last step's input is what mu_tilde_out returns: no new measurement after it
-                    const bool nxt = k.has_next;
+                    const bool nxt = has_next;
                     mt[s][i] = nxt ? clampf(__builtin_fmaf(k.k_next, nz[i], s0[s][i]), -bound, bound) : mt[s][i];
                     wc[s][i] = nxt ? nz[i] : wc[s][i];
                 }

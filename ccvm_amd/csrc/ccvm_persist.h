@@ -306,7 +306,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
                     }
                 }
             } else if constexpr (MODE == MODE_MF) {
-                if (reinterpret_cast<const MfScalars*>(trow)->has_next) stream_normals(step + 1, it + 1, nz0);
+                if (it + 1 < a.nsteps) stream_normals(step + 1, it + 1, nz0);  // (the launch's last step draws none)
             } else {
                 stream_normals(step, it, nz0);
             }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
                 s0[e] = ok[e] ? mun : s0[e];
                 s1[e] = ok[e] ? sgn : s1[e];
                 // the last step's input is what mu_tilde_out returns: no new measurement after it
-                const bool nxt = ok[e] && k.has_next;
+                const bool nxt = ok[e] && it + 1 < a.nsteps;
                 mt[e] = nxt ? clampf(__builtin_fmaf(k.k_next, wn[e], s0[e]), -bound, bound) : mt[e];
                 wc[e] = nxt ? wn[e] : wc[e];
             }

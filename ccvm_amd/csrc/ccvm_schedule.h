@@ -65,7 +65,6 @@ __global__ void mf_schedule_kernel(const MfSched p, float* table) {
     const double j_n = p.j * exp(-(double)(i + 2) / (double)p.T * 3.0);
     const double rate = p.pump_rate_flag ? (double)(i + 1) / (double)p.T : 1.0;
     const double p_i = p.pump * rate + 1.0 + j_i;
-    const bool has_next = it + 1 < p.nsteps;
     MfScalars k;
     k.a0 = (float)(-(1.0 + j_i) + p_i);
     k.g2 = (float)(p.g * p.g);
@@ -76,9 +75,11 @@ __global__ void mf_schedule_kernel(const MfSched p, float* table) {
     k.sqrt_j = (float)sqrt(j_i);
     k.inv_sdt = (float)(1.0 / sdt);
     k.dt = (float)p.dt;
-    k.k_next = has_next ? (float)(sqrt(1.0 / (4.0 * j_n)) / sdt) : 0.0f;
+    // (k_next and has_next of a row are the WHOLE-RUN values: the persistent kernels decide "the launch's last step"
+    // themselves -- it + 1 == nsteps -- so that one table serves every way of chunking the run)
+    k.k_next = (float)(sqrt(1.0 / (4.0 * j_n)) / sdt);
     k.S = (float)p.S;
-    k.has_next = has_next;
+    k.has_next = p.step0 + it + 1 < p.T;
     float* row = table + (size_t)it * TABLE_WORDS;
     *reinterpret_cast<MfScalars*>(row) = k;
     adam_bias(p.ad, i, row);

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
                     s0[p][e] = mun;
                     s1[p][e] = sgn;
                     // the last step's input is what mu_tilde_out returns: no new measurement after it
-                    const bool nxt = k.has_next;
+                    const bool nxt = has_next;
                     mt[p][e] = nxt ? clampf(__builtin_fmaf(k.k_next, nz[p][e], s0[p][e]), -bound, bound) : mt[p][e];
                     wc[p][e] = nxt ? nz[p][e] : wc[p][e];
                 }

@@ -403,7 +403,7 @@ class Trajectories:
                 if float(adam["beta2"]) != 1.0:
                     self.adam_v = zeros()
             self.adam = _adam_struct(adam, self.adam_m, self.adam_v)
-            # The schedule rows of the whole run, made once (DL, Langevin / pumped Langevin: ccvm_hip.h `schedule`):
+            # The schedule rows of the whole run, made once (ccvm_hip.h `schedule`):
             # every run call of a persistent path is then one kernel launch instead of a schedule kernel plus the
             # launch (9 of the 657 us of a 20-step call at the headline shape, a quarter of one at N = 100).
             self._schedule = None
@@ -413,8 +413,8 @@ class Trajectories:
                 if kind == "dl":
                     rc = self.lib.ccvm_dl_schedule(ctypes.byref(cp), self.t, _ptr(self._schedule), _stream_ptr())
                 else:
-                    rc = self.lib.ccvm_langevin_schedule(ctypes.byref(cp), ctypes.byref(self.adam), self.t,
-                                                         _ptr(self._schedule), _stream_ptr())
+                    make = self.lib.ccvm_mf_schedule if kind == "mf" else self.lib.ccvm_langevin_schedule
+                    rc = make(ctypes.byref(cp), ctypes.byref(self.adam), self.t, _ptr(self._schedule), _stream_ptr())
                 _lib.check(rc, "ccvm_schedule")
                 cp.schedule = self._schedule.data_ptr()
             size_of = self.lib.ccvm_workspace_bytes_cols if self.s_cols is not None else self.lib.ccvm_workspace_bytes

@@ -133,6 +133,8 @@ typedef struct ccvm_mf_params {
      * s_cols.  1 / S_bk then sits inside the GEMM's input map per element: this rare input runs on a composed
      * path (one GEMM launch + one elementwise launch per step) instead of the fused kernels. */
     const float* s_full;
+    const float* schedule;   /* as in ccvm_dl_params, from ccvm_mf_schedule (made with the SAME ccvm_adam settings the
+                                run calls pass), or NULL */
 } ccvm_mf_params;
 
 /* Langevin (use_pump = 0): reference langevin_solver.py:368-435, :437-561, :117-166.
@@ -192,12 +194,13 @@ size_t ccvm_status_offset(int solver, int B, int N);
 size_t ccvm_workspace_bytes_cols(int solver, int B, int N);
 
 /* The per-step schedule scalars of a whole run (T steps: pump and noise ramps, dl_solver.py:524-527;
- * pumped_langevin_solver.py:279-282; Adam bias corrections, langevin_solver.py:519-540), made once on the device in
+ * mf_solver.py:550-559, pumped_langevin_solver.py:279-282; Adam bias corrections, langevin_solver.py:519-540), made once on the device in
  * fp64 exactly as the run calls make them per chunk: pass `table` as `schedule` in the parameters of every run call of
- * that run (same parameters, same T, same Adam settings).  ccvm_schedule_bytes: bytes of `table` for solver 0 (DL) and
- * 2 (Langevin / pumped Langevin); 0 for the others (MF's rows depend on where a call ends: made per call). */
+ * that run (same parameters, same T, same Adam settings).  ccvm_schedule_bytes: bytes of `table` for solver 0 (DL),
+ * 1 (MF) and 2 (Langevin / pumped Langevin); 0 for the other entries. */
 size_t ccvm_schedule_bytes(int solver, int T);
 int ccvm_dl_schedule(const ccvm_dl_params* p, int T, float* table, void* stream);
+int ccvm_mf_schedule(const ccvm_mf_params* p, const ccvm_adam* adam, int T, float* table, void* stream);
 int ccvm_langevin_schedule(const ccvm_langevin_params* p, const ccvm_adam* adam, int T, float* table, void* stream);
 
 /* Column sums of Q (the constant term of the folded affine input map: (x a + b) @ Q = a (x @ Q) + b colsum(Q)),

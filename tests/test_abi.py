@@ -81,17 +81,16 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.Adam) == 4 + 4 + 3 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8 + 8 + 8          # ... + qsum + schedule
-    assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8 + 8 + 8          # ... + s_cols + qsum + s_full
+    assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8 + 8 + 8 + 8      # ... + s_cols + qsum + s_full + schedule
     assert ctypes.sizeof(_lib.LangevinParams) == 7 * 8 + 8 + 8 + 8 + 8 + 8  # ... + s_cols + qsum + s_full + schedule
     assert ctypes.sizeof(_lib.FinalizeParams) == 9 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.SolutionStats) == 4 + 7 * 4 + 4 + 4
 
 
 def test_schedule_table_sizes(hip_lib):
-    """The schedule rows of a whole run (ccvm_dl_schedule / ccvm_langevin_schedule): 16 words per step; MF makes its
-    rows per call (they depend on where the call ends)."""
-    assert hip_lib.ccvm_schedule_bytes(0, 1500) == 1500 * 64 == hip_lib.ccvm_schedule_bytes(2, 1500)
-    assert hip_lib.ccvm_schedule_bytes(1, 1500) == 0 and hip_lib.ccvm_schedule_bytes(0, 0) == 0
+    """The schedule rows of a whole run (ccvm_dl_schedule / ccvm_mf_schedule / ccvm_langevin_schedule): 16 words per step."""
+    assert hip_lib.ccvm_schedule_bytes(0, 1500) == 1500 * 64 == hip_lib.ccvm_schedule_bytes(2, 1500) == hip_lib.ccvm_schedule_bytes(1, 1500)
+    assert hip_lib.ccvm_schedule_bytes(3, 1500) == 0 and hip_lib.ccvm_schedule_bytes(0, 0) == 0
 
 
 def test_describe_launch_names_the_instantiation(hip_lib):

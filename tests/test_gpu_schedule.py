@@ -1,5 +1,5 @@
 """GPU tests of the whole-run schedule table (include/ccvm_hip.h: `schedule` of ccvm_dl_params / ccvm_langevin_params,
-ccvm_dl_schedule, ccvm_langevin_schedule, CCVM_RUN_FORWARD): the per-step scalars (pump and noise ramps,
+ccvm_dl_schedule, ccvm_mf_schedule, ccvm_langevin_schedule, CCVM_RUN_FORWARD): the per-step scalars (pump and noise ramps,
 dl_solver.py:524-527, pumped_langevin_solver.py:279-282; Adam bias corrections, langevin_solver.py:519-540) made once
 per run instead of by a small kernel in front of every launch of a persistent path, so that a run call is one launch.
 
@@ -22,6 +22,10 @@ CASES = [
     ("dl", 1000, 1000, 24, None, "ptile_kernel"), ("pl", 2000, 512, 12, "second_moment", "ptile_kernel"),
     ("dl", 1000, 2000, 9, None, "slices"), ("langevin", 1000, 1100, 11, None, "cut in two"),
     ("dl", 1000, 256, 7, None, "step_kernel"),  # (the per-step kernel computes its scalars on the host: no table read)
+    # MF: a row's "next step" scalars are the whole run's; the kernels decide "the launch's last step" themselves
+    ("mf", 100, 1000, 30, None, "persist_kernel"), ("mf", 500, 32, 20, "second_moment", "slab_kernel"),
+    ("mf", 500, 1000, 20, None, "cluster_kernel"), ("mf", 640, 1000, 12, "add_assign", "cluster_kernel"),
+    ("mf", 1000, 1000, 16, None, "ptile_kernel"), ("mf", 1000, 2000, 9, "second_moment", "slices"),
 ]
 
 
@@ -69,7 +73,3 @@ def test_flag_lines_are_set_without_the_forward_promise(monkeypatch, kind, n, b,
         assert torch.equal(got[name], want[name]), name
 
 
-def test_mf_makes_its_rows_per_call():
-    traj = _run_engine("mf", 1000, 1000, 6, None, 1, 0)
-    assert traj._schedule is None
-    traj.check()
