@@ -138,6 +138,18 @@ def test_host_side_argument_checks_need_no_gpu(hip_lib):
     buf = ctypes.create_string_buffer(64)
     addr = ctypes.c_void_p(ctypes.addressof(buf))
     assert hip_lib.ccvm_clamp(addr, 4, 20, 64, 0.0, 1.0, None) == -2  # ld != ccvm_ld(20)
+    # whole-run schedule tables: NULL arguments, T <= 0, parameters no run call would accept
+    from ccvm_amd import _lib
+
+    dl = _lib.DlParams(pump=2.5, dt=0.005, noise_ratio=10.0, feedback_scale=100.0, g=0.05, lower=0.0, upper=1.0, pump_rate_flag=1)
+    assert hip_lib.ccvm_dl_schedule(None, 10, addr, None) == -1 and hip_lib.ccvm_dl_schedule(ctypes.byref(dl), 0, addr, None) == -1
+    assert hip_lib.ccvm_dl_schedule(ctypes.byref(dl), 10, None, None) == -1
+    dl.upper = 0.0
+    assert hip_lib.ccvm_dl_schedule(ctypes.byref(dl), 10, addr, None) == -1 and b"upper > lower" in hip_lib.ccvm_last_error()
+    mf = _lib.MfParams(pump=0.5, dt=0.0025, j=399.0, feedback_scale=20.0, g=0.01, S=0.0, lower=0.0, upper=1.0)
+    assert hip_lib.ccvm_mf_schedule(ctypes.byref(mf), None, 10, addr, None) == -1 and b"S > 0" in hip_lib.ccvm_last_error()
+    lv = _lib.LangevinParams(dt=0.002, sigma=0.5, feedback_scale=1.0, S=0.5, lower=0.0, upper=1.0)
+    assert hip_lib.ccvm_langevin_schedule(ctypes.byref(lv), None, -3, addr, None) == -1
 
 
 def test_product_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
