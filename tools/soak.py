@@ -9,7 +9,10 @@ CASES = (("dl", 20, 1000, 100000), ("mf", 64, 500, 50000), ("pl", 300, 512, 2000
          # the tile kernel's 32 x 32 and multi-round 32 x 64 shapes
          ("dl", 1000, 256, 20000), ("langevin", 1500, 1000, 5000),
          # the row-owner kernel's K split: two and four waves side by side
-         ("mf", 100, 1000, 100000), ("dl", 256, 1000, 30000), ("langevin", 200, 500, 50000))
+         ("mf", 100, 1000, 100000), ("dl", 256, 1000, 30000), ("langevin", 200, 500, 50000),
+         # round 4: the persistent tile kernel, slices of the batch, batches cut in two
+         ("dl", 1000, 1000, 30000), ("mf", 1000, 2000, 10000), ("langevin", 1000, 1100, 20000), ("dl", 500, 1100, 20000),
+         ("pl", 2000, 640, 8000))
 for kind, n, b, t in CASES:
     traj, q, v = bench.make_trajectories(kind, n, b, t, 0)
     t0 = time.time()
