@@ -23,7 +23,7 @@ from ctypes import (
 LIB_NAME = "libccvm_hip.so"
 # CCVM_AMD_LIB: another build of the same library (same-box A/B of kernel variants); default: the in-tree one
 LIB_PATH = os.environ.get("CCVM_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 NOISE_PHILOX = 0
 NOISE_REPLAY = 1
@@ -53,6 +53,7 @@ class Noise(Structure):
         ("row_offset", c_int64),
         ("w0", c_void_p),
         ("w1", c_void_p),
+        ("w_ld", c_int64),
     ]
 
 

@@ -58,11 +58,15 @@ int check_steps(const char* fn, int step0, int nsteps, int T) {
     return CCVM_OK;
 }
 
-int check_noise(const char* fn, const ccvm_noise* nz, bool two_streams) {
+// REPLAY: the pitch of the noise blocks, element (step, j, b) at w[(step N + j) w_ld + b] (0: the batch itself)
+size_t noise_pitch(const ccvm_noise* nz, int B) { return nz->w_ld > 0 ? (size_t)nz->w_ld : (size_t)B; }
+int check_noise(const char* fn, const ccvm_noise* nz, bool two_streams, int B) {
     if (!nz) return fail(CCVM_E_INVALID, "%s: noise is NULL", fn);
     if (nz->mode == CCVM_NOISE_REPLAY) {
         if (!nz->w0 || (two_streams && !nz->w1))
             return fail(CCVM_E_INVALID, "%s: REPLAY noise needs w0%s", fn, two_streams ? " and w1" : "");
+        if (nz->w_ld != 0 && (nz->w_ld < B || nz->w_ld > 0x7FFFFFFF))
+            return fail(CCVM_E_INVALID, "%s: REPLAY noise pitch w_ld must be 0 or at least the batch", fn);
     } else if (nz->mode != CCVM_NOISE_PHILOX) {
         return fail(CCVM_E_INVALID, "%s: unknown noise mode %d", fn, nz->mode);
     }
@@ -288,7 +292,8 @@ void set_noise(StepArgs& a, const ccvm_noise* nz, int i, int step0, int B, int N
     a.row_offset = nz->row_offset;
     a.replay = nz->mode == CCVM_NOISE_REPLAY;
     if (a.replay) {
-        const size_t blk = (size_t)N * B;
+        const size_t blk = (size_t)N * noise_pitch(nz, B);
+        a.wld = (int)noise_pitch(nz, B);
         a.w0 = nz->w0 + (size_t)(i - step0) * blk;
         a.w1 = two ? nz->w1 + (size_t)(i - step0) * blk : nullptr;
         a.w0n = next ? nz->w0 + (size_t)(i + 1 - step0) * blk : nullptr;
@@ -465,7 +470,7 @@ int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V,
     xid = exchange_layout_id({1, B, N, planes});
     if (exchange_prepare(area, xb, 0, 0, ca.status, xid, step0, st)) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
-    ca.B = B; ca.N = N; ca.ld = ld;
+    ca.B = B; ca.N = N; ca.ld = ld; ca.wld = (int)noise_pitch(nz, B);
     ca.nclusters = cluster_count(B, N);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
     ca.spread = cluster_spread(B, N, chip_of(tun));
@@ -516,7 +521,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
     xid = exchange_layout_id({2, B, N, planes, p.cgrp, p.rg, p.K, p.nclusters, p.G});
     if (exchange_prepare(area, 2 * half, p.K, p.G * 4 * p.cgrp, sa.status, xid, step0, st)) return CCVM_E_HIP;
     sa.seed = nz->seed; sa.row_offset = nz->row_offset; sa.replay = nz->mode == CCVM_NOISE_REPLAY;
-    sa.B = B; sa.N = N; sa.ld = ld;
+    sa.B = B; sa.N = N; sa.ld = ld; sa.wld = (int)noise_pitch(nz, B);
     sa.nclusters = p.nclusters; sa.G = p.G; sa.RG = p.rg; sa.span = p.span;
     sa.nxcd = chip_of(tun).xcds;
     sa.delay_fabric = tun.slab_delay >= 0 ? tun.slab_delay : slab_fabric_delay(planes, p.rg, p.K);
@@ -574,8 +579,8 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // 35 row blocks, three rounds of 32 x 64 tiles per step, 50.9 us -- runs as two calls on the same stream: the rows that
 // fill whole resident grids (1024: one launch per chunk, 30.9 us per step) and the rest under its own plan (76 rows:
 // the column-slab kernel).  Decided on the per-step estimates of the plans involved (us; fits of
-// profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Fused noise only (replay
-// blocks are pitched by the batch: parity mode keeps one plan per batch), no saturation arrays.
+// profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Replay
+// noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
     const bool two = mode == MODE_DL;
     const double mf = mode == MODE_MF ? 1.0 : 0.0;
@@ -686,10 +691,10 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
         pa.flags = static_cast<unsigned*>(area) + (size_t)rb0 * PT_FLAG_WORDS;
         pa.status = status;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset + r0; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
-        pa.wld = a.B;
+        pa.wld = (int)noise_pitch(nz, a.B);
         if (pa.replay) {
-            pa.w0 = nz->w0 + (size_t)done * a.N * a.B + r0;
-            pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * a.B + r0 : nullptr;
+            pa.w0 = nz->w0 + (size_t)done * a.N * pa.wld + r0;
+            pa.w1 = nz->w1 ? nz->w1 + (size_t)done * a.N * pa.wld + r0 : nullptr;
         }
         pa.B = rows; pa.N = a.N; pa.ld = a.ld; pa.nrb = g.nrb; pa.ncb = g.ncb; pa.xr = g.xr; pa.xc = g.xc;
         pa.par = par;
@@ -868,7 +873,6 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     const Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
     if (const int cut = per_variable_s ? 0 : split_rows(solver, B, N, tun)) {
-        // (fused noise; a replay call runs the batch uncut: describe it with CCVM_AMD_SPLIT=0)
         char first[512], rest[512];
         int rc;
         if ((rc = ccvm_describe_launch(solver, cut, N, adam, 0, first, sizeof(first)))) return rc;
@@ -958,22 +962,25 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
     if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
-    if ((rc = check_noise(fn, nz, true))) return rc;
+    if ((rc = check_noise(fn, nz, true, B))) return rc;
     if (!aligned16(Q) || !aligned16(c) || !aligned16(s) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, c, s and workspace must be 16-byte aligned", fn);
     if (ws_bytes < workspace_plain(0, B, N)) return fail(CCVM_E_WORKSPACE, "%s: workspace too small", fn);
     if (!(p->upper > p->lower) || !(p->dt > 0)) return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0", fn);
     hipStream_t st = (hipStream_t)stream;
 
-    if (const int cut = (nsteps > 0 && nz->mode != CCVM_NOISE_REPLAY) ? split_rows(MODE_DL, B, N, tun) : 0;
+    if (const int cut = nsteps > 0 ? split_rows(MODE_DL, B, N, tun) : 0;
         cut && ws_bytes >= ccvm_workspace_bytes(0, B, N)) {
         // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
         char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(0, B, N));
         unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ccvm_status_offset(0, B, N));
         for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
             const int rows = r0 ? B - cut : cut;
-            ccvm_noise n = *nz;
+            ccvm_noise n = *nz;  // (replay: the part's columns of the batch's blocks)
             n.row_offset += r0;
+            n.w_ld = (int64_t)noise_pitch(nz, B);
+            if (n.w0) n.w0 += r0;
+            if (n.w1) n.w1 += r0;
             const size_t off = (size_t)r0 * ld, bytes = workspace_plain(0, rows, N);
             if ((rc = ccvm_dl_run(Q, V, c + off, s + off, rows, N, ld, step0, nsteps, T, p, &n, part_ws, bytes, stream))) return rc;
             hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, st, status,
@@ -1007,7 +1014,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.x1 = s; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
-        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.wld = (int)noise_pitch(nz, B); pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
         pa.simds = 4 * chip_of(tun).cus;
@@ -1024,8 +1031,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             pa.table = rows;
             pa.nsteps = k;
             if (pa.replay) {
-                pa.w0 = nz->w0 + (size_t)done * N * B;
-                pa.w1 = nz->w1 + (size_t)done * N * B;
+                pa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
+                pa.w1 = nz->w1 + (size_t)done * N * noise_pitch(nz, B);
             }
             if ((rc = launch_persist<MODE_DL, false>(pa, st, fn))) return rc;
         }
@@ -1054,8 +1061,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             sa.table = rows;
             sa.nsteps = k;
             if (sa.replay) {
-                sa.w0 = nz->w0 + (size_t)done * N * B;
-                sa.w1 = nz->w1 + (size_t)done * N * B;
+                sa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
+                sa.w1 = nz->w1 + (size_t)done * N * noise_pitch(nz, B);
             }
             slab_launch_dl(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
@@ -1086,8 +1093,8 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             ca.table = rows;
             ca.nsteps = k;
             if (ca.replay) {
-                ca.w0 = nz->w0 + (size_t)done * N * B;
-                ca.w1 = nz->w1 + (size_t)done * N * B;
+                ca.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
+                ca.w1 = nz->w1 + (size_t)done * N * noise_pitch(nz, B);
             }
             cluster_launch_dl(ca, st);
             CCVM_CHECK_LAUNCH(fn);
@@ -1162,7 +1169,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
     if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
-    if ((rc = check_noise(fn, nz, false))) return rc;
+    if ((rc = check_noise(fn, nz, false, B))) return rc;
     if ((rc = check_adam(fn, adam))) return rc;
     if (!aligned16(Q) || !aligned16(mu) || !aligned16(sigma) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, mu, sigma and workspace must be 16-byte aligned", fn);
@@ -1173,6 +1180,8 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0) || !(p->j > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0, j > 0", fn);
     if (s_cols && s_full) return fail(CCVM_E_INVALID, "%s: s_cols and s_full are exclusive", fn);
+    if (s_full && nz->mode == CCVM_NOISE_REPLAY && nz->w_ld != 0 && nz->w_ld != B)
+        return fail(CCVM_E_INVALID, "%s: s_full needs replay blocks pitched by the batch (w_ld = 0)", fn);
     if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
     // per-variable saturation: every 1 / S factor of the scalars is left out (S_eff = 1) and applied per
     // column -- 1 / S_k of the input map through the row-scaled copy Qs, 1 / S_j in the epilogue
@@ -1181,7 +1190,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
 
-    if (const int cut = (nz->mode != CCVM_NOISE_REPLAY && !s_cols && !s_full) ? split_rows(MODE_MF, B, N, tun) : 0;
+    if (const int cut = (!s_cols && !s_full) ? split_rows(MODE_MF, B, N, tun) : 0;
         cut && ws_bytes >= ccvm_workspace_bytes(1, B, N)) {
         // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
         char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(1, B, N));
@@ -1189,8 +1198,11 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
             const int rows = r0 ? B - cut : cut;
             const size_t off = (size_t)r0 * ld, bytes = workspace_plain(1, rows, N);
-            ccvm_noise n = *nz;
+            ccvm_noise n = *nz;  // (replay: the part's columns of the batch's blocks)
             n.row_offset += r0;
+            n.w_ld = (int64_t)noise_pitch(nz, B);
+            if (n.w0) n.w0 += r0;
+            if (n.w1) n.w1 += r0;
             ccvm_adam ad;
             if (adam) {
                 ad = *adam;
@@ -1285,7 +1297,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.Q = s_cols ? scaled_rows(Q, s_cols, N, ld, ws, workspace_plain(1, B, N), st) : Q;
         pa.V = V; pa.qsum = qsum; pa.x0 = mu; pa.x1 = sigma; pa.xt = mu_tilde_out; pa.table = table;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = replay;
-        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.wld = (int)noise_pitch(nz, B); pa.in_scale = (float)(ul / S_eff); pa.in_shift = (float)up;
         pa.S = (float)S_eff;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
@@ -1305,7 +1317,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             pa.table = rows;
             pa.nsteps = k;
             pa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
-            if (replay) pa.w0 = nz->w0 + (size_t)done * N * B;
+            if (replay) pa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             rc = use_adam ? launch_persist<MODE_MF, true>(pa, st, fn) : launch_persist<MODE_MF, false>(pa, st, fn);
             if (rc) return rc;
         }
@@ -1342,7 +1354,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             sa.table = rows;
             sa.nsteps = k;
             sa.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
-            if (replay) sa.w0 = nz->w0 + (size_t)done * N * B;
+            if (replay) sa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             slab_launch_mf(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
         }
@@ -1380,7 +1392,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             ca.table = rows;
             ca.nsteps = k;
             ca.k_first = (float)(std::sqrt(1.0 / (4.0 * j_at(step0 + done))) / sdt);
-            if (replay) ca.w0 = nz->w0 + (size_t)done * N * B;
+            if (replay) ca.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             cluster_launch_mf(ca, use_adam, st);
             CCVM_CHECK_LAUNCH(fn);
         }
@@ -1407,7 +1419,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         const float k0 = (float)(std::sqrt(1.0 / (4.0 * j_at(first_step))) / sdt);
         hipLaunchKernelGGL(mf_prepare_kernel, dim3(ew_grid((size_t)B * N)), dim3(256), 0, st, mu, mt[0], carry, B, N,
                            ld, k0, (float)S_eff, s_cols, nz->seed, nz->row_offset, first_step,
-                           replay ? nz->w0 + (size_t)done * N * B : nullptr);
+                           replay ? nz->w0 + (size_t)done * N * noise_pitch(nz, B) : nullptr, (int)noise_pitch(nz, B));
     };
     if (want_ptile(a, tun, MODE_MF, s_cols != nullptr)) {
         // whole chunks in one launch each, the tile grid resident (ccvm_ptile.h): the exchanged plane is the measured
@@ -1496,7 +1508,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     int rc;
     if ((rc = check_layout(fn, B, N, ld))) return rc;
     if ((rc = check_steps(fn, step0, nsteps, T))) return rc;
-    if ((rc = check_noise(fn, nz, false))) return rc;
+    if ((rc = check_noise(fn, nz, false, B))) return rc;
     if ((rc = check_adam(fn, adam))) return rc;
     if (!aligned16(Q) || !aligned16(c) || !aligned16(ws))
         return fail(CCVM_E_LAYOUT, "%s: Q, c and workspace must be 16-byte aligned", fn);
@@ -1507,13 +1519,15 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
     if (!(p->upper > p->lower) || !(p->dt > 0) || !(s_cols || s_full || p->S > 0))
         return fail(CCVM_E_INVALID, "%s: need upper > lower, dt > 0, S > 0", fn);
     if (s_cols && s_full) return fail(CCVM_E_INVALID, "%s: s_cols and s_full are exclusive", fn);
+    if (s_full && nz->mode == CCVM_NOISE_REPLAY && nz->w_ld != 0 && nz->w_ld != B)
+        return fail(CCVM_E_INVALID, "%s: s_full needs replay blocks pitched by the batch (w_ld = 0)", fn);
     if (s_cols && !aligned16(s_cols)) return fail(CCVM_E_LAYOUT, "%s: s_cols must be 16-byte aligned", fn);
     const double S_eff = (s_cols || s_full) ? 1.0 : p->S;  // see ccvm_mf_run
     if (nsteps == 0) return CCVM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool use_adam = adam && adam->enabled;
 
-    if (const int cut = (nz->mode != CCVM_NOISE_REPLAY && !s_cols && !s_full) ? split_rows(MODE_LANGEVIN, B, N, tun) : 0;
+    if (const int cut = (!s_cols && !s_full) ? split_rows(MODE_LANGEVIN, B, N, tun) : 0;
         cut && ws_bytes >= ccvm_workspace_bytes(2, B, N)) {
         // two calls on this stream: the rows of whole resident grids, then the rest (split_rows)
         char* part_ws = static_cast<char*>(ws) + part_offset(workspace_plain(2, B, N));
@@ -1521,8 +1535,11 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         for (int r0 = 0; r0 < B; r0 = r0 ? B : cut) {
             const int rows = r0 ? B - cut : cut;
             const size_t off = (size_t)r0 * ld, bytes = workspace_plain(2, rows, N);
-            ccvm_noise n = *nz;
+            ccvm_noise n = *nz;  // (replay: the part's columns of the batch's blocks)
             n.row_offset += r0;
+            n.w_ld = (int64_t)noise_pitch(nz, B);
+            if (n.w0) n.w0 += r0;
+            if (n.w1) n.w1 += r0;
             ccvm_adam ad;
             if (adam) {
                 ad = *adam;
@@ -1603,7 +1620,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = a.Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table; pa.s_cols = s_cols;
         pa.seed = nz->seed; pa.row_offset = nz->row_offset; pa.replay = nz->mode == CCVM_NOISE_REPLAY;
-        pa.B = B; pa.N = N; pa.ld = ld; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
+        pa.B = B; pa.N = N; pa.ld = ld; pa.wld = (int)noise_pitch(nz, B); pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
         pa.simds = 4 * chip_of(tun).cus;
@@ -1621,7 +1638,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             pa.step0 = step0 + done;
             pa.table = rows;
             pa.nsteps = k;
-            if (pa.replay) pa.w0 = nz->w0 + (size_t)done * N * B;
+            if (pa.replay) pa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             rc = use_adam ? launch_persist<MODE_LANGEVIN, true>(pa, st, fn)
                           : launch_persist<MODE_LANGEVIN, false>(pa, st, fn);
             if (rc) return rc;
@@ -1653,7 +1670,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             sa.step0 = step0 + done;
             sa.table = rows;
             sa.nsteps = k;
-            if (sa.replay) sa.w0 = nz->w0 + (size_t)done * N * B;
+            if (sa.replay) sa.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             slab_launch_lv(sa, sp, st);
             CCVM_CHECK_LAUNCH(fn);
         }
@@ -1685,7 +1702,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             ca.step0 = step0 + done;
             ca.table = rows;
             ca.nsteps = k;
-            if (ca.replay) ca.w0 = nz->w0 + (size_t)done * N * B;
+            if (ca.replay) ca.w0 = nz->w0 + (size_t)done * N * noise_pitch(nz, B);
             cluster_launch_lv(ca, use_adam, st);
             CCVM_CHECK_LAUNCH(fn);
         }

@@ -101,6 +101,7 @@ struct ClusterArgs {
     int step0, nsteps;
     int replay;
     int B, N, ld;
+    int wld;             // REPLAY: pitch of the noise blocks (ccvm_noise::w_ld; >= B)
     int nclusters, G;
     int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         } else if constexpr (REPLAY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                out[i] = ok[s][i] ? a.w0[((size_t)it * N + col) * a.B + brow[s][i]] : 0.0f;
+                out[i] = ok[s][i] ? a.w0[((size_t)it * N + col) * a.wld + brow[s][i]] : 0.0f;
         } else {
             NormalPair pa, pb;
             normal_two_rows_x2(a.seed, a.row_offset + brow[s][0], a.row_offset + brow[s][2], step, col, pa, pb);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         } else if constexpr (REPLAY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const size_t wi = ((size_t)it * N + col) * a.B + brow[s][i];
+                const size_t wi = ((size_t)it * N + col) * a.wld + brow[s][i];
                 n0[i] = ok[s][i] ? a.w0[wi] : 0.0f;
                 n1[i] = ok[s][i] ? a.w1[wi] : 0.0f;
             }

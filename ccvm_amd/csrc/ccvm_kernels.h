@@ -62,6 +62,7 @@ struct StepArgs {
     int step;
     int replay;
     int B, N, ld;
+    int wld;  // REPLAY: pitch of the noise blocks (ccvm_noise::w_ld; >= B)
     int nrb, ncb;       // row blocks, column blocks
     int xr, xc;         // tiles of one XCD form an xr x xc rectangle (0: linear fallback)
     int ks;             // host only: the tile shape this launch plan uses (template parameter KS)
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
                         if constexpr (MODE == MODE_DL) n1 = lds_noise[(1 * NR + ibase + ii) * NTHREADS + tid];
                     }
                 } else if (ok) {
-                    const size_t widx = (size_t)j * a.B + row0 + erow(r);
+                    const size_t widx = (size_t)j * a.wld + row0 + erow(r);
                     n0 = a.w0[widx];
                     if constexpr (MODE == MODE_DL) n1 = a.w1[widx];
                     if constexpr (MODE == MODE_MF)
@@ -1011,12 +1012,12 @@ __global__ void change_variables_kernel(const float* x, float* y, int B, int N, 
 // Also seeds the carry buffer with this step's normals (fused mode).
 __global__ void mf_prepare_kernel(const float* mu, float* out, float* carry, int B, int N, int ld,
                                   float k, float S, const float* s_cols, uint64_t seed, int64_t row_offset,
-                                  int step, const float* w0) {
+                                  int step, const float* w0, int wld) {
     const size_t total = (size_t)B * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
-        const float n0 = w0 ? w0[(size_t)j * B + b] : normal_single(seed, row_offset + b, step, j);
+        const float n0 = w0 ? w0[(size_t)j * wld + b] : normal_single(seed, row_offset + b, step, j);
         const size_t idx = (size_t)b * ld + j;
         const float bound = s_cols ? s_cols[j] : S;
         out[idx] = clampf(mu[idx] + k * n0, -bound, bound);

@@ -63,6 +63,7 @@ struct PersistArgs {
     int step0, nsteps;
     int replay;
     int B, N, ld;
+    int wld;             // REPLAY: pitch of the noise blocks (rows of the WHOLE batch, ccvm_noise::w_ld; >= B)
     float in_scale, in_shift;
     float k_first;      // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;            // MF: clamp of the measured amplitude
@@ -201,7 +202,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
     auto stream_normals = [&](int step, int it, float* out) {
         if (a.replay) {
 #pragma unroll
-            for (int e = 0; e < NE; ++e) out[e] = ok[e] ? a.w0[((size_t)it * N + col) * a.B + brow[e]] : 0.0f;
+            for (int e = 0; e < NE; ++e) out[e] = ok[e] ? a.w0[((size_t)it * N + col) * a.wld + brow[e]] : 0.0f;
         } else {
             if constexpr (NE == 4) {  // rows (0,1) and (2,3): two generator calls in lockstep
                 NormalPair pa, pb;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
                 if (a.replay) {
     #pragma unroll
                     for (int e = 0; e < NE; ++e) {
-                        const size_t w = ((size_t)it * N + col) * a.B + brow[e];
+                        const size_t w = ((size_t)it * N + col) * a.wld + brow[e];
                         nz0[e] = ok[e] ? a.w0[w] : 0.0f;
                         nz1[e] = ok[e] ? a.w1[w] : 0.0f;
                     }

@@ -79,6 +79,7 @@ struct SlabArgs {
     int step0, nsteps;
     int replay, adam;
     int B, N, ld;
+    int wld;             // REPLAY: pitch of the noise blocks (ccvm_noise::w_ld; >= B)
     int nclusters, G, RG;  // clusters of G members; a cluster owns 4 RG batch rows
     int span;            // XCDs a cluster's members are confined to (1, 2, 4, ... nxcd): speed only
     int nxcd;            // XCDs of the device (blocks b and b + nxcd share one)
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     auto stream_normals = [&](int p, int step, int it, float* out) {
         if (a.replay) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) out[e] = ok[p][e] ? a.w0[((size_t)it * N + col) * a.B + brow[p][e]] : 0.0f;
+            for (int e = 0; e < 2; ++e) out[e] = ok[p][e] ? a.w0[((size_t)it * N + col) * a.wld + brow[p][e]] : 0.0f;
         } else {
             const NormalPair n = normal_two_rows(a.seed, a.row_offset + brow[p][0], step, col);
             out[0] = n.n0;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
         if (a.replay) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const size_t wi = ((size_t)it * N + col) * a.B + brow[p][e];
+                const size_t wi = ((size_t)it * N + col) * a.wld + brow[p][e];
                 n0[e] = ok[p][e] ? a.w0[wi] : 0.0f;
                 n1[e] = ok[p][e] ? a.w1[wi] : 0.0f;
             }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCVM_ABI_VERSION 9  /* 8: workspaces above N = 768 carry the persistent tile kernel's flag lines */
+#define CCVM_ABI_VERSION 10  /* 8: workspaces above N = 768 carry the persistent tile kernel's flag lines */
 
 typedef enum ccvm_status {
     CCVM_OK = 0,
@@ -87,6 +87,10 @@ typedef struct ccvm_noise {
      * w1 is the second stream of the DL solver (s quadrature); NULL otherwise. */
     const float* w0;
     const float* w1;
+    /* REPLAY: pitch of the blocks in elements, W[step][b][n] = w[((step - step0) * N + n) * w_ld + b], for a call that
+     * runs rows [r, r + B) of a larger batch out of that batch's blocks (pass w0 + r, w1 + r and the larger batch as
+     * w_ld: what the library does itself for the two parts of a cut batch); 0 = B. */
+    int64_t w_ld;
 } ccvm_noise;
 
 /* Optional Adam preconditioning of the feedback term (reference
@@ -173,7 +177,7 @@ int ccvm_unpack(const float* src, int src_ld,
  * buffers of 8-byte {value, tag} packets, and the column-slab path's for small batches above N = 256; a status
  * line; above N = 768, for a batch larger than one resident grid of the persistent tile kernel, behind all that the
  * workspaces of the two parts a run call may cut the batch into -- the rows of whole resident grids and the rest, run
- * as two calls on the same stream, fused noise only; a call given less than this but enough for the uncut batch runs
+ * as two calls on the same stream; a call given less than this but enough for the uncut batch runs
  * uncut).  `what`: 0 ccvm_dl_run, 1 ccvm_mf_run,
  * 2 ccvm_langevin_run, 3 ccvm_energy, 4 ccvm_pp_*, 5 ccvm_feedback. */
 size_t ccvm_workspace_bytes(int solver, int B, int N);

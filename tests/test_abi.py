@@ -41,7 +41,7 @@ def test_library_is_gfx950_only(hip_lib):
 
 
 def test_layout_helpers_and_version(hip_lib):
-    assert hip_lib.ccvm_abi_version() == 9
+    assert hip_lib.ccvm_abi_version() == 10
     assert [hip_lib.ccvm_ld(n) for n in (1, 20, 128, 129, 1000, 2000)] == [128, 128, 128, 256, 1024, 2048]
     assert [hip_lib.ccvm_rows(b) for b in (1, 64, 65, 1000, 4096)] == [64, 64, 128, 1024, 4096]
     assert hip_lib.ccvm_ld(0) == 0 and hip_lib.ccvm_rows(-3) == 0
@@ -78,7 +78,7 @@ def test_struct_layouts_match_the_header():
     """ctypes mirrors of the C structs: sizes follow from the header's field lists."""
     from ccvm_amd import _lib
 
-    assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.Noise) == 4 + 4 + 8 + 8 + 8 + 8 + 8   # ... + w_ld
     assert ctypes.sizeof(_lib.Adam) == 4 + 4 + 3 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.DlParams) == 7 * 8 + 8 + 8 + 8          # ... + qsum + schedule
     assert ctypes.sizeof(_lib.MfParams) == 8 * 8 + 8 + 8 + 8 + 8 + 8      # ... + s_cols + qsum + s_full + schedule

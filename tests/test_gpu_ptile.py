@@ -183,16 +183,24 @@ def test_batches_cut_in_two_match_oracle(monkeypatch, kind, n, b, t, adam):
     _check_against_oracle(kind, n, b, t, adam)
 
 
-def test_replay_runs_of_a_cut_shape_stay_uncut(monkeypatch):
-    """Replay blocks are pitched by the batch, so parity mode keeps one plan per batch: the same result with the cut
-    switched off, and close to the fused-mode plan's arithmetic (the oracle check above)."""
+@pytest.mark.parametrize("kind,n,b,adam,cut", [("dl", 1000, 1100, None, 1024), ("mf", 1000, 1200, "second_moment", 1024),
+                                               ("langevin", 500, 1100, None, 1024), ("pl", 2000, 640, None, 512)])
+def test_cut_batches_in_replay_mode_are_their_parts(monkeypatch, kind, n, b, adam, cut):
+    """Replay noise (parity mode) takes the same plan: the parts read their columns of the batch's blocks
+    (ccvm_noise::w_ld).  Bit for bit the separately run trajectories of the rows on either side of the cut, fed the
+    columns of the unsharded run's blocks."""
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.delenv("CCVM_AMD_KS", raising=False)
-    a = _state(_run_engine("dl", 1000, 1100, 5, None, 12, 0, replay_global_batch=1100))
-    monkeypatch.setenv("CCVM_AMD_SPLIT", "0")
-    b = _state(_run_engine("dl", 1000, 1100, 5, None, 12, 0, replay_global_batch=1100))
-    for name in a:
-        assert torch.equal(a[name], b[name]), name
+    assert "cut in two" in _describe(kind, b, n, adam is not None)
+    t, hp = 7, _ADAMS[adam]
+    whole = _state(_run_engine(kind, n, b, t, hp, 12, 0, replay_global_batch=b))
+    parts = _state(_run_engine(kind, n, b, t, hp, 12, 0, chunks=[2, 1, 4], replay_global_batch=b))
+    lo = _state(_run_engine(kind, n, cut, t, hp, 12, 0, replay_global_batch=b))
+    hi = _state(_run_engine(kind, n, b - cut, t, hp, 12, cut, replay_global_batch=b))
+    for name in whole:
+        assert bool(torch.isfinite(whole[name]).all()), name
+        assert torch.equal(whole[name], parts[name]), name
+        assert torch.equal(whole[name][:cut], lo[name]) and torch.equal(whole[name][cut:], hi[name]), name
 
 
 def test_time_out_in_a_part_of_a_cut_batch_recovers_the_whole_batch(monkeypatch):
