@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #include "../../include/ccvm_hip.h"
 #include "ccvm_cluster.h"
@@ -549,7 +550,7 @@ struct PtilePlan {
 };
 PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     PtilePlan p;
-    (void)vs;  // per-variable saturation: a run-time form inside the kernel (Q = the row-scaled copy, as for the step kernel)
+    (void)vs;  // per-variable saturation is the kernel's VS template parameter (ptile_launch_*): every variant exists, the plan is the same
     if (!tun.ptile || a.N <= CL_MAX_N) return p;
     const ChipGeometry chip = chip_of(tun);
     const int nrb = (a.B + BM - 1) / BM, ncb = (a.N + BN - 1) / BN;
@@ -641,10 +642,31 @@ __global__ void flags_init_kernel(unsigned* flags, int words, unsigned step0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) flags[i] = step0;
 }
-const float* given_rows(const float* schedule, const ccvm_noise* nz, int first, unsigned* flags, int words, hipStream_t st) {
+// CCVM_RUN_FORWARD is a promise, and a broken one is a silent read-before-publish race (a reader takes the flag a LATER
+// step left behind for its peer's publication), so the library keeps its own books on the host: per flag area the
+// step behind the last chunk launched on it.  A chunk that does not start at or behind that step gets its flag lines
+// set whatever the caller says; a workspace the library has never seen is covered by the contract that
+// fresh workspaces are zeroed.  (Host memory behind a mutex, keyed by the device pointer: no device traffic, nothing
+// the 8 host threads of 8 GPUs share but the lock; stale entries of freed workspaces can only cost a launch.)
+bool forward_holds(const unsigned* flags, int first, int k) {
+    static std::mutex mu;
+    static std::unordered_map<const unsigned*, int> reached;
+    std::lock_guard<std::mutex> lock(mu);
+    if (reached.size() > 4096) reached.clear();  // (bounded: forgetting an area costs its next call one launch ...
+    auto it = reached.find(flags);               //  ... only if it then claims CCVM_RUN_FORWARD from step > 0: see below)
+    const bool known = it != reached.end();
+    const bool ok = known ? first >= it->second : first == 0;  // unknown area: only a run's first chunk may skip the init
+    reached[flags] = first + k;
+    return ok;
+}
+const float* given_rows(const float* schedule, const ccvm_noise* nz, int first, int k, unsigned* flags, int words,
+                        hipStream_t st) {
     if (!schedule) return nullptr;
-    if (flags && !(nz->flags & CCVM_RUN_FORWARD))
-        hipLaunchKernelGGL(flags_init_kernel, dim3((words + 255) / 256), dim3(256), 0, st, flags, words, (unsigned)first);
+    if (flags) {
+        const bool forward = forward_holds(flags, first, k) && (nz->flags & CCVM_RUN_FORWARD);
+        if (!forward)
+            hipLaunchKernelGGL(flags_init_kernel, dim3((words + 255) / 256), dim3(256), 0, st, flags, words, (unsigned)first);
+    }
     return schedule + (size_t)first * TABLE_WORDS;
 }
 // blocks of a schedule-kernel launch that also initialises the flag lines of `nrb` row blocks
@@ -1022,7 +1044,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1052,7 +1074,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1084,7 +1106,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(dl_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1112,7 +1134,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
             const int k = std::min(TABLE_STEPS, nsteps - done);
             DlSched sc{p->pump, p->dt, p->noise_ratio, p->feedback_scale, p->g, ul, Sd, p->pump_rate_flag, T,
                        step0 + done, k, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(dl_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1308,7 +1330,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1345,7 +1367,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1383,7 +1405,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(mf_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1438,7 +1460,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
             prepare(step0 + done, done);
             MfSched sc{p->pump, p->dt, p->j, p->feedback_scale, p->g, S_eff, ul, p->pump_rate_flag, T, step0 + done, k, asc,
                        reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(mf_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1630,7 +1652,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1662,7 +1684,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1694,7 +1716,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(lv_schedule_kernel, dim3((k + 255) / 256), dim3(256), 0, st, sc, table);
                 rows = table;
@@ -1721,7 +1743,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
             const int k = std::min(TABLE_STEPS, nsteps - done);
             LvSched sc{p->dt, p->sigma, p->feedback_scale, S_eff, p->pump, ul, p->use_pump, p->pump_rate_flag, T,
                        step0 + done, k, asc, reinterpret_cast<unsigned*>(after + table_bytes()), a.nrb * PT_FLAG_WORDS};
-            const float* rows = given_rows(p->schedule, nz, step0 + done, sc.flags, sc.flag_words, st);
+            const float* rows = given_rows(p->schedule, nz, step0 + done, k, sc.flags, sc.flag_words, st);
             if (!rows) {
                 hipLaunchKernelGGL(lv_schedule_kernel, dim3(ptile_sched_grid(k, a.nrb)), dim3(256), 0, st, sc, table);
                 rows = table;

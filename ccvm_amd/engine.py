@@ -46,6 +46,13 @@ def gpu_device():
             )
         _gpu_seen = True
     index = int(os.environ.get("CCVM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if index != 0 and not 0 <= index < torch.cuda.device_count():
+        # (one process per GPU under a launcher: LOCAL_RANK names the device unless the launcher also narrowed
+        # *_VISIBLE_DEVICES to one GPU per rank -- then CCVM_AMD_DEVICE=0 says so)
+        raise EngineUnavailable(
+            f"device index {index} (from ${'CCVM_AMD_DEVICE' if 'CCVM_AMD_DEVICE' in os.environ else 'LOCAL_RANK'}) "
+            f"is outside the {torch.cuda.device_count()} GPU(s) visible to this process; set CCVM_AMD_DEVICE"
+        )
     return torch.device("cuda", index)
 
 
@@ -290,6 +297,50 @@ class DeviceProblem:
                                             _stream_ptr()), "ccvm_column_sums")
 
 
+# Kernels whose workgroups wait for each other (column-cluster, column-slab, persistent tile) are deadlock-free only
+# while their grid is resident; two such grids launched from different streams of one process can interleave on the
+# CUs, and each then sits out its bounded wait (~0.5 s), falls back, and puts the device into its cool-down (ADVICE
+# r4).  So run calls that launch one are chained per device ACROSS streams: the enqueue happens under the device's lock
+# and, once a second stream has shown up, every such call waits for the event behind the previous one.  A process
+# that drives a device from one stream (the normal case) pays a lock and a set lookup per run call.
+_exchange_chain = {}  # device index -> {"lock", "streams": raw handles seen, "event": behind the last call, "last": its stream}
+
+
+class _ExchangeTurn:
+    """Context of one run call that launches a kernel whose workgroups wait for each other."""
+
+    def __init__(self, device):
+        with _cache_lock:
+            self.ch = _exchange_chain.setdefault(
+                device.index, {"lock": threading.Lock(), "streams": set(), "event": None, "last": None})
+        self.device = device
+
+    def __enter__(self):
+        ch = self.ch
+        ch["lock"].acquire()
+        raw = _stream_ptr().value
+        if raw not in ch["streams"]:
+            ch["streams"].add(raw)
+            if len(ch["streams"]) == 2:
+                torch.cuda.synchronize(self.device)  # the first stream's calls so far left no event behind them
+        self.chained = len(ch["streams"]) > 1
+        if self.chained and ch["event"] is not None and ch["last"] != raw:
+            torch.cuda.current_stream(self.device).wait_event(ch["event"])
+        self.raw = raw
+        return self
+
+    def __exit__(self, *exc):
+        ch = self.ch
+        try:
+            if self.chained and exc[0] is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                ch["event"], ch["last"] = ev, self.raw
+        finally:
+            ch["lock"].release()
+        return False
+
+
 #: device index -> time.monotonic() until which new Trajectories avoid the cluster / slab kernels (set by a time-out
 #: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 30)
 _exchange_blocked_until = {}
@@ -424,6 +475,12 @@ class Trajectories:
             off = self.lib.ccvm_status_offset(self._SOLVER_ID[kind], self.b, self.n)
             self._status = self.ws[off:off + 4] if off != ctypes.c_size_t(-1).value else None
             self._ws_padded = False  # set by the first completed run call (ccvm_hip.h: CCVM_RUN_WS_PADDED)
+            # Everything above -- the zero-filled arrays, the schedule kernel -- sits on the stream current NOW; a
+            # first run call on another stream waits for this event (nothing else orders that stream's
+            # first persistent launch behind the kernel that writes the table it reads)
+            self._built = torch.cuda.Event()
+            self._built.record()
+            self._built_on = _stream_ptr().value
         self.feeder = _NoiseFeeder(noise, self.n, self.b, 2 if kind == "dl" else 1, self.device)
         # Time-out recovery (see check): the state at the last verified point, taken before the first run call that
         # may launch a kernel whose workgroups wait for each other; None while nothing unverified has run.
@@ -433,6 +490,7 @@ class Trajectories:
         # whatever held the GPU -- another process, a CU mask -- would cost each of them its own ~1 s wait)
         self.no_exchange = time.monotonic() < _exchange_blocked_until.get(self.device.index, 0.0)
         self.fallbacks = 0         # time-outs recovered so far
+        self._waits = None         # does a run call launch a kernel whose workgroups wait for each other? (asked once)
 
     def _set_saturation(self, cp, S):
         """Scalar S; a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs); a 2-D
@@ -464,8 +522,23 @@ class Trajectories:
                 self.step += k
                 nsteps -= k
 
+    def arm(self, force=False):
+        """Take the recovery snapshot NOW instead of inside the next ``advance`` -- for callers that time that call (two
+        device-to-device copies and their allocation are no part of the loop).  ``force``: also when the next run call
+        launches no kernel that can time out (``rollback`` then has something to go back to)."""
+        if self._snap is None and (force or (not self.no_exchange and self._exchange_kernel())):
+            with torch.cuda.device(self.device):
+                self._snap = self._snapshot()
+
+    def rollback(self):
+        """Back to the snapshot ``check(hold=True)`` kept although the steps since were valid (a caller repeats them:
+        bench.py's ranks repeat a timed region TOGETHER when any of them had to).  The kernel policy stays as it is."""
+        if self._snap is None:
+            raise RuntimeError("rollback needs a snapshot: arm(force=True), then check(hold=True)")
+        with torch.cuda.device(self.device):
+            self._restore(self._snap)
+
     def _run(self, step0, k, nz):
-        lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
         if self._ws_padded:  # this object zero-filled the workspace and only its own run calls have used it since
             nz.flags |= _lib.RUN_WS_PADDED
         if self.no_exchange:
@@ -474,6 +547,19 @@ class Trajectories:
             # this object's run calls only ever move forward on its workspace (a recovered time-out goes back, and stays
             # off the kernels that care: no_exchange)
             nz.flags |= _lib.RUN_FORWARD
+        if self._built is not None:  # the first run call: behind the construction, whatever stream that was on
+            if _stream_ptr().value != self._built_on:
+                torch.cuda.current_stream(self.device).wait_event(self._built)
+            self._built = None
+        if self._waits is None:
+            self._waits = self._exchange_kernel()
+        turn = _ExchangeTurn(self.device) if self._waits and not self.no_exchange else contextlib.nullcontext()
+        with turn:
+            self._launch(step0, k, nz)
+        self._ws_padded = True
+
+    def _launch(self, step0, k, nz):
+        lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
         tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
         if self.kind == "dl":
             rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,
@@ -486,7 +572,6 @@ class Trajectories:
             rc = lib.ccvm_langevin_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), *common,
                                        ctypes.byref(self.cparams), ctypes.byref(self.adam), *tail)
         _lib.check(rc, f"ccvm_{self.kind}_run")
-        self._ws_padded = True
 
     # ------------------------------------------------------------------ #
     def clamp(self, name, lo, hi):
@@ -516,9 +601,9 @@ class Trajectories:
     def _exchange_kernel(self):
         """Would a run call of this shape launch a kernel whose workgroups wait for each other (column-cluster,
         column-slab, persistent tile: ccvm_describe_launch under the current tuning environment)?"""
-        buf = ctypes.create_string_buffer(512)
+        buf = ctypes.create_string_buffer(1024)  # (the description of a cut batch names both parts' plans)
         rc = self.lib.ccvm_describe_launch(self._SOLVER_ID[self.kind], self.b, self.n, 1 if self.adam.enabled else 0,
-                                           1 if self.s_cols is not None else 0, buf, 512)
+                                           1 if self.s_cols is not None else 0, buf, 1024)
         return rc == 0 and any(k in buf.value for k in (b"cluster_kernel", b"slab_kernel", b"ptile_kernel"))
 
     def _snapshot(self):
@@ -552,7 +637,7 @@ class Trajectories:
                 torch.random.set_rng_state(snap["rng"])
         self.step = snap["step"]
 
-    def check(self, rerun=True):
+    def check(self, rerun=True, hold=False):
         """Synchronisation point (4 bytes to the host): did a kernel of this run report a failure through the
         workspace's status word?  The column-cluster and column-slab persistent kernels give up a bounded wait when
         their workgroups cannot all become resident (e.g. another process holding the GPU for a second); the state
@@ -562,17 +647,22 @@ class Trajectories:
         repeated there -- same noise, same result up to the summation order -- with a RuntimeWarning instead of an
         error.  Returns True when a time-out was recovered (with ``rerun=False`` the caller repeats the steps:
         ``self.step`` is back at the snapshot).  Without a snapshot (the status word was set by something else) it
-        raises."""
+        raises.  ``hold``: keep the snapshot of verified steps (see ``rollback``)."""
         if self._status is None:
+            if not hold:
+                self._snap = None
             return False
         if int(self._status.cpu().view(torch.int32).item()) == 0:
-            self._snap = None  # verified: the next run call snapshots anew
+            if not hold:
+                self._snap = None  # verified: the next run call snapshots anew
             return False
         snap, self._snap = self._snap, None
         if snap is None:
             raise _lib.EngineError(
-                f"ccvm_{self.kind}_run: the column-cluster kernel timed out waiting for its workgroups (is another "
-                "process using this GPU?); the trajectories are invalid -- rerun, or set CCVM_AMD_KERNEL=nocluster"
+                f"ccvm_{self.kind}_run: a persistent kernel whose workgroups wait for each other (column-cluster, "
+                "column-slab or persistent tile kernel) timed out (is another process using this GPU?) and no snapshot "
+                "of the trajectories exists; they are invalid -- rerun, or set CCVM_AMD_KERNEL=nocluster (no kernel of "
+                "that kind; noptile / noslab switch off one family)"
             )
         import warnings
 

@@ -17,7 +17,6 @@ Evolution sampling under sharding: every rank writes the best row OF ITS SHARD t
 ``<evolution_file>.rank<r>`` (rank r; the name is returned in ``Solution.evolution_file``).
 """
 import copy
-import time
 
 import torch
 import torch.distributed as dist
@@ -57,7 +56,12 @@ def solve_sharded(solver, instance, group=None, gather_variables=False, local_so
     """Solve ``instance`` with ``solver.batch_size`` rows split over the ranks of ``group``.
 
     Every rank returns the SAME global ``Solution`` (objective values of all rows, global
-    success statistics, solve time = slowest rank's wall time / global batch).  ``variables``
+    success statistics).  ``solve_time`` keeps the reference's definition -- the time of the LOOP
+    only, per row (dl_solver.py:851, 933: the timer brackets ``_solve`` and is divided by the batch) --
+    for the job as a whole: every rank's local ``Solution.solve_time`` already is its loop's time per
+    local row, the ranks run side by side, so the job's loop took ``max_r(solve_time_r * rows_r)`` and
+    the global figure is that over the GLOBAL batch; ``pp_time`` likewise.  Priming, the finalize, host
+    copies and the gather are outside it, as they are outside the reference's timer.  ``variables``
     hold this rank's rows unless ``gather_variables``.
 
     ``local_solve(solver, instance, **call_kwargs) -> Solution`` defaults to calling the solver
@@ -91,9 +95,10 @@ def solve_sharded(solver, instance, group=None, gather_variables=False, local_so
         base = call_kwargs.get("evolution_file") or f"./{instance.name}_evolution.txt"
         call_kwargs = dict(call_kwargs, evolution_file=f"{base}.rank{rank}")
 
-    t0 = time.time()
     sol = (local_solve or (lambda s, inst, **kw: s(instance=inst, **kw)))(local, instance, **call_kwargs)
-    wall = torch.tensor([time.time() - t0, sol.pp_time * (hi - lo)], dtype=torch.float64, device=comm_device)
+    # seconds this rank's loop / post-processor took in all (the local Solution reports them per local row)
+    wall = torch.tensor([sol.solve_time * (hi - lo), sol.pp_time * (hi - lo)], dtype=torch.float64,
+                        device=comm_device)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX, group=group)
 
     # gather from where the values already are: the device copy of ccvm_finalize under RCCL

@@ -83,7 +83,7 @@ def test_gpu_count_without_the_hip_runtime(monkeypatch):
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
     assert bench.visible_gpu_count() == 1
     src = open(os.path.join(ROOT, "bench.py")).read()
-    launcher = src[src.index("def launch_ranks"):src.index("def profiled_counters")]
+    launcher = src[src.index("def launch_ranks"):src.index("def rccl_group")]
     assert "torch.cuda" not in launcher  # the launcher never asks the HIP runtime anything
 
 

@@ -17,11 +17,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _fake_loop_seconds_per_row(row_offset):
+    """What the stand-in solves report as their loop's time per local row: different on every rank."""
+    return 1e-3 * (1 + row_offset)
+
+
 def _oracle_local_solve(solver, instance, **kw):
     """Oracle-backed stand-in for the engine: PL solver with the engine's Philox stream."""
     from ccvm_amd.solution import Solution
     from oracle import ccvm_oracle as oracle
     from oracle.noise_ref import FusedNoise
+
+    import time
 
     n = instance.problem_size
     p = solver.parameter_key[n]
@@ -30,10 +37,13 @@ def _oracle_local_solve(solver, instance, **kw):
         p["sigma"], p["feedback_scale"], p["S"], scaled_by=instance.scaled_by,
         noise=FusedNoise(solver.noise_seed, solver.row_offset, single=True),
     )
+    time.sleep(0.2)  # everything around the loop (priming, finalize, copies): never part of solve_time
     return Solution(
         problem_size=n, batch_size=solver.batch_size, instance_name=instance.name,
-        iterations=p["iterations"], objective_values=out["objective_values"], solve_time=1e-3,
-        pp_time=0.0, optimal_value=instance.optimal_sol, best_value=instance.best_sol,
+        iterations=p["iterations"], objective_values=out["objective_values"],
+        solve_time=_fake_loop_seconds_per_row(solver.row_offset),  # per LOCAL row, as a solver reports it
+        pp_time=2.0 * _fake_loop_seconds_per_row(solver.row_offset),
+        optimal_value=instance.optimal_sol, best_value=instance.best_sol,
         num_frac_values=0, solution_vector=[], variables={"problem_variables": out["problem_variables"]},
     )
 
@@ -137,7 +147,7 @@ def _worker(rank, world, port, batch, queue):
         # parent may try to open after this process has gone)
         queue.put((rank, sol.objective_values.numpy().copy(), sol.variables["problem_variables"].numpy().copy(),
                    sol.best_objective_value, sol.solution_performance, sol.batch_size, sol.shard,
-                   solver.noise_seed))
+                   solver.noise_seed, sol.solve_time, sol.pp_time))
     finally:
         dist.destroy_process_group()
 
@@ -166,7 +176,17 @@ def test_sharded_solve_equals_unsharded(world, batch):
     solver.noise_seed = seed
     whole = _oracle_local_solve(solver, inst)
     sizes = []
-    for rank, obj, xs, best, perf, b, shard, _ in results:
+    # solve_time keeps the reference's definition (dl_solver.py:851, 933: the loop only, per row) for the whole job:
+    # the ranks' loops run side by side, so the job's loop took max_r(local solve_time x local rows) and the global
+    # figure is that over the GLOBAL batch -- not the wall time of the local solver call (the stand-in sleeps 0.2 s
+    # around its "loop": 0.02 s per row if that were counted)
+    from ccvm_amd.sharded import shard_bounds
+
+    bounds = [shard_bounds(batch, world, r) for r in range(world)]
+    loop_s = max(_fake_loop_seconds_per_row(lo) * (hi - lo) for lo, hi in bounds)
+    for rank, obj, xs, best, perf, b, shard, _, solve_time, pp_time in results:
+        assert solve_time == pytest.approx(loop_s / batch, rel=1e-12)
+        assert pp_time == pytest.approx(2.0 * loop_s / batch, rel=1e-12)
         assert b == batch and shard["world"] == world and shard["rank"] == rank
         sizes.append(shard["rows"][1] - shard["rows"][0])
         assert torch.equal(torch.from_numpy(obj), whole.objective_values)   # exact: same global rows, same noise
