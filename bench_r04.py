@@ -159,105 +159,6 @@ def launch_ranks(n, argv, script=None, timeout=None):
 
 
 # --------------------------------------------------------------------------- #
-# collectives of a multi-rank run
-# --------------------------------------------------------------------------- #
-def rccl_group(dev, world, timeout_s):
-    """An RCCL ("nccl") process group over all ranks, PROVEN by a one-element all-reduce on `dev`: communicator
-    creation is lazy, so the transport set-up (xGMI / dmabuf IPC between the ranks' devices) only happens -- and only
-    fails -- inside the first collective.  Raises whatever RCCL raises."""
-    import datetime
-
-    import torch.distributed as dist
-
-    # a collective that cannot complete raises in THIS thread after the group's time-out instead of leaving the
-    # watchdog to abort the process (an explicit setting in the caller's environment wins)
-    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
-    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s), device_id=dev)
-    probe = torch.ones(1, dtype=torch.float32, device=dev)
-    dist.all_reduce(probe, group=grp)
-    torch.cuda.synchronize(dev)
-    if int(probe.item()) != world:
-        raise RuntimeError(f"RCCL warm-up all-reduce returned {probe.item()} on {world} ranks")
-    return grp
-
-
-def init_collectives(rank, world, dev, share, probe=None, timeout_s=None):
-    """The process groups of a multi-rank run, decided so that the line is never lost to a transport problem.
-
-    The DEFAULT group is gloo (TCP on 127.0.0.1, the rendez-vous the launcher / torch.distributed.run set up): it
-    carries the barriers around the timed region and the per-rank clocks (host scalars), and it is the control plane on
-    which the ranks AGREE how the one data collective -- the all-gather of the objective values after the loop --
-    travels: every rank tries to set up RCCL (`probe`, default rccl_group: group creation + a warm-up all-reduce on
-    its device) inside try / except, the outcomes are min-reduced over gloo, and unless EVERY rank succeeded every rank
-    gathers host copies over gloo instead, in the same processes -- no re-exec, no relaunch, the measured steps are
-    the same either way (no collective sits in the timed region) -- and the line says so
-    (`"collective": "gloo-fallback: <first error>"`).  RCCL with more than one rank has never run on this pipeline's
-    boxes before the driver's round-end run: its first failure must not cost the scaling curve.
-
-    Returns {"group": data group or None (= default), "device": where the gathered tensors live, "collective": label}."""
-    import torch.distributed as dist
-
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    cpu = torch.device("cpu")
-    if share:  # rehearsal on one GPU: RCCL refuses two ranks on one device
-        return {"group": None, "device": cpu, "collective": "gloo (rehearsal: the ranks share one GPU)"}
-    timeout_s = float(timeout_s or os.environ.get("CCVM_BENCH_RCCL_TIMEOUT", "120"))
-    grp, err = None, ""
-    try:
-        grp = (probe or rccl_group)(dev, world, timeout_s)
-    except Exception as exc:  # noqa: BLE001 -- whatever the transport set-up raises
-        err = f"{type(exc).__name__}: {exc}".replace("\n", " ")[:300]
-    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        return {"group": grp, "device": dev, "collective": "RCCL"}
-    errs = [None] * world
-    dist.all_gather_object(errs, err)
-    first = next((f"rank {r}: {e}" for r, e in enumerate(errs) if e), "unknown")
-    return {"group": None, "device": cpu, "collective": f"gloo-fallback: {first}"}
-
-
-def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag):
-    """W untimed warm-up steps, then K steps of `traj` under the contract's clock -- barrier + device synchronisation on
-    both sides, HIP events on the launch stream around the same region -- repeated when the steps turn out INVALID: a
-    persistent kernel whose workgroups could not all become resident gives up a bounded wait and sets the run's status
-    word; its steps are garbage, and `traj.check` puts the trajectories back where the recovery snapshot was taken and
-    moves the run to the per-step kernel.  The snapshot is taken ONCE, in front of the warm-up steps (two
-    device-to-device copies: right in front of the timed region they would push Q and the state out of the L2s), the
-    status word is read right after the clock stops (4 bytes; inside the region it would cost ~25 us of a 0.65 ms run),
-    and a run that was recovered -- in its warm-up or in its timed region -- starts over from the snapshot on the path
-    that then runs, so `value` never describes discarded work.  `any_rank(flag)`: True when the flag is set
-    on ANY rank: the ranks start over together (the barriers must pair up).
-    Returns (wall seconds, stream ms, attempts)."""
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()  # torch creates the HIP event at its first record (15-20 us): the measuring apparatus is set up
-    ev1.record()  # BEFORE the timed region (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
-    traj.arm(force=True)  # (forced: another rank may ask this one to start over although its own steps were valid)
-    for attempt in (1, 2, 3):
-        traj.advance(warmup)
-        recovered = traj.check(rerun=False, hold=True)  # verified before the clock starts
-        if not any_rank(recovered):
-            torch.cuda.synchronize(dev)
-            barrier()     # every rank starts its K steps together ...
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            ev0.record()
-            traj.advance(steps)
-            ev1.record()
-            torch.cuda.synchronize(dev)
-            elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
-            #                                     inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
-            #                                     loss" on the driver's 0.7 ms, VERDICT r3); the job's time is the MAX over ranks
-            recovered = traj.check(rerun=False, hold=True)
-            if not any_rank(recovered):
-                traj.check()  # (drops the snapshot)
-                return elapsed, ev0.elapsed_time(ev1), attempt
-        if not recovered:
-            traj.rollback()  # another rank starts over: this one does with it
-    raise SystemExit("bench.py: the run was invalid three times in a row")
-
-
-# --------------------------------------------------------------------------- #
 def profiled_counters(workload):
     """Counters of the dominant kernel from the COMMITTED rocprofv3 --pmc passes of this same
     command (profiles/r*_<workload>_pmc.json, written by tools/pmc_summary.py).  They are NOT
@@ -512,11 +413,14 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    coll = {"group": None, "device": dev, "collective": "single rank"}
+    comm_dev = torch.device("cpu") if share else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault(*IPC_ENV)  # before any process group exists (under torch.distributed.run too)
-        coll = init_collectives(rank, world, dev, share)
+        os.environ.setdefault(*IPC_ENV)  # before the process group exists (under torch.distributed.run too)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, n, b = WORKLOADS[args.workload]
     row0 = rank * b
@@ -528,7 +432,7 @@ def main():
     total = args.warmup + args.steps
     traj, q, v = make_trajectories(kind, n, b, total, rank, row_offset=row0)
 
-    def barrier():  # the default (gloo) group: a rendez-vous of the host processes, never on the device's queue
+    def barrier():
         if world > 1:
             dist.barrier()
 
@@ -539,20 +443,27 @@ def main():
             scratch.advance(256)
             torch.cuda.synchronize(dev)
         del scratch
+    traj.advance(args.warmup)
     # HIP events on the stream the engine launches on (torch's current stream: engine._stream_ptr)
-    def any_rank(flag):
-        if world == 1:
-            return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(t.item())
-
-    elapsed, stream_ms, attempts = timed_steps(traj, args.warmup, args.steps, dev, barrier, any_rank)
-    gpu_ms_per_step = stream_ms / args.steps  # stream time of the timed region / steps
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()  # torch creates the HIP event at its first record (15-20 us): the measuring apparatus is set up
+    ev1.record()  # BEFORE the timed region (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
+    torch.cuda.synchronize(dev)
+    barrier()     # every rank starts its K steps together ...
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    traj.advance(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
+    barrier()                           # inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
+    #                                     loss" on the driver's 0.7 ms); the job's time is the MAX over ranks
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # stream time of the timed region / steps
 
     per_rank_elapsed = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)  # host scalars over the default (gloo) group
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         each = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(each, t)
         per_rank_elapsed = [float(x.item()) for x in each]
@@ -564,32 +475,29 @@ def main():
 
     _, _, f = scaled_qv(n, kind)
     pp_seconds = 0.0
+    if kind == "dl":
+        traj.clamp("c", -1.0, 1.0)
     name = "mu_tilde" if kind == "mf" else "c"
-    # (DL's final clamp, dl_solver.py:567, inside the finalize: behind score's own verification of the state, never on
-    # a state a recovery would still replace)
-    obj, pp_seconds = traj.score(name, SATURATION[kind], float(f), post_processor=args.post,
-                                 clamp=(-1.0, 1.0) if kind == "dl" else None)
+    obj, pp_seconds = traj.score(name, SATURATION[kind], float(f), post_processor=args.post)
     finite = bool(torch.isfinite(obj).all().item())
     ranks_seen = 1
     if world > 1:
-        obj = obj.to(coll["device"])
+        obj = obj.to(comm_dev)
         if args.global_batch is not None:  # shards differ by a row: gather equal-length, +inf-padded vectors
             per = -(-args.global_batch // world)
             obj = torch.cat([obj, torch.full((per - obj.numel(),), float("inf"), dtype=obj.dtype, device=obj.device)])
         gathered = [torch.empty_like(obj) for _ in range(world)]
-        dist.all_gather(gathered, obj, group=coll["group"])  # THE data collective: RCCL (or what the ranks agreed on)
+        dist.all_gather(gathered, obj)
         obj = torch.cat(gathered)
         if args.global_batch is not None:
             obj = obj[torch.isfinite(obj) | torch.isnan(obj)]
-        ranks_seen = dist.get_world_size(coll["group"])
+        ranks_seen = dist.get_world_size()
     best = float((-obj).max().item())
 
     if rank == 0:
         na = 2 if kind == "dl" else 1
         launch = describe_launch(kind, b, n)
-        if traj.fallbacks:  # the timed steps ran on the per-step kernel (CCVM_RUN_NO_EXCHANGE), not on the default plan
-            launch = f"step_kernel<{SOLVER_ID[kind]}, ...> per step, after a recovered time-out of: {launch}"
-        persistent = not traj.fallbacks and any(k in launch for k in ("persist_kernel", "cluster_kernel", "slab_kernel", "ptile_kernel"))
+        persistent = any(k in launch for k in ("persist_kernel", "cluster_kernel", "slab_kernel", "ptile_kernel"))
         # a persistent launch runs up to 4096 steps (the schedule table of a run call, ccvm_abi.hip: TABLE_STEPS);
         # traj.advance(steps) in fused-noise mode is ONE run call = ceil(steps / 4096) launches
         launches = -(-args.steps // 4096) if persistent else args.steps
@@ -658,15 +566,11 @@ def main():
                 "rows_per_rank": [shard_rows(global_rows, world, r)[1] for r in range(world)],
                 "parallelism": f"batch-sharded x{world}, no data-path collective; one all-gather of "
                                f"{global_rows} objective values after the loop "
-                               f"({coll['collective']})",
+                               f"({'gloo rehearsal on one GPU' if share else 'RCCL' if world > 1 else 'single rank'})",
             },
-            "collective": coll["collective"],
             "roofline": roofline,
             "check": {"objective_values_finite": finite, "best_objective_value": best,
-                      "post_processor": args.post, "pp_seconds": pp_seconds, "time_outs_recovered": traj.fallbacks,
-                      # > 1: warm-up or timed steps were invalid (a persistent kernel gave up its bounded wait) and the
-                      # run started over on the per-step kernel -- the line's times are the LAST attempt's
-                      "timed_attempts": attempts},
+                      "post_processor": args.post, "pp_seconds": pp_seconds, "time_outs_recovered": traj.fallbacks},
         }
         prof = profiled_counters(args.workload)
         if prof is not None:

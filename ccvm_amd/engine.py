@@ -303,42 +303,34 @@ class DeviceProblem:
 # r4).  So run calls that launch one are chained per device ACROSS streams: the enqueue happens under the device's lock
 # and, once a second stream has shown up, every such call waits for the event behind the previous one.  A process
 # that drives a device from one stream (the normal case) pays a lock and a set lookup per run call.
-_exchange_chain = {}  # device index -> {"lock", "streams": raw handles seen, "event": behind the last call, "last": its stream}
+_exchange_chain = {}  # device index -> {"lock", "streams": raw handles seen, "single": the only one so far (else -1), "event", "last"}
 
 
-class _ExchangeTurn:
-    """Context of one run call that launches a kernel whose workgroups wait for each other."""
+def _exchange_chain_of(device):
+    with _cache_lock:
+        return _exchange_chain.setdefault(
+            device.index, {"lock": threading.Lock(), "streams": set(), "single": -1, "event": None, "last": None})
 
-    def __init__(self, device):
-        with _cache_lock:
-            self.ch = _exchange_chain.setdefault(
-                device.index, {"lock": threading.Lock(), "streams": set(), "event": None, "last": None})
-        self.device = device
 
-    def __enter__(self):
-        ch = self.ch
-        ch["lock"].acquire()
-        raw = _stream_ptr().value
-        if raw not in ch["streams"]:
-            ch["streams"].add(raw)
-            if len(ch["streams"]) == 2:
-                torch.cuda.synchronize(self.device)  # the first stream's calls so far left no event behind them
-        self.chained = len(ch["streams"]) > 1
-        if self.chained and ch["event"] is not None and ch["last"] != raw:
-            torch.cuda.current_stream(self.device).wait_event(ch["event"])
-        self.raw = raw
-        return self
-
-    def __exit__(self, *exc):
-        ch = self.ch
-        try:
-            if self.chained and exc[0] is None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                ch["event"], ch["last"] = ev, self.raw
-        finally:
-            ch["lock"].release()
+def _exchange_enter(ch, device, raw):
+    """Called under the chain's lock by a run call on stream `raw` that is not the device's only stream so far;
+    returns True when the call must leave an event behind it."""
+    if raw not in ch["streams"]:
+        ch["streams"].add(raw)
+        ch["single"] = raw if len(ch["streams"]) == 1 else -1
+        if len(ch["streams"]) == 2:
+            torch.cuda.synchronize(device)  # the first stream's calls so far left no event behind them
+    if len(ch["streams"]) == 1:
         return False
+    if ch["event"] is not None and ch["last"] != raw:
+        torch.cuda.current_stream(device).wait_event(ch["event"])
+    return True
+
+
+def _exchange_exit(ch, device, raw):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    ch["event"], ch["last"] = ev, raw
 
 
 #: device index -> time.monotonic() until which new Trajectories avoid the cluster / slab kernels (set by a time-out
@@ -553,8 +545,16 @@ class Trajectories:
             self._built = None
         if self._waits is None:
             self._waits = self._exchange_kernel()
-        turn = _ExchangeTurn(self.device) if self._waits and not self.no_exchange else contextlib.nullcontext()
-        with turn:
+            self._chain = _exchange_chain_of(self.device)
+        if self._waits and not self.no_exchange:
+            ch = self._chain
+            with ch["lock"]:  # (one stream per device, the normal case: a lock and an integer compare per run call)
+                raw = _stream_ptr().value or 0
+                chained = raw != ch["single"] and _exchange_enter(ch, self.device, raw)
+                self._launch(step0, k, nz)
+                if chained:
+                    _exchange_exit(ch, self.device, raw)
+        else:
             self._launch(step0, k, nz)
         self._ws_padded = True
 

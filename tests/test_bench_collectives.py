@@ -90,10 +90,11 @@ class _FakeEvent:
 
 
 class _FakeTraj:
-    """Trajectories whose first timed region is invalid (check reports a recovered time-out and goes back)."""
+    """Trajectories whose verification points fail as listed (check then reports a recovered time-out and goes back to
+    the snapshot)."""
 
-    def __init__(self, invalid_regions):
-        self.invalid, self.step, self.calls, self.rollbacks, self.fallbacks = invalid_regions, 5, [], 0, 0
+    def __init__(self, invalid_checks):
+        self.invalid, self.step, self.calls, self.rollbacks, self.fallbacks = list(invalid_checks), 0, [], 0, 0
         self._start = None
 
     def arm(self, force=False):
@@ -104,8 +105,9 @@ class _FakeTraj:
         self.step += n
 
     def check(self, rerun=True, hold=False):
-        if self.invalid > 0:
-            self.invalid -= 1
+        if not hold:
+            return False  # (the final check that drops the snapshot)
+        if self.invalid and self.invalid.pop(0):
             self.fallbacks += 1
             self.step = self._start
             return True
@@ -116,25 +118,32 @@ class _FakeTraj:
         self.step = self._start
 
 
-def test_an_invalid_timed_region_is_timed_again(monkeypatch):
+def test_an_invalid_run_starts_over(monkeypatch):
     import bench
 
     monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda dev=None: None)
     barriers = []
-    traj = _FakeTraj(invalid_regions=1)
-    elapsed, stream_ms, attempts = bench.timed_steps(traj, 20, torch.device("cpu"), lambda: barriers.append(1))
+    # the TIMED region of the first attempt is invalid (its warm-up check passes: the second check fails)
+    traj = _FakeTraj(invalid_checks=[False, True])
+    elapsed, stream_ms, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
     assert attempts == 2 and stream_ms == 1.25 and elapsed >= 0
-    assert traj.calls == [(5, 20), (5, 20)]  # the SAME steps again, from the start of the region
-    assert traj.step == 25 and len(barriers) == 2  # one opening barrier per attempt
+    assert traj.calls == [(0, 5), (5, 20), (0, 5), (5, 20)]  # warm-up and timed steps again, from the snapshot
+    assert traj.step == 25 and len(barriers) == 2  # one opening barrier per timed region
 
-    # a valid region on this rank, an invalid one on another: this rank repeats WITH it (the barriers must pair up)
-    traj = _FakeTraj(invalid_regions=0)
-    told = iter([True, False])
-    elapsed, stream_ms, attempts = bench.timed_steps(traj, 20, torch.device("cpu"), lambda: None,
-                                                     any_rank=lambda flag: flag or next(told))
-    assert attempts == 2 and traj.rollbacks == 1 and traj.calls == [(5, 20), (5, 20)]
+    # invalid WARM-UP steps: no timed region is opened for that attempt
+    traj = _FakeTraj(invalid_checks=[True])
+    barriers.clear()
+    _, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
+    assert attempts == 2 and traj.calls == [(0, 5), (0, 5), (5, 20)] and len(barriers) == 1
 
-    traj = _FakeTraj(invalid_regions=3)
+    # valid here, invalid on another rank: this rank starts over WITH it (the barriers must pair up)
+    traj = _FakeTraj(invalid_checks=[])
+    told = iter([False, True, False, False])  # attempt 1: warm-up fine, another rank's timed region invalid
+    _, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None,
+                                       any_rank=lambda flag: flag or next(told))
+    assert attempts == 2 and traj.rollbacks == 1 and traj.calls == [(0, 5), (5, 20), (0, 5), (5, 20)]
+
+    traj = _FakeTraj(invalid_checks=[True, True, True])
     with pytest.raises(SystemExit):
-        bench.timed_steps(traj, 20, torch.device("cpu"), lambda: None)
+        bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None)

@@ -215,7 +215,7 @@ def test_status_word_is_checked_at_synchronisation_points(cluster):
     traj.check()                                     # a normal run leaves it at 0
     assert traj._status is not None and int(traj._status.cpu().view(torch.int32).item()) == 0
     traj._status.view(torch.int32)[0] = 1            # what a timed-out workgroup stores
-    with pytest.raises(_lib.EngineError, match="cluster kernel timed out"):
+    with pytest.raises(_lib.EngineError, match="timed out .* no snapshot"):
         traj.compact("c")
     with pytest.raises(_lib.EngineError):
         traj.score("c", 0.5, 1.0)

@@ -1,0 +1,241 @@
+// What would a split-bf16 ("bf16x3") contraction of the streamed-Q tile kernel cost at the headline shape?  (VERDICT r4
+// item 2; developer probe, not product code.)
+//
+// x = x1 + x2 + x3, Q = q1 + q2 + q3 in bf16; the six leading products x1q1, x1q2, x2q1, x1q3, x2q2, x3q1 on
+// v_mfma_f32_32x32x16_bf16 are 6/16 of the exact-fp32 matrix time.  But every operand then travels as THREE bf16 planes
+// (6 bytes per element instead of 4) in 0.375 of the time, through the same L2 -> LDS path and the same 160 KB of LDS.
+// This probe runs the main loop such a kernel would have -- nothing else: no epilogue, no split of the new state, no
+// hand-over between workgroups, no noise -- in the best layout one could wish for: both operands stored in global memory
+// as the exact LDS image of a stage (every LDS-DMA piece is 1 KiB contiguous), fragments read with conflict-free
+// ds_read_b128, double-buffered in registers, one barrier per stage.  Tile, grid and XCD rectangles are the persistent
+// tile kernel's (32 rows x 128 columns per workgroup, 256 workgroups, 4 consumer + 4 producer waves).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/bf16x3_floor.hip -o tools/bf16x3_floor && tools/bf16x3_floor
+//
+// Variants: MODE 0 = everything, 1 = no DMA (MFMA + fragment reads: the matrix floor), 2 = no MFMA / no fragment reads
+// (the stream alone).  NA = 2: DL (c and s planes share the Q fragments), NA = 1: Langevin / MF.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int BM = 32, BN = 128, SLAB = 16;  // a slab = the K extent of one MFMA
+constexpr int N = 1024, B = 1024, NRB = B / BM, NCB = N / BN, XR = 8, XC = 4;
+
+// s_waitcnt vmcnt(n) for a wave-uniform n: the counter is an instruction immediate
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        default:
+            if (n > 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");  // (stricter than needed: never reached by the shapes below)
+            else if (n > 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// bytes of one slab in a stage: A: NA planes x 3 splits x [half 2][row 32][8 bf16]; Q: 3 splits x [half 2][col 128][8 bf16]
+template <int NA> constexpr int a_slab_bytes() { return NA * 3 * 2 * 32 * 16; }
+constexpr int Q_SLAB_BYTES = 3 * 2 * 128 * 16;
+
+template <int NA, int SPS, int NST, int MODE>
+__global__ __launch_bounds__(512) void floor_kernel(const char* __restrict__ aimg0, const char* __restrict__ aimg1,
+                                                    const char* __restrict__ qimg, float* out, int nsteps) {
+    constexpr int A_SLAB = a_slab_bytes<NA>(), STAGE = SPS * (A_SLAB + Q_SLAB_BYTES);
+    constexpr int PIECES = STAGE / 1024, PPW = (PIECES + 3) / 4;  // 1 KiB LDS-DMA pieces of a stage, per producer wave
+    static_assert(STAGE % 1024 == 0 && NST * STAGE <= 160 * 1024 - 1024, "ring");
+    __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int rb = (x / (NCB / XC)) * XR + i / XC, cb = (x % (NCB / XC)) * XC + i % XC;
+    constexpr int NSLAB = N / SLAB, NSTG = NSLAB / SPS;  // stages per step
+    // global images: A [rb][stage][STAGE's A part], Q [cb][stage][STAGE's Q part]: a stage's A and Q parts are contiguous
+    const size_t a_stage = (size_t)SPS * A_SLAB, q_stage = (size_t)SPS * Q_SLAB_BYTES;
+    const char* const abase0 = aimg0 + (size_t)rb * NSTG * a_stage;
+    const char* const abase1 = aimg1 + (size_t)rb * NSTG * a_stage;
+    const char* const qbase = qimg + (size_t)cb * NSTG * q_stage;
+    const int total = nsteps * NSTG;
+
+    if (wave >= 4) {
+        // ---------------- producers: stage s into slot s % NST, NST - 1 stages ahead ----------------
+        const int pw = wave - 4;
+        const unsigned voff = lane * 16;
+        auto issue = [&](int s) {
+            if constexpr (MODE == 1) return;
+            const int step = s / NSTG, st = s - step * NSTG;
+            const char* ab = ((step & 1) ? abase1 : abase0) + (size_t)st * a_stage;
+            const char* qb = qbase + (size_t)st * q_stage;
+            char* slot = lds + (s % NST) * STAGE;
+#pragma unroll
+            for (int p = 0; p < PPW; ++p) {
+                const int piece = pw + 4 * p;  // wave-uniform
+                if (piece >= PIECES) break;
+                const int apieces = (int)(a_stage / 1024);
+                const char* src = piece < apieces ? ab + piece * 1024 : qb + (piece - apieces) * 1024;
+                const unsigned ldst = (unsigned)(size_t)(lds_void*)(slot + piece * 1024);
+                unsigned keep;
+                if (piece < apieces)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(ldst) : "memory");
+                else
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(ldst) : "memory");
+            }
+        };
+        // pieces this wave issues per stage (the last wave may have one fewer)
+        const int mine = (PIECES - pw + 3) / 4;
+        for (int s = 0; s < NST - 1 && s < total; ++s) issue(s);
+        for (int t = 0; t < total; ++t) {
+            // barrier_t: stage t has landed (stages t+1 .. t+NST-2 may still fly), slot (t - 1) % NST is free
+            const int later = min(total - 1, t + NST - 2) - t;  // stages issued behind stage t
+            if (MODE != 1) {
+                wait_vmcnt(min(63, later * mine));
+            }
+            __builtin_amdgcn_s_barrier();
+            if (t + NST - 1 < total) issue(t + NST - 1);  // into the slot of stage t - 1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---------------- consumers: wave w owns columns [32 w, 32 w + 32) ----------------
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[NA];
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    struct Frags { bf16x8 a[SPS][NA][3]; bf16x8 q[SPS][3]; };
+    auto read = [&](Frags& f, int slot) {
+        if constexpr (MODE == 2) return;
+        const char* st = lds + slot * STAGE;
+#pragma unroll
+        for (int sl = 0; sl < SPS; ++sl) {
+            const char* ap = st + sl * A_SLAB;
+            const char* qp = st + SPS * A_SLAB + sl * Q_SLAB_BYTES;
+#pragma unroll
+            for (int n = 0; n < NA; ++n)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    f.a[sl][n][sp] = *reinterpret_cast<const bf16x8*>(ap + ((n * 3 + sp) * 64 + half * 32 + l31) * 16);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+                f.q[sl][sp] = *reinterpret_cast<const bf16x8*>(qp + (sp * 256 + half * 128 + 32 * wave + l31) * 16);
+        }
+    };
+    auto mfma = [&](const Frags& f) {
+        if constexpr (MODE == 2) return;
+#pragma unroll
+        for (int sl = 0; sl < SPS; ++sl)
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                // smallest first: x1 q3, x2 q2, x3 q1, then x1 q2, x2 q1, then x1 q1
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][2], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][1], f.q[sl][1], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][2], f.q[sl][0], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][1], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][1], f.q[sl][0], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][0], acc[n], 0, 0, 0);
+            }
+    };
+    Frags f0, f1;
+    __builtin_amdgcn_s_barrier();  // barrier_0: stage 0 landed
+    read(f0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int t = 0; t < total; t += 2) {
+        // iteration t: behind barrier_(t+1) read stage t + 1 while the MFMAs of stage t run
+        if (t + 1 < total) { __builtin_amdgcn_s_barrier(); read(f1, (t + 1) % NST); }
+        mfma(f0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 >= total) break;
+        if (t + 2 < total) { __builtin_amdgcn_s_barrier(); read(f0, (t + 2) % NST); }
+        mfma(f1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[n][r];
+    if (s == 123.456f) out[blockIdx.x] = s;
+}
+
+template <int NA, int SPS, int NST, int MODE>
+float run(const char* a0, const char* a1, const char* q, float* out, int nsteps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((floor_kernel<NA, SPS, NST, MODE>), dim3(256), dim3(512), 0, 0, a0, a1, q, out, nsteps);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((floor_kernel<NA, SPS, NST, MODE>), dim3(256), dim3(512), 0, 0, a0, a1, q, out, nsteps);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(1); }
+    return ms * 1000.0f / nsteps;
+}
+
+template <int NA, int SPS, int NST>
+void report(const char* a0, const char* a1, const char* q, float* out, int nsteps) {
+    const float all = run<NA, SPS, NST, 0>(a0, a1, q, out, nsteps);
+    const float mat = run<NA, SPS, NST, 1>(a0, a1, q, out, nsteps);
+    const float dma = run<NA, SPS, NST, 2>(a0, a1, q, out, nsteps);
+    const int stage = SPS * (a_slab_bytes<NA>() + Q_SLAB_BYTES);
+    printf("planes %d  stage %2d KB x %d slots (%3d KB LDS, %3d KB in flight)  K per stage %2d:  main loop %6.2f us/step   "
+           "MFMA + fragment reads alone %6.2f   LDS-DMA stream alone %6.2f  (%.0f KB per workgroup and step = %.0f GB/s per CU)\n",
+           NA, stage / 1024, NST, NST * stage / 1024, (NST - 1) * stage / 1024, SPS * SLAB, all, mat, dma,
+           stage * (N / SLAB / SPS) / 1024.0, stage * (N / SLAB / SPS) / (dma * 1e-6) / 1e9);
+}
+
+int main() {
+    const size_t abytes = (size_t)NRB * (N / SLAB) * a_slab_bytes<2>(), qbytes = (size_t)NCB * (N / SLAB) * Q_SLAB_BYTES;
+    char *a0, *a1, *q;
+    float* out;
+    hipMalloc(&a0, abytes); hipMalloc(&a1, abytes); hipMalloc(&q, qbytes); hipMalloc(&out, 4096);
+    std::vector<unsigned short> h(abytes / 2);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3C00 + (unsigned short)((i * 2654435761u) >> 25);  // bf16 values near 0.01
+    hipMemcpy(a0, h.data(), abytes, hipMemcpyHostToDevice);
+    hipMemcpy(a1, h.data(), abytes, hipMemcpyHostToDevice);
+    hipMemcpy(q, h.data(), qbytes, hipMemcpyHostToDevice);
+    printf("bf16x3 main-loop floor, N = %d, B = %d, 256 workgroups of 32 x 128 (exact-fp32 kernel today: 31.0 us per DL step, "
+           "15.9 per Langevin step; matrix time of six bf16 products: 10.2 / 5.1 us)\n", N, B);
+    // spin the clocks up
+    for (int i = 0; i < 20; ++i) run<2, 2, 3, 1>(a0, a1, q, out, 64);
+    const int nsteps = 200;
+    report<2, 2, 3>(a0, a1, q, out, nsteps);   // DL, K tile 32: 36 KB stages, 3 slots
+    report<2, 1, 7>(a0, a1, q, out, nsteps);   // DL, K tile 16: 18 KB stages, 7 slots
+    report<2, 1, 8>(a0, a1, q, out, nsteps);   // DL, 8 slots = 144 KB (no room for the noise buffer the real kernel needs)
+    report<1, 2, 4>(a0, a1, q, out, nsteps);   // one-stream solvers, K tile 32: 30 KB stages, 4 slots
+    report<1, 1, 8>(a0, a1, q, out, nsteps);   // one-stream, K tile 16: 15 KB stages, 8 slots
+    report<1, 1, 10>(a0, a1, q, out, nsteps);  // 10 slots = 150 KB
+    return 0;
+}

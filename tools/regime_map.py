@@ -13,7 +13,7 @@ PATH = os.path.join("gpurun_out", "regime_map.jsonl")
 
 def family(kernel):
     if kernel.startswith("batch cut in two"):
-        first, rest = kernel[len("batch cut in two: "):].split(" | ")
+        first, rest = kernel[len("batch cut in two: "):].split(" | ", 1)
         return family(first.split(" ", 2)[2]) + "+" + family(rest.split(" ", 2)[2])
     if "persist_kernel" in kernel:
         return "R"
