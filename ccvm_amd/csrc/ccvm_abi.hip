@@ -196,28 +196,51 @@ ChipGeometry device_geometry() {
 }
 ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : device_geometry(); }
 
-// Tile choice: 32 x 128 (KS = 1) unless that grid would leave at least half of the 256 CUs without
-// a tile; then 32 x 64 with the K split inside the workgroup (KS = 2).
-int choose_ks(int B, int N, const Tuning& tun, int max_ks) {
+// ---- what a step costs on the per-step tile kernel (us), per solver and tile shape ---------------------------------
+// Fits of the round-5 regret audit (tools/policy_regret.py: every (solver, N, B) cell of the regime map timed under the
+// default plan and under every forced family / tile shape; profiles/r05_policy_regret.md): a launch of a solver step
+// runs ROUNDS of workgroups, ceil(tiles / CUs); relative error of the fits 2-3 % rms for the 32 x 128 and 32 x 64 tiles,
+// 3-7 % (worst cells 15-20 %: the one-stream solvers at N = 2000) for the 32 x 32 tiles, over 300 <= N <= 2000,
+// 1 <= B <= 4000 (tools/policy_regret.py prints them).  The 32 x 32 tiles' later rounds overlap the launch boundary: 9.0 us
+// per round at DL N = 1000 where a lone round takes 11.7 -- round 3's "0.37 of a 32 x 128 workgroup" priced every round
+// as the first and kept these tiles off every multi-round grid.
+struct TileFit { double l0, l1, m0, m1, a, b, e, q; };
+constexpr TileFit TILE_FIT[3][3] = {  // [DL, MF, Langevin / pumped Langevin][32 x 128, 32 x 64, 32 x 32]
+    {{6.047, 0.02663, 0.876, 0.00070, 0.02726, 5.378, 0.258, 0.037}, {4.440, 0.01364, 1.150, 0.00049, 0.01376, 2.396, 1.963, 0.029}, {3.905, 0.00668, 0.649, 0.00031, 0.00653, 1.791, 2.015, 0.450}},
+    {{5.368, 0.01329, 1.220, 0.00084, 0.01423, 5.919, -0.236, -0.170}, {3.885, 0.00673, 0.915, 0.00043, 0.00762, 2.832, 0.145, -0.248}, {4.030, 0.00340, -0.951, 0.00297, 0.00338, 1.840, 1.671, 0.498}},
+    {{4.305, 0.01342, 0.344, 0.00087, 0.01364, 3.313, 0.882, 0.125}, {3.960, 0.00677, 0.193, 0.00076, 0.00684, 1.731, 1.735, 0.119}, {3.616, 0.00373, -0.514, 0.00119, 0.00257, 1.121, 2.735, 0.865}}};
+int fit_row(int mode) { return mode == MODE_MF ? 1 : mode == MODE_LANGEVIN ? 2 : 0; }
+double tile_us(int mode, int ks, int B, int N, int cus) {
+    const TileFit& f = TILE_FIT[fit_row(mode)][ks == 1 ? 0 : ks == 2 ? 1 : 2];
+    const int tiles = ((B + BM - 1) / BM) * ((N + BN / ks - 1) / (BN / ks));
+    // one round: what a lone workgroup takes, plus what the chip's share of the grid adds (more workgroups stream more
+    // through the L2s); several rounds: rounds x a round, plus what a launch pays once
+    if (tiles <= cus) return f.l0 + f.l1 * N + (double)tiles / cus * (f.m0 + f.m1 * N);
+    return ((tiles + cus - 1) / cus) * (f.a * N + f.b + f.q * 1e-6 * N * N) + f.e;
+}
+bool solver_mode(int mode) { return mode == MODE_DL || mode == MODE_MF || mode == MODE_LANGEVIN; }
+
+// Tile shape of a per-step launch.  Solver steps (`mode`): the shape with the smallest estimate above, a finer one
+// only where it is estimated 3 % ahead (ties to the larger tile).  Other kernels (energy, post-processors: 32 x 128 or
+// 32 x 64 tiles only, once per solve): 32 x 64 where the 32 x 128 grid would leave half the chip idle or round up more
+// (a 32 x 64 workgroup = 0.54 of a 32 x 128 one, round 3).
+int choose_ks(int B, int N, const Tuning& tun, int max_ks, int mode = -1) {
     if (tun.ks) return tun.ks < max_ks ? tun.ks : max_ks;
-    // A launch costs the rounds its fullest CU runs times what one workgroup of that tile shape takes: a 32 x 64
-    // split-K workgroup 0.54 of a 32 x 128 one (tools/ks_sweep.sh: DL N = 1000, B = 1000: 36.8 us for two rounds
-    // against 34.2 for one), a 32 x 32 one 0.37 (DL N = 1000, B = 256: 11.8 us against 19.1 with 32 x 64 tiles on
-    // half the chip; Langevin 8.0 against 11.2; solver steps only: max_ks).  Finer tiles win where the grid leaves
-    // CUs idle and where several workgroups per CU round up less: N = 1100 ... 1536 at B = 1000 is 3 rounds of 0.54
-    // against 2 of 1 (DL N = 1500: 92.4 -> 74.5 us per step, Langevin 48.7 -> 40.6); the model matched all 61
-    // measured points of profiles/r03_tile_shape_sweep.txt.  Ties go to the larger tile.
     const int cus = chip_of(tun).cus;
     const int nrb = (B + BM - 1) / BM;
-    static const double rel[3] = {1.0, 0.54, 0.37};
     int best_ks = 1;
     double best = 0.0;
+    static const double rel[3] = {1.0, 0.54, 0.37};
     for (int i = 0, ks = 1; ks <= max_ks && i < 3; ++i, ks *= 2) {
         const int tiles = nrb * ((N + BN / ks - 1) / (BN / ks));
-        const double cost = rel[i] * ((tiles + cus - 1) / cus);
+        const double cost = solver_mode(mode) ? tile_us(mode, ks, B, N, cus) : rel[i] * ((tiles + cus - 1) / cus);
         if (i == 0 || cost < 0.97 * best) { best = cost; best_ks = ks; }
     }
     return best_ks;
+}
+// the cheapest per-step plan's estimate (solver steps)
+double best_tile_us(int mode, int B, int N, const Tuning& tun) {
+    return tile_us(mode, choose_ks(B, N, tun, 4, mode), B, N, chip_of(tun).cus);
 }
 
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
@@ -244,7 +267,8 @@ void set_grid(StepArgs& a, const Tuning& tun) {
 }
 
 // Everything of a launch that does not change from step to step: operands, tile shape and grid.
-void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun, int max_ks = 2) {
+void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun, int max_ks = 2,
+               int mode = -1) {
     std::memset(&a, 0, sizeof(a));
     a.Q = Q;
     a.V = V;
@@ -254,7 +278,7 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
     a.in_scale = 1.0f;
     a.in_shift = 0.0f;
     a.qsum = V;  // any valid array while in_shift == 0
-    a.ks = choose_ks(B, N, tun, max_ks);
+    a.ks = choose_ks(B, N, tun, max_ks, mode);
     set_grid(a, tun);
 }
 
@@ -368,6 +392,15 @@ bool cluster_spread(int B, int N, const ChipGeometry& chip) {
     return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip) &&
            cluster_count(B, N) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
 }
+// what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 384 / 512 / 640 / 768
+// (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it)
+double cluster_us(int mode, int B, int N, const ChipGeometry& chip) {
+    static const double round_us[4][3] = {{7.9, 4.27, 3.77}, {10.1, 5.38, 4.87}, {18.1, 9.6, 8.9}, {21.8, 11.4, 10.7}};
+    const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
+    const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
+    const int k = round_up(N, 128) / 128 - 3;
+    return (count + per_round - 1) / per_round * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
+}
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
@@ -411,6 +444,11 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
             if (10 * rounds >= 13 * waves) return false;
         }
     }
+    // Round 5 (regret audit): a cluster's time per step does not shrink with the batch, the per-step kernel's rounds of
+    // 32 x 32 tiles do -- DL N = 640, B = 768: 18.3 us against 14.6; N = 300, B = 768: 7.9 against 6.1; N = 768, B = 1500
+    // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 5 %
+    // behind the best per-step shape
+    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip)) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
@@ -502,10 +540,7 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     // DL 13.9 / 18.5 / 25 / 32; 32 x 32 tiles Langevin 5.9 / 7.8 / 10.0 / 12.5 at N = 600 / 1000 / 1500 / 2000, DL 7.9 /
     // 11.4 / 14.3 / 17.9): the plan's own estimate must beat it by 10 % (Langevin N = 700, B = 256, 28 rows per
     // cluster over the chip: 9.2 vs 8.6 measured)
-    const bool fine = choose_ks(B, N, tun, 4) == 4;
-    const double tile_us = fine ? (planes == 2 ? 0.0072 * N + 3.9 : 0.0047 * N + 3.1)
-                                : (planes == 2 ? 0.0142 * N + 4.0 : 0.0088 * N + 2.0);
-    if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.9 * tile_us) return none;
+    if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.9 * best_tile_us(mode, B, N, tun)) return none;
     return p;
 }
 // the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]
@@ -548,6 +583,10 @@ struct PtilePlan {
     int slices = 0;  // 0: not this kernel
     int rbs = 0;     // row blocks per slice (the last one may hold fewer)
 };
+// a resident round of 32 x 128 tiles (us per step; fits of the regime map: DL 30.9 at N = 1000, 59 at N = 2000)
+double ptile_round_us(int mode, int N) {
+    return mode == MODE_DL ? 0.0281 * N + 2.8 : 0.0145 * N + 1.4 + (mode == MODE_MF ? 0.4 : 0.0);
+}
 PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     PtilePlan p;
     (void)vs;  // per-variable saturation is the kernel's VS template parameter (ptile_launch_*): every variant exists, the plan is the same
@@ -557,17 +596,12 @@ PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     if (ncb > PT_FLAG_WORDS || ncb > chip.cus) return p;
     const int fit = chip.cus / ncb;  // row blocks one resident grid holds
     const int slices = (nrb + fit - 1) / fit;
-    if (slices == 1) {
-        if (a.ks != 1) return p;
-        if (tun.ptile < 0 && 4 * nrb * ncb < 3 * chip.cus) return p;
-    } else if (tun.ptile < 0) {
-        static const double resident[3] = {0.91, 0.76, 0.82};                        // MODE_DL, MODE_MF, MODE_LANGEVIN
-        static const double rel[3][3] = {{1.0, 0.54, 0.37}, {1.0, 0.49, 0.37}, {1.0, 0.48, 0.37}};  // KS = 1, 2, 4
-        const int m = mode == MODE_MF ? 1 : mode == MODE_LANGEVIN ? 2 : 0;
-        const int tiles = a.nrb * a.ncb;
-        const double step_cost = rel[m][a.ks == 1 ? 0 : a.ks == 2 ? 1 : 2] * ((tiles + chip.cus - 1) / chip.cus);
-        if (resident[m] * slices >= 0.97 * step_cost) return p;
-    }
+    // By default: where the resident slices are estimated no more than 5 % behind the best per-step shape (round 5; before:
+    // one slice only on grids that fill three quarters of the chip, several by a model in relative rounds that priced
+    // every round of 32 x 32 tiles as a lone one -- DL N = 1500, B = 512: resident 45.4 us against 39.3 on three rounds of
+    // 32 x 32 tiles; N = 1000, B = 768: 31.2 against 28.8; and N = 1500, B = 384, half the chip: resident 45.2 against
+    // 47.0 on 32 x 128 tiles per step, but 37.2 on 32 x 32)
+    if (tun.ptile < 0 && slices * ptile_round_us(mode, a.N) > 1.05 * best_tile_us(mode, a.B, a.N, tun)) return p;
     p.slices = slices;
     p.rbs = (nrb + slices - 1) / slices;
     return p;
@@ -583,28 +617,12 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Replay
 // noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
-    const bool two = mode == MODE_DL;
-    const double mf = mode == MODE_MF ? 1.0 : 0.0;
     if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return sp.est_us;
-    if (want_cluster(B, N, tun, mode, false)) {
-        // rounds of resident clusters; a round by K (cluster kernel: measured at B = 1000)
-        static const double round_us[4][3] = {{7.9, 4.27, 3.77}, {10.1, 5.38, 4.87}, {18.1, 9.6, 8.9}, {21.8, 11.4, 10.7}};
-        const ChipGeometry chip = chip_of(tun);
-        const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
-        const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
-        const int k = round_up(N, 128) / 128 - 3;  // K = 384, 512, 640, 768
-        return (count + per_round - 1) / per_round * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
-    }
+    if (want_cluster(B, N, tun, mode, false)) return cluster_us(mode, B, N, chip_of(tun));
     StepArgs a;
-    base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
-    if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices)
-        return pp.slices * (two ? 0.0281 * N + 2.8 : 0.0145 * N + 1.4 + 0.4 * mf);
-    // per-step kernel: rounds of workgroups plus what a launch costs once (a lone round of 32 x 64 tiles 19.4 us at
-    // N = 1000, three rounds 51.4)
-    const int cus = chip_of(tun).cus, rounds = (a.nrb * a.ncb + cus - 1) / cus;
-    if (a.ks == 1) return rounds * (two ? 0.0267 * N + 7.3 : 0.0122 * N + 7.3 + 1.9 * mf);
-    if (a.ks == 2) return rounds * (two ? 0.0142 * N + 2.8 : 0.0088 * N + 1.2 + 1.0 * mf) + (two ? 2.4 : 1.6);
-    return rounds * (two ? 0.0072 * N + 3.9 : 0.0047 * N + 3.1 + 0.5 * mf);
+    base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, mode);
+    if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices) return pp.slices * ptile_round_us(mode, N);
+    return tile_us(mode, a.ks, B, N, chip_of(tun).cus);  // per-step kernel, the shape base_args chose
 }
 // rows of the first part (a multiple of 64: the parts' pitched arrays and workspaces tile the batch's), 0: no cut
 int split_rows(int mode, int B, int N, const Tuning& tun) {
@@ -628,7 +646,7 @@ int split_rows(int mode, int B, int N, const Tuning& tun) {
     const int cut = (B / rows_fit) * rows_fit / 64 * 64;
     if (cut <= 0 || cut >= B) return 0;
     if (tun.split > 0) return cut;
-    return plan_us(mode, cut, N, tun) + plan_us(mode, B - cut, N, tun) < 0.93 * plan_us(mode, B, N, tun) ? cut : 0;
+    return plan_us(mode, cut, N, tun) + plan_us(mode, B - cut, N, tun) < 0.97 * plan_us(mode, B, N, tun) ? cut : 0;
 }
 __global__ void status_merge_kernel(unsigned* whole, unsigned* part) {
     if (*part) { *whole = *part; *part = 0u; }
@@ -928,7 +946,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
                       sh.ncg * sh.kh > 4 ? 512 : 256, TABLE_STEPS);
     } else {
         StepArgs a;
-        base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4);
+        base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, solver);
         if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0, solver); plan.slices == 1) {
             std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s%s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
                           solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", a.nrb * a.ncb,
@@ -1025,7 +1043,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     const double Sd = p->pump > 1.0 ? std::sqrt(p->pump - 1.0) : 1.0;  // dl_solver.py:140-141
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun, 4);
+    base_args(a, Q, V, B, N, ld, tun, 4, MODE_DL);
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
     if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
@@ -1428,7 +1446,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         return fail(CCVM_E_HIP, "%s: memset failed", fn);
 
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun, 4);
+    base_args(a, Q, V, B, N, ld, tun, 4, MODE_MF);
     a.in_scale = (float)(ul / S_eff);
     a.in_shift = (float)up;
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &a.qsum, p->qsum))) return rc;
@@ -1587,7 +1605,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
 
     const double ul = p->upper - p->lower, up = p->upper + p->lower;
     StepArgs a;
-    base_args(a, Q, V, B, N, ld, tun, s_full ? 2 : 4);  // (the composed per-element-saturation path below runs MODE_AFFINE)
+    base_args(a, Q, V, B, N, ld, tun, s_full ? 2 : 4, s_full ? -1 : MODE_LANGEVIN);  // (the composed per-element-saturation path below runs MODE_AFFINE)
     a.in_scale = (float)(ul / (2.0 * S_eff));  // langevin_solver.py:133
     a.in_shift = (float)(up / 2.0);
     if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;

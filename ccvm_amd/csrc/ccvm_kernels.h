@@ -14,7 +14,7 @@
 //   producers (waves 4-7): stream tiles L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA: no
 //     VGPRs, no ds_write), four tiles ahead in a 4-stage ring, and generate the Threefry
 //     normals for the consumers' accumulator elements into LDS.
-// Why this shape (all measured with tools/ablate.hip): a single wave issues in
+// Why this shape (all measured with tools/ablate.hip, see docs/kernel-step.md): a single wave issues in
 // order, so any LDS/VMEM/VALU issue stall delays its next MFMA; ds_write_b128 staging from
 // VGPRs blocked the SIMD's MFMA for its 13-cycle data transfer; L2-hit latency under load is
 // ~1.5 us, so >= 3 tiles must be in flight.
@@ -22,7 +22,7 @@
 // address of the DMA (dest is lane-linear by hardware); the input map x*scale+shift is folded
 // into the epilogue as  scale*(x@Q) + shift*colsum(Q).  Inside a K tile lane-half h owns
 // k in [16h, 16h+16); the k order differs from the reference's BLAS, which is inside the
-// stated fp32 tolerance.
+// stated fp32 tolerance (docs/parity.md).
 #pragma once
 #include "ccvm_common.h"
 

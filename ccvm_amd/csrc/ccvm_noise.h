@@ -6,7 +6,7 @@
 // Chosen over Philox4x32 and over more rounds for this chip: on gfx950 every VALU instruction
 // costs matrix-pipe time (the f32 MFMA shares the FP32 datapath; measured with tools/coissue.hip
 // and tools/filler.hip), Philox needs two quarter-rate 32x32->64 multiplies per round, and
-// Threefry is add / rotate / xor only ("Noise").
+// Threefry is add / rotate / xor only (docs/noise.md).
 //
 //   counter = (column, global_row_lo),  key = (K_lo, K_hi ^ global_row_hi),
 //   K = step_key(seed, step) = splitmix64 finaliser of  seed + 0x9E3779B97F4A7C15 * (step + 1)

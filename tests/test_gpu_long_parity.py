@@ -3,9 +3,9 @@ the PUBLIC solver API in replay mode (identical seeded noise: the normals come f
 the reference's order) against the oracle -- the reference's op sequence on the host -- at the stated
 shapes and hundreds to thousands of steps, not a handful.
 
-Each case appends its measured deviations to gpurun_out/r02_parity.jsonl (the table in
-profiles/r02_parity.md is made from that file).  Gates: the tolerance DESIGN.md section 5 states from
-these measurements, per shape -- no sqrt(N/20) extrapolation.
+A run writes nothing by itself; with $CCVM_PARITY_RECORD naming a file each case appends its measured deviations to it
+as one JSON line (tools/make_parity_md.py makes profiles/rNN_parity.md from such a file).  Gates: the tolerance
+docs/parity.md states from these measurements, per shape -- no sqrt(N/20) extrapolation.
 """
 import json
 import os

@@ -85,7 +85,7 @@ def test_solver_matches_reference_golden(tag, case, kernel_path):
     # Adam runs with alpha = 0.001 and no add_assign barely move (objective far from optimum,
     # values ~20-60); every case uses the same absolute gates.
     n = g.instance["problem_size"]
-    gate = math.sqrt(max(n, 20) / 20.0)  # the stated gates scale with sqrt(N / 20)
+    gate = math.sqrt(max(n, 20) / 20.0)  # the stated gates scale with sqrt(N / 20) (docs/parity.md)
     for field in g.fields(case):
         want = g.out(case, field)
         got = sol.objective_values if field == "objective_values" else sol.variables[field]

@@ -88,3 +88,29 @@ def test_bench_multi_rank_line(extra, scaling):
     assert roof["bound"] in ("mfma", "latency", "issue") and 0 < roof["frac"] < 1 and roof["achieved"] > 0
     assert line["check"]["objective_values_finite"] is True
     assert "cpu_baseline" not in line  # rank 0 at N = 1 only
+
+
+def test_bench_collectives_set_up_rccl_next_to_the_gloo_control_group():
+    """bench.init_collectives as the driver's ranks run it (round 5): default group gloo, the data collective on an
+    RCCL group proven by a warm-up all-reduce -- here with the one rank a 1-GPU box allows, which still exercises group
+    creation beside an existing gloo group, the device-side all-gather through it, and the agreement step."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(HERE)!r})\n"
+        "import bench\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "coll = bench.init_collectives(0, 1, dev, share=False)\n"
+        "assert coll['collective'] == 'RCCL' and coll['group'] is not None and coll['device'] == dev, coll\n"
+        "x = torch.arange(5, dtype=torch.float32, device=dev)\n"
+        "parts = [torch.empty_like(x)]\n"
+        "dist.all_gather(parts, x, group=coll['group'])\n"
+        "assert torch.equal(parts[0], x) and dist.get_backend(coll['group']) == 'nccl' and dist.get_backend() == 'gloo'\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stderr[-3000:]

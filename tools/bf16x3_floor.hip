@@ -128,11 +128,14 @@ __global__ __launch_bounds__(512) void floor_kernel(const char* __restrict__ aim
 
     // ---------------- consumers: wave w owns columns [32 w, 32 w + 32) ----------------
     const int half = lane >> 5, l31 = lane & 31;
-    f32x16 acc[NA];
+    // consecutive MFMAs never depend on each other: DL alternates its two planes, a one-plane solver deals the six
+    // products to two accumulators (four accumulators for DL would spill next to the double-buffered fragments)
+    constexpr int NACC = NA == 1 ? 2 : 1;
+    f32x16 acc[NA][2];
 #pragma unroll
     for (int n = 0; n < NA; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[n][0][r] = acc[n][1][r] = 0.0f;
     struct Frags { bf16x8 a[SPS][NA][3]; bf16x8 q[SPS][3]; };
     auto read = [&](Frags& f, int slot) {
         if constexpr (MODE == 2) return;
@@ -151,20 +154,24 @@ __global__ __launch_bounds__(512) void floor_kernel(const char* __restrict__ aim
                 f.q[sl][sp] = *reinterpret_cast<const bf16x8*>(qp + (sp * 256 + half * 128 + 32 * wave + l31) * 16);
         }
     };
+    // products smallest first: x1 q3, x2 q2, x3 q1, then x1 q2, x2 q1, then x1 q1
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PQ[6] = {2, 1, 0, 1, 0, 0};
     auto mfma = [&](const Frags& f) {
         if constexpr (MODE == 2) return;
 #pragma unroll
         for (int sl = 0; sl < SPS; ++sl)
 #pragma unroll
-            for (int n = 0; n < NA; ++n) {
-                // smallest first: x1 q3, x2 q2, x3 q1, then x1 q2, x2 q1, then x1 q1
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][2], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][1], f.q[sl][1], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][2], f.q[sl][0], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][1], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][1], f.q[sl][0], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][0], f.q[sl][0], acc[n], 0, 0, 0);
-            }
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int n = 0; n < NA; ++n)
+                    acc[n][p % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sl][n][PA[p]], f.q[sl][PQ[p]], acc[n][p % NACC], 0, 0, 0);
+        // the next stage's fragment reads go into the issue gaps of these MFMAs, a few at a time
+        constexpr int NMF = SPS * 6 * NA, NRD = SPS * (3 * NA + 3);
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
     };
     Frags f0, f1;
     __builtin_amdgcn_s_barrier();  // barrier_0: stage 0 landed
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(512) void floor_kernel(const char* __restrict__ aim
 #pragma unroll
     for (int n = 0; n < NA; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[n][r];
+        for (int r = 0; r < 16; ++r) s += acc[n][0][r] + acc[n][1][r];
     if (s == 123.456f) out[blockIdx.x] = s;
 }
 

@@ -1,4 +1,4 @@
-// Ablation harness for the column-cluster persistent kernel (developer tool): Langevin (or DL: -DCCVM_ABL_DL), N = 500, B = 1000.
+// Ablation harness for the column-cluster persistent kernel (developer tool): Langevin (or DL: -DCCVM_ABL_DL, MF: -DCCVM_ABL_MF), N = 500, B = 1000.
 //   for b in 0 1 2 4 ...; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DCCVM_CLUSTER_ABL=$b tools/cluster_ablate.hip -o tools/cluster_ablate_$b; done
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,6 +26,10 @@ int main(int argc, char** argv) {
     constexpr int MODE = MODE_DL;
     DlSched sc{2.5, 0.002, 10.0, 1.0, 0.05, 1.0, 1.2247, 1, 15000, 0, steps};
     hipLaunchKernelGGL(dl_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
+#elif defined(CCVM_ABL_MF)
+    constexpr int MODE = MODE_MF;  // the example's parameters (examples/ccvm_boxqp_mf.py: pump 0, feedback_scale 4000, j 5, S 20, dt 0.0025)
+    MfSched sc{0.0, 0.0025, 5.0, 4000.0, 0.01, 20.0, 1.0, 1, 15000, 0, steps, AdamSched{}};
+    hipLaunchKernelGGL(mf_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
 #else
     constexpr int MODE = MODE_LANGEVIN;
     LvSched sc{0.002, 0.5, 1.0, 0.5, 2.0, 1.0, 1, 1, 15000, 0, steps, AdamSched{}};
@@ -35,6 +39,7 @@ int main(int argc, char** argv) {
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
     a.status = sync;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
+    a.k_first = 4.47f; a.S = 20.0f;  // MF only: sqrt(1 / (4 j)) / sqrt(dt), the measured amplitude's clamp
     const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512
     a.nclusters = (B + crows - 1) / crows; a.G = (N + 63) / 64;
     a.spread = getenv("CL_SPREAD") ? atoi(getenv("CL_SPREAD")) : 0;
@@ -58,7 +63,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
-        if (rep == 2) printf("%s ABL=%2d N=%d B=%d grid %d: %.3f us/step%s\n", MODE == MODE_DL ? "DL" : "LV", CCVM_CLUSTER_ABL, N, B, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
+        if (rep == 2) printf("%s ABL=%2d N=%d B=%d grid %d: %.3f us/step%s\n", MODE == MODE_DL ? "DL" : MODE == MODE_MF ? "MF" : "LV", CCVM_CLUSTER_ABL, N, B, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
     }
     if (CCVM_CLUSTER_ABL & 64) {
         std::vector<unsigned long long> hd((size_t)grid * 16);

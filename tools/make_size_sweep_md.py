@@ -5,12 +5,21 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
+ran = {}  # what ccvm_describe_launch said ran (tools/time_small.py prints it since round 5)
+NAMES = {"R": "persistent row-owner", "S": "column-slab persistent", "C": "column-cluster persistent",
+         "P": "persistent tile kernel", "T1": "per-step tile kernel, 32 x 128 tiles", "T2": "per-step tile kernel, 32 x 64 tiles",
+         "T4": "per-step tile kernel, 32 x 32 tiles"}
+
+
 def parse(path):
     out = {}
     for line in open(path):
-        m = re.match(r"(\w+):(\d+):(\d+)(:adam)?\s+RU=\w+\s+([\d.]+) us/step", line)
+        m = re.match(r"(\w+):(\d+):(\d+)(:adam)?\s+RU=\w+\s+([\d.]+) us/step.*?(?:\[([^\]]+)\])?$", line.rstrip())
         if m:
-            out[(m.group(1) + (" + Adam" if m.group(4) else ""), int(m.group(2)), int(m.group(3)))] = float(m.group(5))
+            key = (m.group(1) + (" + Adam" if m.group(4) else ""), int(m.group(2)), int(m.group(3)))
+            out[key] = float(m.group(5))
+            if m.group(6):
+                ran[key] = m.group(6)
     return out
 
 
@@ -46,4 +55,6 @@ for (k, n, b), t in sorted(auto.items(), key=lambda kv: (kv[0][0], kv[0][1])):
     tf = flops[k] * n * n * b / (t * 1e-6) / 1e12
     tl = tile.get((k, n, b))
     extra = "" if tl is None else f"{tl:.2f}, {flops[k] * n * n * b / (tl * 1e-6) / 1e12 / 157.3:.2f}"
-    print(f"| {k} | {n} | {b} | {path(n)} | {t:.2f} | {tf:.1f} | {tf / 157.3:.2f} | {extra} |")
+    fam = ran.get((k, n, b))
+    what = path(n) if fam is None else " + ".join(NAMES.get(f, NAMES.get(f[:1], f) + (f" ({f[1:]} slices)" if f[:1] == "P" and f[1:] else "")) for f in fam.split("+"))
+    print(f"| {k} | {n} | {b} | {what} | {t:.2f} | {tf:.1f} | {tf / 157.3:.2f} | {extra} |")

@@ -198,21 +198,33 @@ def markdown(tag):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", default=None)
+    ap.add_argument("--regime-md", default=None, help="print profiles/<TAG>_regime_map.md (the default plan of every cell) from the audit's data")
     ap.add_argument("--out", default=None, help="measure: the jsonl file to append to; --md: comma-separated files to read")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--ns", default=",".join(map(str, NS)))
     ap.add_argument("--bs", default=",".join(map(str, BS)))
     args = ap.parse_args()
-    if args.out and not args.md:
+    if args.out and not (args.md or args.regime_md):
         PATH = args.out
-    if args.md and args.out:
+    if (args.md or args.regime_md) and args.out:
         import tempfile
         merged = tempfile.NamedTemporaryFile("w", suffix=".jsonl", delete=False)
         for f in args.out.split(","):
             merged.write(open(f).read())
         merged.close()
         PATH = merged.name
-    if args.md:
+    if args.regime_md:
+        from tools.regime_map import markdown as regime_markdown
+
+        rows = []
+        for (kind, n, b), r in sorted(load().items()):
+            d = next((p for p in r["plans"] if p.get("us") and "default" in p["variants"]), None)
+            if d:
+                rows.append({"kind": kind, "n": n, "b": b, "us": d["us"], "family": d["family"]})
+        regime_markdown(args.regime_md, rows, how="`python3 tools/policy_regret.py` (the default plan of every cell of the "
+                        "regret audit, `profiles/" + args.regime_md + "_policy_regret.md`): run calls of the engine, fused noise, "
+                        "64-4096 steps of about 50 ms, best of 3, no profiler.")
+    elif args.md:
         markdown(args.md)
     else:
         measure(args.kinds.split(","), [int(x) for x in args.ns.split(",")], [int(x) for x in args.bs.split(",")])

@@ -13,8 +13,10 @@ PATH = os.path.join("gpurun_out", "regime_map.jsonl")
 
 def family(kernel):
     if kernel.startswith("batch cut in two"):
-        first, rest = kernel[len("batch cut in two: "):].split(" | ", 1)
-        return family(first.split(" ", 2)[2]) + "+" + family(rest.split(" ", 2)[2])
+        # "batch cut in two: rows a-b <plan> | rows c-d <plan>"; a part may be cut again, and the library's 512-byte
+        # buffers may truncate a nested description: name the families in the order their kernels appear
+        parts = re.findall(r"rows \d+-\d+ (?:batch cut in two: )?(ccvm::\w+<[^>]*>[^|]*)", kernel)
+        return "+".join(family(part) for part in parts) or "?"
     if "persist_kernel" in kernel:
         return "R"
     if "slab_kernel" in kernel:
@@ -56,11 +58,12 @@ def measure():
                 del traj
 
 
-def markdown(tag):
-    rows = [json.loads(line) for line in open(PATH)]
+def markdown(tag, rows=None, how=None):
+    """`rows`: records {kind, n, b, us, kernel or family} (default: this tool's own measurements)."""
+    rows = rows if rows is not None else [json.loads(line) for line in open(PATH)]
     print(f"# Round {tag[1:].lstrip('0')}: the regime map (1x MI355X, default launch policy)\n")
-    print("`python3 tools/regime_map.py`: run calls of the engine (fused noise; 128-4096 steps, about 60 ms each), best of 3, "
-          "no profiler.  Cell = us per step, kernel family: R row-owner persistent, S column-slab persistent, C "
+    print((how or "`python3 tools/regime_map.py`: run calls of the engine (fused noise; 128-4096 steps, about 60 ms each), best of 3, "
+          "no profiler.") + "  Cell = us per step, kernel family: R row-owner persistent, S column-slab persistent, C "
           "column-cluster persistent, P persistent tile (32 x 128 tiles resident over the chunk; round 4; Pk: k slices of the batch one after the other; X+Y: the batch cut in two, rows of whole resident grids + the rest), T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
           "table: fraction of the fp32 MFMA peak (157.3 TFLOP/s; DL 4 N^2 B flop per step, the others 2 N^2 B).\n")
     for kind in KINDS:
@@ -75,7 +78,7 @@ def markdown(tag):
                     if not r:
                         cells.append("")
                     elif what == "us":
-                        cells.append(f"{r['us']:.2f} {family(r['kernel'])}")
+                        cells.append(f"{r['us']:.2f} {r.get('family') or family(r['kernel'])}")
                     else:
                         flop = (4.0 if kind == "dl" else 2.0) * n * n * b
                         cells.append(f"{flop / (r['us'] * 1e-6) / 157.3e12:.2f}")

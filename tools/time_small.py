@@ -23,5 +23,11 @@ for case in cases:
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     traj.check()
+    # what ran, in the regime map's letters (ccvm_describe_launch under the current tuning environment)
+    import ctypes
+    from ccvm_amd import _lib
+    from tools.regime_map import family
+    buf = ctypes.create_string_buffer(1024)
+    _lib.load().ccvm_describe_launch(bench.SOLVER_ID[kind], b, n, 1 if adam else 0, 0, buf, 1024)
     print(f"{case:24s} RU={os.environ.get('CCVM_AMD_PERSIST_RU', 'auto'):4s} {best / steps * 1e6:8.3f} us/step "
-          f"{steps * b / best:.3e} row-steps/s", flush=True)
+          f"{steps * b / best:.3e} row-steps/s  [{family(buf.value.decode())}]", flush=True)
