@@ -137,7 +137,7 @@ Tuning read_tuning() {
         t.force_tile = !std::strcmp(e, "tile");
         if (!std::strcmp(e, "cluster")) { t.cluster = 1; t.slab = 0; }
         if (!std::strcmp(e, "nocluster") || t.force_tile) t.cluster = t.slab = t.ptile = 0;  // no cross-workgroup kernel at all
-        if (!std::strcmp(e, "ptile")) t.ptile = 1;
+        if (!std::strcmp(e, "ptile")) { t.ptile = 1; t.slab = 0; }  // (the slab path is asked first: a forced family stands alone)
         if (!std::strcmp(e, "noptile")) t.ptile = 0;
         if (!std::strcmp(e, "slab")) t.slab = 1;
         if (!std::strcmp(e, "noslab")) t.slab = 0;

@@ -332,7 +332,7 @@ def test_going_back_on_a_workspace_never_meets_the_flags_of_later_steps(ptile, k
     them (Trajectories.rollback: no time-out, the run stays on this kernel), the same 40 steps again in other chunks --
     bit for bit the first pass, and the straight run of a fresh object."""
     want = _state(_run_engine(kind, n, b, 40, None, 5, 0))
-    traj = _run_engine(kind, n, b, 40, None, 5, 0, chunks=[])
+    traj = _run_engine(kind, n, b, 40, None, 5, 0, chunks=[0])  # (built, not advanced)
     traj.arm(force=True)
     traj.advance(40)
     assert traj.check(rerun=False, hold=True) is False
