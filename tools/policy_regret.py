@@ -157,10 +157,11 @@ def markdown(tag):
               f"{' / '.join(best['variants'])}) | {ratio:.2f} |")
     print()
     mono = []
+    ns, bs = sorted({n for _, n, _ in cells}), sorted({b for _, _, b in cells})  # (the standard grid + any extra cells)
     for kind in KINDS:
-        for n in NS:
+        for n in ns:
             series = []
-            for b in BS:
+            for b in bs:
                 r = cells.get((kind, n, b))
                 d = r and next((p for p in r["plans"] if p.get("us") and "default" in p["variants"]), None)
                 if d:
@@ -181,8 +182,8 @@ def markdown(tag):
         print(f"### {kind}\n")
         print("| N | B | default | other plans |")
         print("|---|---|---|---|")
-        for n in NS:
-            for b in BS:
+        for n in ns:
+            for b in bs:
                 r = cells.get((kind, n, b))
                 if not r:
                     continue

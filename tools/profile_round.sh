@@ -6,7 +6,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
@@ -36,7 +36,7 @@ if [ "${PART}" = classes ]; then
   done
   echo ALL_DONE; exit 0
 fi
-for w in dl_n1000_b1000 pl_n2000_b512 langevin_n500_b1000 dl_n100_b1000 dl_n1000_b32 dl_n1000_b256; do
+for w in dl_n1000_b1000 pl_n2000_b512 langevin_n500_b1000 mf_n500_b1000 dl_n100_b1000 dl_n1000_b32 dl_n1000_b256; do
   pmc fetch $w FETCH_SIZE
   pmc write $w WRITE_SIZE
   pmc sq1 $w SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT

@@ -66,14 +66,15 @@ def markdown(tag, rows=None, how=None):
           "no profiler.") + "  Cell = us per step, kernel family: R row-owner persistent, S column-slab persistent, C "
           "column-cluster persistent, P persistent tile (32 x 128 tiles resident over the chunk; round 4; Pk: k slices of the batch one after the other; X+Y: the batch cut in two, rows of whole resident grids + the rest), T1 / T2 / T4 per-step tile kernel with 32 x 128 / 32 x 64 / 32 x 32 tiles.  Second "
           "table: fraction of the fp32 MFMA peak (157.3 TFLOP/s; DL 4 N^2 B flop per step, the others 2 N^2 B).\n")
+    ns, bs = sorted({r["n"] for r in rows}), sorted({r["b"] for r in rows})
     for kind in KINDS:
         print(f"## {kind}\n")
         for what in ("us", "frac"):
-            print("| N \\\\ B | " + " | ".join(str(b) for b in BS) + " |")
-            print("|---|" + "---|" * len(BS))
-            for n in NS:
+            print("| N \\\\ B | " + " | ".join(str(b) for b in bs) + " |")
+            print("|---|" + "---|" * len(bs))
+            for n in ns:
                 cells = []
-                for b in BS:
+                for b in bs:
                     r = next((r for r in rows if r["kind"] == kind and r["n"] == n and r["b"] == b), None)
                     if not r:
                         cells.append("")
