@@ -224,9 +224,10 @@ def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag):
     word; its steps are garbage, and `traj.check` puts the trajectories back where the recovery snapshot was taken and
     moves the run to the per-step kernel.  The snapshot is taken ONCE, in front of the warm-up steps (two
     device-to-device copies: right in front of the timed region they would push Q and the state out of the L2s), the
-    status word is read right after the clock stops (4 bytes; inside the region it would cost ~25 us of a 0.65 ms run),
-    and a run that was recovered -- in its warm-up or in its timed region -- starts over from the snapshot on the path
-    that then runs, so `value` never describes discarded work.  `any_rank(flag)`: True when the flag is set
+    status word is read ONCE, right after the clock stops (4 bytes; inside the region it would cost ~25 us of a 0.65 ms
+    run, between warm-up and timed steps it would leave the chip idle for as long), and a run that was recovered -- the
+    word is set by warm-up and timed steps alike and never cleared by a kernel -- starts over from the snapshot on the
+    path that then runs, so `value` never describes discarded work.  `any_rank(flag)`: True when the flag is set
     on ANY rank: the ranks start over together (the barriers must pair up).
     Returns (wall seconds, stream ms, attempts)."""
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,24 +235,22 @@ def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag):
     ev1.record()  # BEFORE the timed region (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
     traj.arm(force=True)  # (forced: another rank may ask this one to start over although its own steps were valid)
     for attempt in (1, 2, 3):
-        traj.advance(warmup)
-        recovered = traj.check(rerun=False, hold=True)  # verified before the clock starts
+        traj.advance(warmup)  # (not verified by itself: a status word set here is still set behind the timed steps)
+        torch.cuda.synchronize(dev)
+        barrier()     # every rank starts its K steps together ...
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev0.record()
+        traj.advance(steps)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
+        #                                     inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
+        #                                     loss" on the driver's 0.7 ms); the job's time is the MAX over ranks
+        recovered = traj.check(rerun=False, hold=True)  # True: back at the snapshot, on the per-step kernel from here on
         if not any_rank(recovered):
-            torch.cuda.synchronize(dev)
-            barrier()     # every rank starts its K steps together ...
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            ev0.record()
-            traj.advance(steps)
-            ev1.record()
-            torch.cuda.synchronize(dev)
-            elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
-            #                                     inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
-            #                                     loss" on the driver's 0.7 ms); the job's time is the MAX over ranks
-            recovered = traj.check(rerun=False, hold=True)
-            if not any_rank(recovered):
-                traj.check()  # (drops the snapshot)
-                return elapsed, ev0.elapsed_time(ev1), attempt
+            traj.check()  # (drops the snapshot)
+            return elapsed, ev0.elapsed_time(ev1), attempt
         if not recovered:
             traj.rollback()  # another rank starts over: this one does with it
     raise SystemExit("bench.py: the run was invalid three times in a row")

@@ -124,22 +124,16 @@ def test_an_invalid_run_starts_over(monkeypatch):
     monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda dev=None: None)
     barriers = []
-    # the TIMED region of the first attempt is invalid (its warm-up check passes: the second check fails)
-    traj = _FakeTraj(invalid_checks=[False, True])
+    # the first attempt's steps (warm-up or timed: one status word) are invalid
+    traj = _FakeTraj(invalid_checks=[True])
     elapsed, stream_ms, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
     assert attempts == 2 and stream_ms == 1.25 and elapsed >= 0
     assert traj.calls == [(0, 5), (5, 20), (0, 5), (5, 20)]  # warm-up and timed steps again, from the snapshot
     assert traj.step == 25 and len(barriers) == 2  # one opening barrier per timed region
 
-    # invalid WARM-UP steps: no timed region is opened for that attempt
-    traj = _FakeTraj(invalid_checks=[True])
-    barriers.clear()
-    _, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
-    assert attempts == 2 and traj.calls == [(0, 5), (0, 5), (5, 20)] and len(barriers) == 1
-
     # valid here, invalid on another rank: this rank starts over WITH it (the barriers must pair up)
     traj = _FakeTraj(invalid_checks=[])
-    told = iter([False, True, False, False])  # attempt 1: warm-up fine, another rank's timed region invalid
+    told = iter([True, False])
     _, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None,
                                        any_rank=lambda flag: flag or next(told))
     assert attempts == 2 and traj.rollbacks == 1 and traj.calls == [(0, 5), (5, 20), (0, 5), (5, 20)]

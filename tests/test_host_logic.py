@@ -226,3 +226,15 @@ def test_wrong_algorithm_parameters_type_is_rejected_before_the_engine_is_touche
         solver.parameter_key = {20: dict(g.cases[keys[kind]]["params"])}
         with pytest.raises(ValueError, match="Solver option type <class 'str'> is not supported."):
             solver(instance=inst, algorithm_parameters="adam")
+
+
+def test_design_tables_are_generated_from_the_committed_profiles():
+    """DESIGN.md's roofline table is written by tools/make_design_tables.py from profiles/rNN_bench*.json and the PMC
+    summaries (numbers not typed by hand): the committed file must be what the tool writes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "make_design_tables.py"), "--check"])
+    assert run.returncode == 0, "run `python tools/make_design_tables.py` and commit DESIGN.md"

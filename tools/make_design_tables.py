@@ -105,10 +105,10 @@ BLOCKS = {"roofline": roofline_block}
 
 def render(text):
     for name, fn in BLOCKS.items():
-        pat = re.compile(rf"(<!-- BEGIN GENERATED: {name} -->\n).*?(\n<!-- END GENERATED: {name} -->)", re.S)
+        pat = re.compile(rf"(<!-- BEGIN GENERATED: {name} -->\n).*?(<!-- END GENERATED: {name} -->)", re.S)
         if not pat.search(text):
             raise SystemExit(f"DESIGN.md has no GENERATED block {name!r}")
-        text = pat.sub(lambda m: m.group(1) + fn() + m.group(2), text)
+        text = pat.sub(lambda m: m.group(1) + fn() + "\n" + m.group(2), text)
     return text
 
 

@@ -18,7 +18,7 @@ def parse(path):
         if m:
             key = (m.group(1) + (" + Adam" if m.group(4) else ""), int(m.group(2)), int(m.group(3)))
             out[key] = float(m.group(5))
-            if m.group(6):
+            if m.group(6) and path.endswith("_auto.txt"):  # (the second pass forces the per-step kernel: not what runs by default)
                 ran[key] = m.group(6)
     return out
 
