@@ -54,13 +54,27 @@ def set_env(env):
     os.environ.update(env)
 
 
+ADAM = None  # --adam: the example scripts' Adam variant of MF / Langevin (alpha 0.001, beta1 0.9, beta2 0.999)
+
+
+def describe(kind, b, n):
+    import ctypes
+
+    import bench
+    from ccvm_amd import _lib
+
+    buf = ctypes.create_string_buffer(1024)
+    _lib.check(_lib.load().ccvm_describe_launch(bench.SOLVER_ID[kind], b, n, 1 if ADAM else 0, 0, buf, 1024), "ccvm_describe_launch")
+    return buf.value.decode()
+
+
 def time_cell(kind, n, b, budget_s=0.05):
     """us per step of the plan the current environment selects; None when a persistent kernel timed out."""
     import torch
 
     import bench
 
-    traj, _, _ = bench.make_trajectories(kind, n, b, 1 << 20, 0)
+    traj, _, _ = bench.make_trajectories(kind, n, b, 1 << 20, 0, adam=ADAM)
     traj.advance(64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -92,13 +106,13 @@ def measure(kinds, ns, bs):
     for kind in kinds:
         for n in ns:
             for b in bs:
-                if (kind, n, b) in done:
+                if (kind + ("+adam" if ADAM else ""), n, b) in done:
                     continue
-                seen, rec = {}, {"kind": kind, "n": n, "b": b, "plans": []}
+                seen, rec = {}, {"kind": kind + ("+adam" if ADAM else ""), "n": n, "b": b, "plans": []}
                 for name in variants_for(n):
                     set_env(VARIANTS[name])
                     try:
-                        kernel = bench.describe_launch(kind, b, n)
+                        kernel = describe(kind, b, n)
                     except Exception as exc:  # noqa: BLE001 -- a forced plan the library refuses
                         rec["plans"].append({"variant": name, "error": str(exc)[:120]})
                         continue
@@ -158,7 +172,8 @@ def markdown(tag):
     print()
     mono = []
     ns, bs = sorted({n for _, n, _ in cells}), sorted({b for _, _, b in cells})  # (the standard grid + any extra cells)
-    for kind in KINDS:
+    kinds = sorted({k for k, _, _ in cells}, key=lambda k: (KINDS + (k,)).index(k))
+    for kind in kinds:
         for n in ns:
             series = []
             for b in bs:
@@ -178,7 +193,7 @@ def markdown(tag):
         print(f"| {kind} | {n} | {b} | {d['us']:.2f} ({d['family']}) | {b2} | {d2['us']:.2f} ({d2['family']}) | {ratio:.2f} |")
     print()
     print("## Every cell: default vs forced plans (us per step)\n")
-    for kind in KINDS:
+    for kind in kinds:
         print(f"### {kind}\n")
         print("| N | B | default | other plans |")
         print("|---|---|---|---|")
@@ -201,6 +216,7 @@ if __name__ == "__main__":
     ap.add_argument("--md", default=None)
     ap.add_argument("--regime-md", default=None, help="print profiles/<TAG>_regime_map.md (the default plan of every cell) from the audit's data")
     ap.add_argument("--out", default=None, help="measure: the jsonl file to append to; --md: comma-separated files to read")
+    ap.add_argument("--adam", action="store_true", help="the Adam variants (kinds mf, langevin); records carry kind 'mf+adam' / 'langevin+adam'")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--ns", default=",".join(map(str, NS)))
     ap.add_argument("--bs", default=",".join(map(str, BS)))
@@ -228,4 +244,7 @@ if __name__ == "__main__":
     elif args.md:
         markdown(args.md)
     else:
-        measure(args.kinds.split(","), [int(x) for x in args.ns.split(",")], [int(x) for x in args.bs.split(",")])
+        if args.adam:
+            ADAM = {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False}
+        measure([k for k in args.kinds.split(",") if not (args.adam and k == "dl")], [int(x) for x in args.ns.split(",")],
+                [int(x) for x in args.bs.split(",")])
