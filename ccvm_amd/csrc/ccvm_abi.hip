@@ -129,6 +129,7 @@ struct Tuning {
     int ptile = CLUSTER_DEFAULT;     // persistent streamed-Q tile kernel: 1 wherever it applies, 0 never, -1: see want_ptile
     int split = CLUSTER_DEFAULT;     // batches cut into a part of whole resident grids and the rest: 1 wherever a cut exists, 0 never, -1: see split_rows
     ChipGeometry chip{0, 0};  // 0: ask the device
+    bool adam = false;        // the run's Adam variant (set by the entry points, not by the environment): the estimates below price it
 };
 
 Tuning read_tuning() {
@@ -210,13 +211,17 @@ constexpr TileFit TILE_FIT[3][3] = {  // [DL, MF, Langevin / pumped Langevin][32
     {{5.368, 0.01329, 1.220, 0.00084, 0.01423, 5.919, -0.236, -0.170}, {3.885, 0.00673, 0.915, 0.00043, 0.00762, 2.832, 0.145, -0.248}, {4.030, 0.00340, -0.951, 0.00297, 0.00338, 1.840, 1.671, 0.498}},
     {{4.305, 0.01342, 0.344, 0.00087, 0.01364, 3.313, 0.882, 0.125}, {3.960, 0.00677, 0.193, 0.00076, 0.00684, 1.731, 1.735, 0.119}, {3.616, 0.00373, -0.514, 0.00119, 0.00257, 1.121, 2.735, 0.865}}};
 int fit_row(int mode) { return mode == MODE_MF ? 1 : mode == MODE_LANGEVIN ? 2 : 0; }
-double tile_us(int mode, int ks, int B, int N, int cus) {
+// The Adam variants (MF / Langevin: moments read and written every step by the per-step kernel, kept in registers by the
+// persistent ones) cost more by family -- medians over the 84 audited cells (profiles/r05_policy_regret_adam.md): per-step
+// tiles x 1.15 (32 x 32: 1.12), cluster x 1.175, resident tile x 1.10, slab x 1.05.
+double tile_us(int mode, int ks, int B, int N, int cus, bool adam = false) {
     const TileFit& f = TILE_FIT[fit_row(mode)][ks == 1 ? 0 : ks == 2 ? 1 : 2];
     const int tiles = ((B + BM - 1) / BM) * ((N + BN / ks - 1) / (BN / ks));
+    const double up = adam ? (ks == 4 ? 1.12 : 1.15) : 1.0;
     // one round: what a lone workgroup takes, plus what the chip's share of the grid adds (more workgroups stream more
     // through the L2s); several rounds: rounds x a round, plus what a launch pays once
-    if (tiles <= cus) return f.l0 + f.l1 * N + (double)tiles / cus * (f.m0 + f.m1 * N);
-    return ((tiles + cus - 1) / cus) * (f.a * N + f.b + f.q * 1e-6 * N * N) + f.e;
+    if (tiles <= cus) return up * (f.l0 + f.l1 * N + (double)tiles / cus * (f.m0 + f.m1 * N));
+    return up * (((tiles + cus - 1) / cus) * (f.a * N + f.b + f.q * 1e-6 * N * N) + f.e);
 }
 bool solver_mode(int mode) { return mode == MODE_DL || mode == MODE_MF || mode == MODE_LANGEVIN; }
 
@@ -233,14 +238,14 @@ int choose_ks(int B, int N, const Tuning& tun, int max_ks, int mode = -1) {
     static const double rel[3] = {1.0, 0.54, 0.37};
     for (int i = 0, ks = 1; ks <= max_ks && i < 3; ++i, ks *= 2) {
         const int tiles = nrb * ((N + BN / ks - 1) / (BN / ks));
-        const double cost = solver_mode(mode) ? tile_us(mode, ks, B, N, cus) : rel[i] * ((tiles + cus - 1) / cus);
+        const double cost = solver_mode(mode) ? tile_us(mode, ks, B, N, cus, tun.adam) : rel[i] * ((tiles + cus - 1) / cus);
         if (i == 0 || cost < 0.97 * best) { best = cost; best_ks = ks; }
     }
     return best_ks;
 }
 // the cheapest per-step plan's estimate (solver steps)
 double best_tile_us(int mode, int B, int N, const Tuning& tun) {
-    return tile_us(mode, choose_ks(B, N, tun, 4, mode), B, N, chip_of(tun).cus);
+    return tile_us(mode, choose_ks(B, N, tun, 4, mode), B, N, chip_of(tun).cus, tun.adam);
 }
 
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
@@ -394,12 +399,12 @@ bool cluster_spread(int B, int N, const ChipGeometry& chip) {
 }
 // what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 384 / 512 / 640 / 768
 // (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it)
-double cluster_us(int mode, int B, int N, const ChipGeometry& chip) {
+double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false) {
     static const double round_us[4][3] = {{7.9, 4.27, 3.77}, {10.1, 5.38, 4.87}, {18.1, 9.6, 8.9}, {21.8, 11.4, 10.7}};
     const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
     const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
     const int k = round_up(N, 128) / 128 - 3;
-    return (count + per_round - 1) / per_round * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
+    return (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
 }
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
@@ -448,7 +453,7 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // 32 x 32 tiles do -- DL N = 640, B = 768: 18.3 us against 14.6; N = 300, B = 768: 7.9 against 6.1; N = 768, B = 1500
     // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 5 %
     // behind the best per-step shape
-    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip)) return false;
+    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip, tun.adam)) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
@@ -584,8 +589,8 @@ struct PtilePlan {
     int rbs = 0;     // row blocks per slice (the last one may hold fewer)
 };
 // a resident round of 32 x 128 tiles (us per step; fits of the regime map: DL 30.9 at N = 1000, 59 at N = 2000)
-double ptile_round_us(int mode, int N) {
-    return mode == MODE_DL ? 0.0281 * N + 2.8 : 0.0145 * N + 1.4 + (mode == MODE_MF ? 0.4 : 0.0);
+double ptile_round_us(int mode, int N, bool adam = false) {
+    return (adam ? 1.10 : 1.0) * (mode == MODE_DL ? 0.0281 * N + 2.8 : 0.0145 * N + 1.4 + (mode == MODE_MF ? 0.4 : 0.0));
 }
 PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     PtilePlan p;
@@ -601,7 +606,7 @@ PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     // every round of 32 x 32 tiles as a lone one -- DL N = 1500, B = 512: resident 45.4 us against 39.3 on three rounds of
     // 32 x 32 tiles; N = 1000, B = 768: 31.2 against 28.8; and N = 1500, B = 384, half the chip: resident 45.2 against
     // 47.0 on 32 x 128 tiles per step, but 37.2 on 32 x 32)
-    if (tun.ptile < 0 && slices * ptile_round_us(mode, a.N) > 1.05 * best_tile_us(mode, a.B, a.N, tun)) return p;
+    if (tun.ptile < 0 && slices * ptile_round_us(mode, a.N, tun.adam) > 1.05 * best_tile_us(mode, a.B, a.N, tun)) return p;
     p.slices = slices;
     p.rbs = (nrb + slices - 1) / slices;
     return p;
@@ -617,12 +622,12 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Replay
 // noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
-    if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return sp.est_us;
-    if (want_cluster(B, N, tun, mode, false)) return cluster_us(mode, B, N, chip_of(tun));
+    if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return (tun.adam ? 1.05 : 1.0) * sp.est_us;
+    if (want_cluster(B, N, tun, mode, tun.adam)) return cluster_us(mode, B, N, chip_of(tun), tun.adam);
     StepArgs a;
     base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, mode);
-    if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices) return pp.slices * ptile_round_us(mode, N);
-    return tile_us(mode, a.ks, B, N, chip_of(tun).cus);  // per-step kernel, the shape base_args chose
+    if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices) return pp.slices * ptile_round_us(mode, N, tun.adam);
+    return tile_us(mode, a.ks, B, N, chip_of(tun).cus, tun.adam);  // per-step kernel, the shape base_args chose
 }
 // rows of the first part (a multiple of 64: the parts' pitched arrays and workspaces tile the batch's), 0: no cut
 int split_rows(int mode, int B, int N, const Tuning& tun) {
@@ -910,8 +915,9 @@ int ccvm_column_sums(const float* Q, int N, int ld, float* qsum, void* ws, size_
 int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0 || solver < 0 || solver > 2 || B <= 0 || N <= 0)
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
-    const Tuning tun = read_tuning();
+    Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
+    tun.adam = ad;
     if (const int cut = per_variable_s ? 0 : split_rows(solver, B, N, tun)) {
         char first[512], rest[512];
         int rc;
@@ -1204,6 +1210,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
                 const ccvm_noise* nz, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_mf_run";
     Tuning tun = read_tuning();
+    tun.adam = adam && adam->enabled;
     if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = tun.ptile = 0;
     if (!Q || !V || !mu || !sigma || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
@@ -1543,6 +1550,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "ccvm_langevin_run";
     Tuning tun = read_tuning();
+    tun.adam = adam && adam->enabled;
     if (nz && (nz->flags & CCVM_RUN_NO_EXCHANGE)) tun.cluster = tun.slab = tun.ptile = 0;
     if (!Q || !V || !c || !p) return fail(CCVM_E_INVALID, "%s: NULL argument", fn);
     int rc;
