@@ -619,7 +619,8 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // 35 row blocks, three rounds of 32 x 64 tiles per step, 50.9 us -- runs as two calls on the same stream: the rows that
 // fill whole resident grids (1024: one launch per chunk, 30.9 us per step) and the rest under its own plan (76 rows:
 // the column-slab kernel).  Decided on the per-step estimates of the plans involved (us; fits of
-// profiles/r04_regime_map.md and r03_tile_shape_sweep.txt, r04_cut_batches.txt), the cut wins with 7 % to spare.  Replay
+// the round-5 regret audit: tile_us / cluster_us / ptile_round_us above), the cut must be estimated 3 % ahead (round 4: 7 %; the
+// audit's cuts came out as estimated, and MF N = 2000, B = 768 lost 7 % to a cut not taken).  Replay
 // noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
     if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return (tun.adam ? 1.05 : 1.0) * sp.est_us;

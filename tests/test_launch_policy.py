@@ -261,6 +261,16 @@ def test_default_policy_against_the_regret_audit(hip_lib, clean_env):
             regrets.append((kind, n, b, fam, round(mine[0]["us"], 2), round(best, 2)))
     assert not regrets, regrets
     assert len(unmeasured) <= 6, unmeasured  # (a plan the audit did not time: re-run tools/policy_regret.py)
+    # the Adam variants of MF / Langevin (84 cells; their estimates carry a factor per family: ccvm_abi.hip, tile_us)
+    adam_regrets = []
+    with open(os.path.join(root, "profiles", "r05_policy_regret_adam.jsonl")) as fh:
+        adam_cells = {(r["kind"], r["n"], r["b"]): r for r in map(json.loads, fh)}
+    for (kind, n, b), r in sorted(adam_cells.items()):
+        plans = {p["family"]: p["us"] for p in r["plans"] if p.get("us")}
+        fam = family(_describe(hip_lib, solver_id[kind.split("+")[0]], b, n, adam=1))
+        if fam in plans and plans[fam] > 1.075 * min(plans.values()):
+            adam_regrets.append((kind, n, b, fam, round(plans[fam], 2), round(min(plans.values()), 2)))
+    assert len(adam_cells) >= 84 and not adam_regrets, adam_regrets
     upside_down = []
     for (kind, n, b), us in picked.items():
         for (k2, n2, b2), us2 in picked.items():
