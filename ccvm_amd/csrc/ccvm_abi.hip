@@ -269,6 +269,17 @@ void set_grid(StepArgs& a, const Tuning& tun) {
             if (best < 0 || cost < best) { best = cost; a.xr = xr; a.xc = xc; }
         }
     }
+    // No rectangle (43 % of the audited cells on this kernel: 47 or 63 column blocks, ragged batches) and a Q that an XCD's
+    // L2 cannot hold next to the state (4 N^2 bytes > 7 MB: N >= 1400): super-columns of 256 output columns -- 2 / 4 / 8
+    // column blocks -- for the blocked order of step_kernel, so the workgroups an XCD runs at a time share a few Q panels
+    // instead of pulling a whole row of them (same-box A/B, us per step, row-major -> blocked: DL N = 2000, B = 384
+    // 62.9 -> 59.3; MF N = 1500, B = 128 13.3 -> 12.1; N = 1500, B = 384 37.3 -> 37.3).  Below that size row-major runs
+    // are better -- Q stays in L2 anyway and one A row block serves the whole run (DL N = 500, B = 2000 19.7 -> 22.2 blocked;
+    // N = 300, B = 2000 13.2 -> 14.7): profiles/r05_ab_blocked_order.txt.  CCVM_AMD_XCD_XC forces the width at any size.
+    if (a.xr == 0 && tun.xcd && total > 8 && (tun.xcd_xc > 0 || a.N >= 1400)) {
+        const int w = tun.xcd_xc > 0 ? tun.xcd_xc : 2 * ks;
+        if (w < a.ncb) a.xc = w;
+    }
 }
 
 // Everything of a launch that does not change from step to step: operands, tile shape and grid.

@@ -64,7 +64,8 @@ struct StepArgs {
     int B, N, ld;
     int wld;  // REPLAY: pitch of the noise blocks (ccvm_noise::w_ld; >= B)
     int nrb, ncb;       // row blocks, column blocks
-    int xr, xc;         // tiles of one XCD form an xr x xc rectangle (0: linear fallback)
+    int xr, xc;         // tiles of one XCD form an xr x xc rectangle; xr = 0: no rectangle, runs of a blocked order with
+                        // super-columns of xc column blocks (xc = 0: row-major)
     int ks;             // host only: the tile shape this launch plan uses (template parameter KS)
     float in_scale, in_shift;  // GEMM input = x * in_scale + in_shift
     union {
@@ -202,9 +203,21 @@ __global__ __launch_bounds__(WG_THREADS) void step_kernel(const StepArgs a) {
         rb = (x / regions_c) * a.xr + i / a.xc;
         cb = (x % regions_c) * a.xc + i % a.xc;
     } else {
+        // No rectangle divides the grid: every XCD takes a contiguous run of tiles in a BLOCKED order (round 5) -- super-
+        // columns of a.xc column blocks, walked row block by row block -- so the workgroups an XCD runs at a time share
+        // a.xc Q panels and a few A row blocks in its L2 instead of one A row block and a whole row of Q panels (row-major
+        // order, a.xc = 0: at N = 2000 every XCD pulled all of Q once per row of tiles).
         const int tile = xcd_remap(blockIdx.x, a.nrb * a.ncb);
-        rb = tile / a.ncb;
-        cb = tile - rb * a.ncb;
+        if (a.xc > 0) {
+            const int per = a.nrb * a.xc;           // tiles of a full super-column
+            const int sc = tile / per, rem = tile - sc * per;
+            const int w = min(a.xc, a.ncb - sc * a.xc);  // (the last one may be narrower)
+            rb = rem / w;
+            cb = sc * a.xc + rem - rb * w;
+        } else {
+            rb = tile / a.ncb;
+            cb = tile - rb * a.ncb;
+        }
     }
     const int row0 = rb * BM, col0 = cb * BNT;
     const int ld = a.ld;
