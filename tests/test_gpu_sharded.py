@@ -114,3 +114,26 @@ def test_bench_collectives_set_up_rccl_next_to_the_gloo_control_group():
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ok" in run.stdout, run.stderr[-3000:]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks sharing the box's one GPU
+    (CCVM_BENCH_SHARE_GPU=1): the ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment the agent
+    sets, rank 0 prints the one JSON line."""
+    import json
+
+    env = dict(os.environ, CCVM_BENCH_SHARE_GPU="1")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--spinup-ms", "20"], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 20 and line["scaling"] == "weak"
+    assert line["collective"].startswith("gloo (rehearsal") and line["check"]["timed_attempts"] == 1
+    assert line["config"]["global_batch"] == 2000 and len(line["ms_per_step_per_rank"]) == 2
