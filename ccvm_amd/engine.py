@@ -483,6 +483,7 @@ class Trajectories:
         self.no_exchange = time.monotonic() < _exchange_blocked_until.get(self.device.index, 0.0)
         self.fallbacks = 0         # time-outs recovered so far
         self._waits = None         # does a run call launch a kernel whose workgroups wait for each other? (asked once)
+        self._fixed_args = None    # the run entry point and its constant arguments (made by the first run call)
 
     def _set_saturation(self, cp, S):
         """Scalar S; a 1-D tensor of length N: per-variable saturation (``s_cols`` of the C structs); a 2-D
@@ -559,18 +560,23 @@ class Trajectories:
         self._ws_padded = True
 
     def _launch(self, step0, k, nz):
-        lib, st, common = self.lib, self.state, (self.b, self.n, self.ld, step0, k, self.t)
-        tail = (ctypes.byref(nz), _ptr(self.ws), self.ws.numel(), _stream_ptr())
-        if self.kind == "dl":
-            rc = lib.ccvm_dl_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]), *common,
-                                 ctypes.byref(self.cparams), *tail)
-        elif self.kind == "mf":
-            rc = lib.ccvm_mf_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["mu"]), _ptr(st["sigma"]),
-                                 _ptr(st["mu_tilde"]), *common, ctypes.byref(self.cparams),
-                                 ctypes.byref(self.adam), *tail)
-        else:
-            rc = lib.ccvm_langevin_run(_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), *common,
-                                       ctypes.byref(self.cparams), ctypes.byref(self.adam), *tail)
+        # the arguments that never change over a run -- device pointers, shapes, parameter structs -- are made once
+        # (ctypes builds a c_void_p per pointer per call otherwise: a few us of host time inside every caller's timed region)
+        fixed = self._fixed_args
+        if fixed is None:
+            lib, st = self.lib, self.state
+            if self.kind == "dl":
+                fn, head = lib.ccvm_dl_run, (_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]), _ptr(st["s"]))
+                mid = (ctypes.byref(self.cparams),)
+            elif self.kind == "mf":
+                fn, head = lib.ccvm_mf_run, (_ptr(self.p.q), _ptr(self.p.v), _ptr(st["mu"]), _ptr(st["sigma"]), _ptr(st["mu_tilde"]))
+                mid = (ctypes.byref(self.cparams), ctypes.byref(self.adam))
+            else:
+                fn, head = lib.ccvm_langevin_run, (_ptr(self.p.q), _ptr(self.p.v), _ptr(st["c"]))
+                mid = (ctypes.byref(self.cparams), ctypes.byref(self.adam))
+            fixed = self._fixed_args = (fn, head + (self.b, self.n, self.ld), (self.t,) + mid, (_ptr(self.ws), self.ws.numel()))
+        fn, head, mid, ws = fixed
+        rc = fn(*head, step0, k, *mid, ctypes.byref(nz), *ws, _stream_ptr())
         _lib.check(rc, f"ccvm_{self.kind}_run")
 
     # ------------------------------------------------------------------ #
