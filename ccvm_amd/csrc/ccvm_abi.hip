@@ -202,7 +202,7 @@ ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : d
 // default plan and under every forced family / tile shape; profiles/r05_policy_regret.md): a launch of a solver step
 // runs ROUNDS of workgroups, ceil(tiles / CUs); relative error of the fits 2-3 % rms for the 32 x 128 and 32 x 64 tiles,
 // 3-7 % (worst cells 15-20 %: the one-stream solvers at N = 2000) for the 32 x 32 tiles, over 300 <= N <= 2000,
-// 1 <= B <= 4000 (tools/policy_regret.py prints them).  The 32 x 32 tiles' later rounds overlap the launch boundary: 9.0 us
+// 1 <= B <= 4000 (tools/fit_tile_model.py refits and checks them: profiles/r05_tile_model_fit.md).  The 32 x 32 tiles' later rounds overlap the launch boundary: 9.0 us
 // per round at DL N = 1000 where a lone round takes 11.7 -- round 3's "0.37 of a 32 x 128 workgroup" priced every round
 // as the first and kept these tiles off every multi-round grid.
 struct TileFit { double l0, l1, m0, m1, a, b, e, q; };
