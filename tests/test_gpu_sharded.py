@@ -137,3 +137,23 @@ def test_bench_under_torch_distributed_run():
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 20 and line["scaling"] == "weak"
     assert line["collective"].startswith("gloo (rehearsal") and line["check"]["timed_attempts"] == 1
     assert line["config"]["global_batch"] == 2000 and len(line["ms_per_step_per_rank"]) == 2
+
+
+def test_bench_starts_over_when_its_persistent_kernel_timed_out():
+    """ADVICE r4 (medium), end to end: with fault injection (CCVM_AMD_FAULT=cluster_drop: the cluster launch omits
+    workgroups, their peers give up a bounded wait and set the status word) the bench's first attempt times garbage;
+    it must notice -- the status word is read right after the clock stops --, go back to the snapshot taken before the
+    warm-up, and time the same steps again on the per-step kernel: the line then describes THAT run."""
+    import json
+
+    env = dict(os.environ, CCVM_AMD_FAULT="cluster_drop", CCVM_AMD_EXCHANGE_COOLDOWN="0")
+    env.pop("WORLD_SIZE", None)
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--workload", "langevin_n500_b1000",
+                          "--steps", "20", "--warmup", "5", "--spinup-ms", "0", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["check"]["timed_attempts"] == 2 and line["check"]["time_outs_recovered"] == 1
+    assert line["check"]["objective_values_finite"] is True
+    assert line["roofline"]["kernel"].startswith("step_kernel<2") and line["roofline"]["launches"] == 20
+    assert 5e-3 < line["ms_per_step"] < 0.5  # the per-step kernel's time (8 us per step), not the ~1.2 s of a bounded wait
