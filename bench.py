@@ -118,7 +118,7 @@ def launch_ranks(n, argv, script=None, timeout=None):
     caller without any."""
     import socket
 
-    share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
+    share = os.environ.get("CCVM_BENCH_SHARE_GPU") in ("1", "try-rccl")
     visible = visible_gpu_count()
     if visible is not None and visible < n and not share:
         raise SystemExit(f"bench.py --gpus {n}: only {visible} GPU(s) visible "
@@ -505,8 +505,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
 
-    share = os.environ.get("CCVM_BENCH_SHARE_GPU") == "1"
-    if share:
+    # CCVM_BENCH_SHARE_GPU (rehearsals on a 1-GPU box): "1" = every rank on cuda:0, collectives over gloo; "try-rccl" = every
+    # rank on cuda:0 and RCCL attempted all the same -- it refuses two ranks on one device, which exercises the REAL
+    # fall-back (tests/test_gpu_sharded.py)
+    share_mode = os.environ.get("CCVM_BENCH_SHARE_GPU", "")
+    share = share_mode == "1"
+    if share_mode in ("1", "try-rccl"):
         local = 0
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)

@@ -157,3 +157,20 @@ def test_bench_starts_over_when_its_persistent_kernel_timed_out():
     assert line["check"]["objective_values_finite"] is True
     assert line["roofline"]["kernel"].startswith("step_kernel<2") and line["roofline"]["launches"] == 20
     assert 5e-3 < line["ms_per_step"] < 0.5  # the per-step kernel's time (8 us per step), not the ~1.2 s of a bounded wait
+
+
+def test_bench_falls_back_to_gloo_when_rccl_refuses():
+    """The real thing: two ranks on the box's ONE GPU with RCCL attempted (CCVM_BENCH_SHARE_GPU=try-rccl) -- RCCL refuses
+    two ranks on one device, on every rank -- so the ranks must agree on the fall-back over their gloo control group,
+    gather host copies in the same processes, and say so in the line; the measured steps are unaffected."""
+    import json
+
+    env = dict(os.environ, CCVM_BENCH_SHARE_GPU="try-rccl", CCVM_BENCH_RCCL_TIMEOUT="60")
+    env.pop("WORLD_SIZE", None)
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "20",
+                          "--warmup", "5", "--spinup-ms", "20"], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["collective"].startswith("gloo-fallback: rank "), line["collective"]
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["check"]["objective_values_finite"] is True
+    assert line["value"] > 0 and len(line["ms_per_step_per_rank"]) == 2
