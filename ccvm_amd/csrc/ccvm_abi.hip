@@ -123,6 +123,7 @@ struct Tuning {
     int persist_ru = 0;  // 0: choose by batch size
     int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
+    int cluster_half = 1;  // 0 (CCVM_AMD_CLUSTER_HALF=0, tuning): the full-chunk cluster kernel also where N mod 128 is in 1 .. 64
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
     int slab_delay = -1;             // >= 0: the fetch delay of clusters that span XCDs (x 64 cycles), else slab_fabric_delay
@@ -157,6 +158,7 @@ Tuning read_tuning() {
         if (e[0] == '1' || e[0] == '2' || e[0] == '4') t.ks = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD")) t.xcd = e[0] != '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
+    if (const char* e = std::getenv("CCVM_AMD_CLUSTER_HALF")) t.cluster_half = e[0] != '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
         if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_KH"))
@@ -408,14 +410,16 @@ bool cluster_spread(int B, int N, const ChipGeometry& chip) {
     return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip) &&
            cluster_count(B, N) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
 }
-// what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 384 / 512 / 640 / 768
-// (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it)
-double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false) {
-    static const double round_us[4][3] = {{7.9, 4.27, 3.77}, {10.1, 5.38, 4.87}, {18.1, 9.6, 8.9}, {21.8, 11.4, 10.7}};
+// what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 320 / 384 / ... / 768 in
+// steps of 64 (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it; the odd
+// multiples of 64 are the half-chunk variant, profiles/r05_ab_cluster_half.txt)
+double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false, bool half = true) {
+    static const double round_us[8][3] = {{7.14, 3.79, 3.35}, {7.9, 4.27, 3.77}, {9.57, 4.91, 4.36}, {10.1, 5.38, 4.87},
+                                          {16.8, 8.83, 8.17}, {18.1, 9.6, 8.9},  {20.3, 10.6, 9.96}, {21.8, 11.4, 10.7}};
     const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
     const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
-    const int k = round_up(N, 128) / 128 - 3;
-    return (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 3 ? 3 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
+    const int k = (cluster_half(N, !half) ? G : round_up(N, 128) / 64) - 5;
+    return (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 7 ? 7 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
 }
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
@@ -464,7 +468,7 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // 32 x 32 tiles do -- DL N = 640, B = 768: 18.3 us against 14.6; N = 300, B = 768: 7.9 against 6.1; N = 768, B = 1500
     // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 5 %
     // behind the best per-step shape
-    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip, tun.adam)) return false;
+    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip, tun.adam, tun.cluster_half != 0)) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
@@ -517,12 +521,13 @@ int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V,
                  int planes = 1) {
     std::memset(&ca, 0, sizeof(ca));
     ca.drop = tun.cluster_drop;
+    ca.half_off = !tun.cluster_half;
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
     const size_t xb = cluster_exchange_bytes(B, N, planes);
     ca.xb0 = static_cast<float*>(area);
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
     ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
-    xid = exchange_layout_id({1, B, N, planes});
+    xid = exchange_layout_id({1, B, N, planes, cluster_half(N, !tun.cluster_half) ? 1 : 0});
     if (exchange_prepare(area, xb, 0, 0, ca.status, xid, step0, st)) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld; ca.wld = (int)noise_pitch(nz, B);
@@ -635,7 +640,7 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
     if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return (tun.adam ? 1.05 : 1.0) * sp.est_us;
-    if (want_cluster(B, N, tun, mode, tun.adam)) return cluster_us(mode, B, N, chip_of(tun), tun.adam);
+    if (want_cluster(B, N, tun, mode, tun.adam)) return cluster_us(mode, B, N, chip_of(tun), tun.adam, tun.cluster_half != 0);
     StepArgs a;
     base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, mode);
     if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices) return pp.slices * ptile_round_us(mode, N, tun.adam);
@@ -952,8 +957,8 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
         const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
         const bool spread = cluster_spread(B, N, chip_of(tun));
-        std::snprintf(buf, buf_len, "ccvm::cluster_kernel<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
-                      solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel%s<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
+                      cluster_half(N, !tun.cluster_half) ? "_half" : "", solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
                       spread ? ", spread over the XCDs" : "", TABLE_STEPS);
         return CCVM_OK;
     }

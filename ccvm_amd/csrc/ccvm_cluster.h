@@ -105,6 +105,7 @@ struct ClusterArgs {
     int nclusters, G;
     int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
+    int half_off;        // host only (tuning): 1 = the full kernel also where the half-chunk variant applies
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;             // MF: clamp of the measured amplitude
@@ -158,8 +159,15 @@ typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 // panel's k >= 512 are B fragments in the MFMA waves' registers (32 / 64 VGPRs), loaded once per launch.
 // REPLAY is a template parameter, not a run-time branch: with the replay loads in the same code as the fused
 // noise hipcc guards the registers they share with s_waitcnt vmcnt(0) in BOTH paths.
-template <int MODE, bool ADAM, int KCH, bool REPLAY>
-__global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
+//
+// HALF (round 5; N mod 128 in 1 .. 64, i.e. an odd number of members): the last chunk of a plane holds 64 real k only.
+// Its single member publishes column 16 w + j of its 64 at position 32 w + j of the chunk and the panel's rows follow
+// (physical k = 32 g + t of that chunk holds logical k = 16 g + t for t < 16, nothing for t >= 16), so that the real k
+// are every lane group's FIRST sixteen operands: the chunk's second half-unit of MFMAs is all padding and is left out
+// (K in steps of 64 instead of 128: 1/6 of a step's MFMAs at K = 320, 1/12 at K = 704).  Fetch waves, ring and
+// barriers are the full kernel's; the results differ from it in nothing (the omitted products are zeros).
+template <int MODE, bool ADAM, int KCH, bool REPLAY, bool HALF>
+__device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant");
     static_assert(KCH >= 3 && KCH <= 6, "K = 384 ... 768");
@@ -178,6 +186,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     auto rowpos = [](int r) { return (r < 4) ? 2 * r : (r < 12) ? 2 * (r - 4) + 1 : 2 * (r - 8); };
     // position of Q[k][.] inside a panel column: k = 128 c + 32 g + t  ->  128 g + 32 c + t
     auto kpos = [](int k) { return 128 * ((k >> 5) & 3) + 32 * (k >> 7) + (k & 31); };
+    // the Q row held at physical k (HALF: the last chunk's operand t of lane group g is row 16 g + t of its 64; t >= 16: none)
+    auto ksrc = [](int k) {
+        if (!HALF || k < CL_KC * (KCH - 1)) return k;
+        return ((k & 31) < 16) ? CL_KC * (KCH - 1) + 16 * ((k >> 5) & 3) + (k & 31) : -1;
+    };
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
     __shared__ __attribute__((aligned(16))) float lds[QPANEL + 3 * ABUF + 4];
     float* const qp = lds;                    // [64 columns][512 + 4]
@@ -210,7 +223,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     {
         const int c = tid & 63, kk = tid >> 6;
 #pragma unroll 8
-        for (int k = kk; k < KL * CL_KC; k += CL_THREADS / 64) qp[c * QS + kpos(k)] = a.Q[(size_t)k * ld + col0 + c];
+        for (int k = kk; k < KL * CL_KC; k += CL_THREADS / 64) {
+            const int ks = ksrc(k);
+            qp[c * QS + kpos(k)] = (ks >= 0) ? a.Q[(size_t)ks * ld + col0 + c] : 0.0f;
+        }
     }
     // buffer descriptors of the two exchange buffers (wave-uniform: kernel arguments only)
     const size_t xbytes = (size_t)(a.nclusters * CROWS * NPL) * ld * CL_XE;
@@ -238,7 +254,8 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         const int ht = tid - 256, hr = ht >> 5, hq = ht & 31;
         const unsigned ld_off = (unsigned)(((size_t)(xrow0 + hr) * ld + 4 * hq) * CL_XE);
         // the columns >= 64 G of a plane's last chunk are never published: their tags are ignored, their values stay 0
-        const unsigned pad_tag = (CL_KC * (KCH - 1) + 4 * hq >= CL_COLS * G) ? 0xFFFFFFFFu : 0u;
+        // (HALF: those are the positions t >= 16 of every lane group's 32)
+        const unsigned pad_tag = (HALF ? ((4 * hq) & 16) != 0 : CL_KC * (KCH - 1) + 4 * hq >= CL_COLS * G) ? 0xFFFFFFFFu : 0u;
         // The fetch waves' VALU instructions are the expensive ones: next to a wave that issues MFMAs back to back a
         // sibling's VALU instruction gets a slot about once per MFMA (~32 cycles; stamps: 60 of them took 1900
         // cycles), so staging and checking must not need any beyond the tag minima: staging addresses are
@@ -475,7 +492,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     // Publish set s's new GEMM input x[i] (rows 4 g + i, column col) with tag `tag` into exchange buffer `par`: this
     // lane's elements are its own 8-byte packets; a store instruction writes 4 rows x 16 columns x 8 bytes = four
     // whole 128-byte lines.  Never waited for.
-    const unsigned pub_off = (unsigned)(((size_t)(xrow0 + 4 * g) * ld + col) * CL_XE);
+    // (HALF: the last member's columns go to the first sixteen positions of each lane group's 32, see above)
+    const int pcol = (HALF && member == G - 1) ? col0 + 32 * wave + c16 : col;
+    const unsigned pub_off = (unsigned)(((size_t)(xrow0 + 4 * g) * ld + pcol) * CL_XE);
     auto publish = [&](int s, int par, const float (&x)[4], unsigned tag, int plane = 0) {
         if constexpr (NO_XCHG || (CCVM_CLUSTER_ABL & 16)) return;
 #pragma unroll
@@ -509,7 +528,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     // operands are read one UNIT (UM MFMAs' worth: a chunk or half a chunk) ahead, double-buffered
     // (MF + Adam at K = 768 with fused noise, the tightest variant: quarter-chunk units -- 2 x 16 operand registers less,
     // 256 cycles of MFMAs still cover the LDS latency -- instead of 10 spilled registers)
-    constexpr int UM = (ADAM && MODE == MODE_MF && KCH == 6 && !REPLAY) ? 8 : CCVM_CL_UNIT, UPC = 32 / UM, NU = NC * UPC;
+    constexpr int UM = (ADAM && MODE == MODE_MF && KCH == 6 && !REPLAY) ? 8 : CCVM_CL_UNIT, UPC = 32 / UM;
+    // units of a plane (HALF: the last chunk's second half is never computed) and of a phase
+    constexpr int UPP = KCH * UPC - (HALF ? UPC / 2 : 0), NU = NPL * UPP;
     static_assert(UM == 32 || UM == 16 || UM == 8, "operand unit: a chunk, half or a quarter of a chunk");
     float bq[2][UM];  // B operands of a unit; the first unit's now
     auto read_ops = [&](float (&dst)[UM], const float* src) {  // the UM operands of one unit
@@ -526,7 +547,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         for (int j = 0; j < KCH - KL; ++j)
 #pragma unroll
             for (int m = 0; m < 32; ++m)
-                breg[j][m] = a.Q[(size_t)(CL_KC * (KL + j) + 32 * g + m) * ld + col];
+                breg[j][m] = (HALF && KL + j == KCH - 1)
+                                 ? ((m < 16) ? a.Q[(size_t)(CL_KC * (KL + j) + 16 * g + m) * ld + col] : 0.0f)
+                                 : a.Q[(size_t)(CL_KC * (KL + j) + 32 * g + m) * ld + col];
     }
     // The first unit's B operands are read during the previous phase's last unit (the panel never changes), into the
     // half of the double buffer that unit does not compute from -- possible when the units of an iteration are even
@@ -581,11 +604,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             __builtin_amdgcn_sched_barrier(0);
             unroll_indices([&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
-                constexpr int c = u / UPC, h = u % UPC;      // chunk c % KCH of plane c / KCH, its unit h
-                constexpr int pl = c / KCH;
-                constexpr int pc = c % KCH;                  // panel chunk: from LDS (pc < KL) or registers
-                constexpr int nc = (u + 1) / UPC, nh = (u + 1) % UPC;  // the next unit's chunk and position
-                constexpr int npc = nc % KCH;
+                constexpr int pl = u / UPP;                  // plane
+                constexpr int pc = (u % UPP) / UPC;          // panel chunk: from LDS (pc < KL) or registers
+                constexpr int h = (u % UPP) % UPC;           // unit inside the chunk
+                constexpr int c = pl * KCH + pc;             // chunk of the phase
+                constexpr int npc = ((u + 1) % UPP) / UPC, nh = ((u + 1) % UPP) % UPC;  // the next unit's chunk and position
+                constexpr int nc = ((u + 1) / UPP) * KCH + npc;
                 // operands to read during this unit: the next unit's A (if it belongs to this phase) and B (if it lives
                 // in LDS and belongs to this phase or the cross-phase read is on)
                 constexpr bool RD_A = u + 1 < NU;
@@ -627,7 +651,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (h == UPC - 1 && c + 1 < NC) {
+                if constexpr (nc != c && u + 1 < NU) {
                     mark(seg[1]);
                     __syncthreads();  // B_(c+1): chunk c's buffer may be refilled; chunk c + 2 is staged
                     if constexpr (CCVM_CLUSTER_ABL & 64) {
@@ -749,9 +773,22 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
 }
 
+template <int MODE, bool ADAM, int KCH, bool REPLAY>
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
+    cluster_body<MODE, ADAM, KCH, REPLAY, false>(a);
+}
+
+// K = 128 KCH - 64 (an odd number of members)
+template <int MODE, bool ADAM, int KCH, bool REPLAY>
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel_half(const ClusterArgs a) {
+    cluster_body<MODE, ADAM, KCH, REPLAY, true>(a);
+}
+
 // K > 512 is served for every solver variant: with half-chunk operand units the MFMA waves' registers suffice (the
 // tightest, MF + Adam at K = 768: 255 of 256)
 constexpr bool cluster_wide_ok(int, bool) { return true; }
+// the half-chunk variant serves N mod 128 in 1 .. 64 (an odd number of 64-column members); `off`: tuning, the full kernel
+inline bool cluster_half(int N, int off) { return !off && (((N + CL_COLS - 1) / CL_COLS) & 1) != 0; }
 
 void cluster_launch_dl(const ClusterArgs& a, hipStream_t st);
 void cluster_launch_mf(const ClusterArgs& a, bool adam, hipStream_t st);
@@ -760,6 +797,13 @@ void cluster_launch_lv(const ClusterArgs& a, bool adam, hipStream_t st);
 template <int MODE, bool ADAM, bool REPLAY>
 void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
     const int kch = a.ld / CL_KC;
+    if (cluster_half(a.N, a.half_off)) {
+        if (kch == 3) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        else if (kch == 4) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        else if (kch == 5) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 5, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        else if (kch == 6) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 6, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        return;
+    }
     if (kch == 3) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
     else if (kch == 4) hipLaunchKernelGGL((cluster_kernel<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
     // K = 640 / 768: three row sets + 32 / 64 registers of Q per MFMA wave

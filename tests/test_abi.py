@@ -104,7 +104,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 500, 0): "ccvm::cluster_kernel<0, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
-        (0, 1000, 300, 0): "ccvm::cluster_kernel<0, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
+        (0, 1000, 300, 0): "ccvm::cluster_kernel_half<0, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
         (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 1024 x 512 threads (125 clusters of 8 workgroups)",
         (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",
         (1, 1000, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
@@ -115,7 +115,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
         (0, 1000, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 252 x 512 threads (21 clusters of 12 workgroups, spread over the XCDs)",
-        (2, 1000, 700, 1): "ccvm::cluster_kernel<2, true, 6, false> grid 231 x 512 threads (21 clusters of 11 workgroups, spread over the XCDs)",
+        (2, 1000, 700, 1): "ccvm::cluster_kernel_half<2, true, 6, false> grid 231 x 512 threads (21 clusters of 11 workgroups, spread over the XCDs)",
         (0, 1100, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 210 x 512",
         (2, 2000, 640, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 480 x 512 threads (42 clusters of 10 workgroups)",
         (2, 1500, 640, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 235 x 512",

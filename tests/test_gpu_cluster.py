@@ -114,6 +114,36 @@ def test_cluster_kernel_matches_oracle(cluster, kind, n, b, t, adam):
         assert float(arr[:, n:].abs().max() if arr.shape[1] > n else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("kind,n,b,t,adam", [("pl", 300, 96, 20, None), ("dl", 320, 100, 16, None), ("mf", 448, 70, 16, "add_assign"),
+                                              ("mf", 576, 200, 12, None), ("dl", 700, 96, 10, None), ("langevin", 641, 33, 12, "second_moment")])
+def test_half_chunk_variant_against_the_full_kernel(cluster, monkeypatch, kind, n, b, t, adam):
+    """N mod 128 in 1 .. 64 (an odd number of members) runs cluster_kernel_half, which leaves out the all-padding second
+    half of every plane's last chunk; CCVM_AMD_CLUSTER_HALF=0 keeps the full kernel on the same shapes.  Both match the
+    oracle, each other up to summation order, and the launch description names the one that runs."""
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    def describe():
+        buf = ctypes.create_string_buffer(1024)
+        assert _lib.load().ccvm_describe_launch({"dl": 0, "mf": 1}.get(kind, 2), b, n, 1 if adam else 0, 0, buf, 1024) == 0
+        return buf.value.decode()
+
+    hp = _ADAMS[adam]
+    seed, row_offset = 0xAB5_1234, 3
+    assert "cluster_kernel_half<" in describe()
+    half = _run_engine(kind, n, b, t, hp, seed, row_offset)
+    monkeypatch.setenv("CCVM_AMD_CLUSTER_HALF", "0")
+    assert "cluster_kernel<" in describe()
+    full = _run_engine(kind, n, b, t, hp, seed, row_offset)
+    gate = (max(n, 20) / 20.0) ** 0.5
+    for name, want in _run_oracle(kind, n, b, t, hp, seed, row_offset):
+        scale = max(1.0, float(want.abs().max()))
+        for got in (half.compact(name).cpu(), full.compact(name).cpu()):
+            assert float((got - want).abs().max()) <= ATOL_X * gate * scale, f"{kind} N={n} {name}"
+        assert float((half.compact(name).cpu() - full.compact(name).cpu()).abs().max()) <= 2e-4 * gate * scale
+
+
 def test_cluster_kernel_is_what_ran(cluster):
     """The path under test is the cluster kernel: it differs from the tile kernel in summation order only
     (close, not bit-identical), and CCVM_AMD_KERNEL=nocluster gives the tile kernel's bits back."""

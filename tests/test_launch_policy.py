@@ -88,7 +88,7 @@ def test_batches_cut_in_two(hip_lib, clean_env):
     # the cluster kernel's sizes up to N = 512: 8 x floor(32 / G) resident clusters of 32 rows, then the rest
     d = _describe(hip_lib, 2, 1100, 500)
     assert d.startswith("batch cut in two: rows 0-1023 ccvm::cluster_kernel<2, false, 4, false>") and "| rows 1024-1099 ccvm::slab_kernel<2" in d
-    assert "rows 0-1535 ccvm::cluster_kernel<1, true, 3" in _describe(hip_lib, 1, 1600, 300, adam=1)
+    assert "rows 0-1535 ccvm::cluster_kernel_half<1, true, 3" in _describe(hip_lib, 1, 1600, 300, adam=1)
     for solver, b, n in ((2, 1500, 500), (2, 2000, 500), (2, 1000, 500), (0, 1100, 640), (2, 1100, 256)):
         assert "cut in two" not in _describe(hip_lib, solver, b, n), (solver, b, n)
     for solver, b, n in ((0, 2000, 1000), (0, 1800, 1000), (0, 1000, 1000), (0, 1000, 1500), (0, 900, 1000), (2, 3000, 1000)):
