@@ -209,9 +209,10 @@ ChipGeometry chip_of(const Tuning& tun) { return tun.chip.cus > 0 ? tun.chip : d
 // as the first and kept these tiles off every multi-round grid.
 struct TileFit { double l0, l1, m0, m1, a, b, e, q; };
 constexpr TileFit TILE_FIT[3][3] = {  // [DL, MF, Langevin / pumped Langevin][32 x 128, 32 x 64, 32 x 32]
-    {{6.047, 0.02663, 0.876, 0.00070, 0.02726, 5.378, 0.258, 0.037}, {4.440, 0.01364, 1.150, 0.00049, 0.01376, 2.396, 1.963, 0.029}, {3.905, 0.00668, 0.649, 0.00031, 0.00653, 1.791, 2.015, 0.450}},
-    {{5.368, 0.01329, 1.220, 0.00084, 0.01423, 5.919, -0.236, -0.170}, {3.885, 0.00673, 0.915, 0.00043, 0.00762, 2.832, 0.145, -0.248}, {4.030, 0.00340, -0.951, 0.00297, 0.00338, 1.840, 1.671, 0.498}},
-    {{4.305, 0.01342, 0.344, 0.00087, 0.01364, 3.313, 0.882, 0.125}, {3.960, 0.00677, 0.193, 0.00076, 0.00684, 1.731, 1.735, 0.119}, {3.616, 0.00373, -0.514, 0.00119, 0.00257, 1.121, 2.735, 0.865}}};
+    {{5.989, 0.02665, 0.864, 0.00062, 0.02783, 5.196, 0.046, -0.243}, {4.411, 0.01362, 0.862, 0.00064, 0.01387, 2.241, 2.017, -0.050}, {3.822, 0.00674, 0.626, 0.00050, 0.00701, 1.544, 2.199, 0.086}},
+    {{5.299, 0.01336, 1.111, 0.00080, 0.01419, 5.922, -0.338, -0.167}, {3.931, 0.00667, 0.751, 0.00058, 0.00772, 2.558, 0.295, -0.220}, {3.962, 0.00355, -0.466, 0.00183, 0.00413, 1.572, 1.712, -0.135}},
+    {{4.220, 0.01350, 0.356, 0.00080, 0.01390, 3.206, 0.717, 0.002}, {3.919, 0.00678, 0.035, 0.00078, 0.00695, 1.594, 1.753, 0.094}, {3.563, 0.00380, -0.294, 0.00072, 0.00361, 0.807, 2.761, 0.068}},
+};
 int fit_row(int mode) { return mode == MODE_MF ? 1 : mode == MODE_LANGEVIN ? 2 : 0; }
 // The Adam variants (MF / Langevin: moments read and written every step by the per-step kernel, kept in registers by the
 // persistent ones) cost more by family -- medians over the 84 audited cells (profiles/r05_policy_regret_adam.md): per-step
@@ -278,8 +279,17 @@ void set_grid(StepArgs& a, const Tuning& tun) {
     // 62.9 -> 59.3; MF N = 1500, B = 128 13.3 -> 12.1; N = 1500, B = 384 37.3 -> 37.3).  Below that size row-major runs
     // are better -- Q stays in L2 anyway and one A row block serves the whole run (DL N = 500, B = 2000 19.7 -> 22.2 blocked;
     // N = 300, B = 2000 13.2 -> 14.7): profiles/r05_ab_blocked_order.txt.  CCVM_AMD_XCD_XC forces the width at any size.
-    if (a.xr == 0 && tun.xcd && total > 8 && (tun.xcd_xc > 0 || a.N >= 1400)) {
-        const int w = tun.xcd_xc > 0 ? tun.xcd_xc : 2 * ks;
+    // The same for a FULL-WIDTH rectangle (xc == ncb: 47 or 63 column blocks have no other divisor, so each XCD would
+    // sweep the whole Q -- 9 / 16 MB -- through its 4 MB L2; round 5's second audit: 32 x 32 tiles at N = 2000, B = 256 in
+    // rectangles 1 x 63: 25.3 us for 504 tiles where B = 384 in the blocked order takes 27.2 for 756; same-box A/B
+    // profiles/r05_ab_full_width.txt: Langevin N = 2000 -11 ... -21 %, N = 1500 -3 ... -10 %, DL -2 ... -6 %), and for every
+    // grid of 32 x 32 tiles at these sizes, proper rectangle or not (profiles/r05_ab_rect_vs_blocked.txt: 2048 x 2048
+    // -12 %, 1024 x 1536 -6 %, else +-0; the 32 x 128 and 32 x 64 grids are no faster blocked, some 10-14 % slower: they
+    // keep their rectangles).  CCVM_AMD_XCD_XC=-1 keeps the rectangle, -w forces the blocked order (A/B runs).
+    if (a.xr > 0 && (a.xc == a.ncb || ks == 4) && a.N >= 1400 && tun.xcd_xc == 0 && a.ncb > 2 * ks) a.xr = a.xc = 0;
+    if (tun.xcd_xc < -1) a.xr = a.xc = 0;  // tuning: -w = the blocked order with super-columns of w blocks whatever rectangle exists
+    if (a.xr == 0 && tun.xcd && total > 8 && (tun.xcd_xc > 0 || tun.xcd_xc < -1 || a.N >= 1400)) {
+        const int w = tun.xcd_xc > 0 ? tun.xcd_xc : tun.xcd_xc < -1 ? -tun.xcd_xc : 2 * ks;
         if (w < a.ncb) a.xc = w;
     }
 }
@@ -414,13 +424,14 @@ bool cluster_spread(int B, int N, const ChipGeometry& chip) {
 // steps of 64 (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it; the odd
 // multiples of 64 are the half-chunk variant, profiles/r05_ab_cluster_half.txt)
 double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false, bool half = true) {
-    static const double round_us[8][3] = {{7.14, 3.79, 3.35}, {7.9, 4.27, 3.77}, {9.57, 4.91, 4.36}, {10.1, 5.38, 4.87},
-                                          {16.8, 8.83, 8.17}, {18.1, 9.6, 8.9},  {20.3, 10.6, 9.96}, {21.8, 11.4, 10.7}};
+    static const double round_us[8][3] = {{7.16, 3.49, 3.37}, {7.9, 4.05, 3.77}, {9.57, 4.60, 4.40}, {10.1, 5.30, 4.85},
+                                          {16.8, 8.69, 8.32}, {18.1, 9.5, 8.9},  {20.2, 10.6, 10.1}, {21.8, 11.2, 10.7}};
     const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
     const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
     const int k = (cluster_half(N, !half) ? G : round_up(N, 128) / 64) - 5;
     return (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 7 ? 7 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
 }
+constexpr double CLUSTER_MARGIN = 0.98;  // (the audit: 0.95 kept six cells on the cluster path that one round of 32 x 64 tiles beats by 5-7 %; 1.0 loses Langevin + Adam N = 640, B = 2000 by 9 %)
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
 bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (!tun.cluster || N < CL_MIN_N || N > CL_MAX_N) return false;
@@ -466,9 +477,9 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     }
     // Round 5 (regret audit): a cluster's time per step does not shrink with the batch, the per-step kernel's rounds of
     // 32 x 32 tiles do -- DL N = 640, B = 768: 18.3 us against 14.6; N = 300, B = 768: 7.9 against 6.1; N = 768, B = 1500
-    // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 5 %
+    // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 2 %
     // behind the best per-step shape
-    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < 0.95 * cluster_us(mode, B, N, chip, tun.adam, tun.cluster_half != 0)) return false;
+    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < CLUSTER_MARGIN * cluster_us(mode, B, N, chip, tun.adam, tun.cluster_half != 0)) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
@@ -551,11 +562,11 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     const SlabPlan p = slab_plan(B, N, planes, chip_of(tun), tun.slab_cgrp, tun.slab_rg);
     if (!p.ok) return none;
     if ((size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE >= ((size_t)1 << 31)) return none;
-    // up to N = 512 the alternative is the cluster kernel, whose time per step does not grow with the batch: beyond
-    // ~20 rows per cluster (DL ~28) it wins (N = 500, us per step, slab vs cluster: Langevin B = 256 3.4 vs 4.9, B = 512
-    // 6.2 vs 4.9; DL B = 256 5.7 vs 9.9, B = 512 10.8 vs 10.0; N = 300 B = 512: 4.9 vs 3.8)
-    // (DL at K = 384, where the cluster kernel takes 7.9 us: N = 300, B = 512 in 24-row clusters 8.4 -> 20 rows at most)
-    if (tun.slab < 0 && N <= CL_LDS_K && p.rg > (planes == 2 ? (round_up(N, 128) <= 384 ? 5 : 7) : 5)) return none;
+    // up to N = 512 the alternatives are the cluster kernel, whose time per step does not grow with the batch, and one
+    // round of 32 x 32 tiles: beyond 20 rows per cluster they win (N = 500, us per step, slab vs cluster: Langevin
+    // B = 256 3.4 vs 4.9, B = 512 6.2 vs 4.9; N = 300 B = 512: 4.9 vs 3.8; DL in 24-row clusters, B = 384, vs 32 x 32 tiles:
+    // N = 448 8.4 vs 7.4, N = 500 8.4 vs 8.0 -- the audit of round 5; DL N = 300, B = 512 8.4 vs 6.5)
+    if (tun.slab < 0 && N <= CL_LDS_K && p.rg > 5) return none;
     // above that the alternative is the per-step tile kernel, whose time at these batches depends on N and the tile
     // shape only (measured, us per step: 32 x 64 tiles Langevin 8.5 / 10.8 / 14.2 / 17.6 at N = 700 / 1000 / 1500 / 2000,
     // DL 13.9 / 18.5 / 25 / 32; 32 x 32 tiles Langevin 5.9 / 7.8 / 10.0 / 12.5 at N = 600 / 1000 / 1500 / 2000, DL 7.9 /

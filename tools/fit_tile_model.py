@@ -29,6 +29,8 @@ def load():
             r = json.loads(line)
             if r["n"] < 300 or "+" in r["kind"]:
                 continue
+            if "first_pass" in path and r["n"] >= 1400:
+                continue  # (measured before the blocked tile order of grids no XCD rectangle divides: ccvm_abi.hip, set_grid)
             for p in r["plans"]:
                 if p.get("us") and p["family"] in ("T1", "T2", "T4"):
                     ks = int(p["family"][1])

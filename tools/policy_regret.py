@@ -220,6 +220,7 @@ if __name__ == "__main__":
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--ns", default=",".join(map(str, NS)))
     ap.add_argument("--bs", default=",".join(map(str, BS)))
+    ap.add_argument("--cells", default=None, help="measure exactly these cells, kind:N:B,... (re-measuring what a policy change moved)")
     args = ap.parse_args()
     if args.out and not (args.md or args.regime_md):
         PATH = args.out
@@ -246,5 +247,10 @@ if __name__ == "__main__":
     else:
         if args.adam:
             ADAM = {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False}
-        measure([k for k in args.kinds.split(",") if not (args.adam and k == "dl")], [int(x) for x in args.ns.split(",")],
-                [int(x) for x in args.bs.split(",")])
+        if args.cells:
+            for cell in args.cells.split(","):
+                kind, n, b = cell.split(":")
+                measure([kind], [int(n)], [int(b)])
+        else:
+            measure([k for k in args.kinds.split(",") if not (args.adam and k == "dl")], [int(x) for x in args.ns.split(",")],
+                    [int(x) for x in args.bs.split(",")])
