@@ -46,6 +46,9 @@ WORKLOADS = {
     "mf_n500_b1000": ("mf", 500, 1000),
     "langevin_n500_b1000": ("langevin", 500, 1000),
     "pl_n2000_b512": ("pl", 2000, 512),
+    # the low end of the column-cluster kernel's range (K = 320: its half-chunk variant, ccvm_cluster.h)
+    "langevin_n300_b1000": ("langevin", 300, 1000),
+    "dl_n300_b1000": ("dl", 300, 1000),
     "langevin_n1000_b1000": ("langevin", 1000, 1000),  # the one-stream solvers at the headline's size
     "mf_n1000_b1000": ("mf", 1000, 1000),
     # small batches (the reference runs any batch_size through the same einsum, dl_solver.py:145-153): the

@@ -30,6 +30,8 @@ ROWS = [
     ("langevin_n1000_b1000", "one-stream solver at the headline's size", "8 N + 4 N²/B"),
     ("mf_n1000_b1000", "one-stream solver at the headline's size", "16 N + 4 N²/B"),
     ("dl_n500_b1000", "DL at config 3's size (not a BASELINE configuration)", "16 N + 4 N²/B"),
+    ("langevin_n300_b1000", "the low end of the cluster kernel's range (its half-chunk variant, K = 320)", "8 N + 4 N²/B"),
+    ("dl_n300_b1000", "the same, DL", "16 N + 4 N²/B"),
     ("dl_n1000_b256", "mid-size batch", "16 N + 4 N²/B"),
     ("dl_n1000_b32", "small batch (the reference runs any batch_size)", "16 N (Q never moves)"),
     ("dl_n1000_b1", "a single trajectory", "16 N (Q never moves)"),
@@ -64,7 +66,7 @@ def pmc(workload):
 
 
 def short_kernel(k):
-    m = re.search(r"(\w+_kernel<[^>]*>)", k)
+    m = re.search(r"(\w+_kernel\w*<[^>]*>)", k)
     name = m.group(1) if m else k[:40]
     extra = re.search(r"(\d+) slices of the batch", k)
     return f"`{name}`" + (f", {extra.group(1)} slices" if extra else "")
