@@ -610,7 +610,7 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
 }
 
 // ---- host side: the shapes that exist, and the plan for (B, N) -------------------------------------------
-// K = 64 NQ / CGRP in {512, 768, 1024, 1280, 1536, 2048}; NQ <= 256 registers per lane
+// K = 64 NQ / CGRP = every multiple of 128 from 384 to 2048; NQ <= 256 registers per lane
 struct SlabPlan {
     int ok;        // 0: the slab path does not serve this shape
     int cgrp, nq;  // template parameters
@@ -629,10 +629,8 @@ struct ChipGeometry {
 };
 
 inline int slab_k_for(int N) {
-    const int ks[6] = {512, 768, 1024, 1280, 1536, 2048};
-    for (int i = 0; i < 6; ++i)
-        if (N <= ks[i]) return ks[i];
-    return 0;
+    // every multiple of 128 (round 5; before: 512, 768, 1024, 1280, 1536, 2048 -- N = 300 contracted K = 512)
+    return (N >= 1 && N <= 2048) ? (N <= 384 ? 384 : (N + 127) / 128 * 128) : 0;
 }
 
 // Every feasible (rows per cluster, XCDs per cluster, member width) is priced with a small model of a step fitted to
@@ -715,11 +713,19 @@ template <int MODE, int CGRP, bool CAL>
 void launch_slab_nq(const SlabArgs& a, const SlabPlan& p, int grid, hipStream_t st) {
     const dim3 g(grid), b(SL_THREADS);
     switch (p.K) {
+        case 384: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 6 * CGRP, CAL>), g, b, 0, st, a); break;
         case 512: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 8 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 640: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 10 * CGRP, CAL>), g, b, 0, st, a); break;
         case 768: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 12 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 896: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 14 * CGRP, CAL>), g, b, 0, st, a); break;
         case 1024: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 16 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1152: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 18 * CGRP, CAL>), g, b, 0, st, a); break;
         case 1280: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 20 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1408: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 22 * CGRP, CAL>), g, b, 0, st, a); break;
         case 1536: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 24 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1664: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 26 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1792: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 28 * CGRP, CAL>), g, b, 0, st, a); break;
+        case 1920: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 30 * CGRP, CAL>), g, b, 0, st, a); break;
         case 2048: hipLaunchKernelGGL((slab_kernel<MODE, CGRP, 32 * CGRP, CAL>), g, b, 0, st, a); break;
         default: break;
     }

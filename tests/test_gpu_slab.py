@@ -50,12 +50,13 @@ def _check_against_oracle(kind, n, b, t, adam):
 @pytest.mark.parametrize("kind,n,b,t,adam", [
     # the bench workloads of this path
     ("dl", 1000, 1, 40, None), ("dl", 1000, 8, 40, None), ("dl", 1000, 32, 40, None), ("pl", 2000, 32, 16, None),
-    # every K: 512, 768, 1024, 1280, 1536, 2048; ragged columns; B not a multiple of 4; odd shard starts
+    # every K (the multiples of 128 from 384 to 2048); ragged columns; B not a multiple of 4; odd shard starts
     ("langevin", 257, 3, 30, None), ("mf", 500, 32, 30, None), ("dl", 512, 5, 24, None),
     ("pl", 513, 9, 24, None), ("mf", 700, 31, 20, "second_moment"), ("dl", 768, 16, 20, None),
     ("langevin", 769, 2, 20, "add_assign"), ("mf", 1000, 32, 20, None), ("pl", 1024, 7, 16, "first_moment_only"),
     ("langevin", 1025, 4, 16, None), ("mf", 1200, 12, 12, None), ("dl", 1280, 6, 12, None),
     ("pl", 1300, 8, 12, "second_moment"), ("dl", 1536, 4, 10, None), ("mf", 1537, 5, 10, "add_assign"),
+    ("langevin", 1400, 6, 10, None), ("dl", 1600, 3, 8, None), ("mf", 1900, 8, 8, None),  # K = 1408, 1664, 1920
     ("langevin", 2000, 8, 10, None), ("dl", 2048, 4, 8, None), ("mf", 2048, 3, 8, None),
     # several row groups per cluster (8 ... 32 rows), several clusters per XCD, clusters spread over the XCDs
     ("langevin", 500, 64, 20, None), ("langevin", 500, 256, 12, None), ("dl", 500, 128, 12, None),
