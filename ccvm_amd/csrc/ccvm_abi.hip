@@ -572,7 +572,7 @@ SlabPlan want_slab(int B, int N, const Tuning& tun, int mode) {
     // DL 13.9 / 18.5 / 25 / 32; 32 x 32 tiles Langevin 5.9 / 7.8 / 10.0 / 12.5 at N = 600 / 1000 / 1500 / 2000, DL 7.9 /
     // 11.4 / 14.3 / 17.9): the plan's own estimate must beat it by 10 % (Langevin N = 700, B = 256, 28 rows per
     // cluster over the chip: 9.2 vs 8.6 measured)
-    if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.9 * best_tile_us(mode, B, N, tun)) return none;
+    if (tun.slab < 0 && N > CL_LDS_K && p.est_us > 0.95 * best_tile_us(mode, B, N, tun)) return none;
     return p;
 }
 // the part of SlabArgs every solver shares; `area` as in cluster_base: [exchange buffer 0][exchange buffer 1][status word]
