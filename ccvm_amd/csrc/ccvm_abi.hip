@@ -633,7 +633,12 @@ PtilePlan plan_ptile(const StepArgs& a, const Tuning& tun, bool vs, int mode) {
     // every round of 32 x 32 tiles as a lone one -- DL N = 1500, B = 512: resident 45.4 us against 39.3 on three rounds of
     // 32 x 32 tiles; N = 1000, B = 768: 31.2 against 28.8; and N = 1500, B = 384, half the chip: resident 45.2 against
     // 47.0 on 32 x 128 tiles per step, but 37.2 on 32 x 32)
-    if (tun.ptile < 0 && slices * ptile_round_us(mode, a.N, tun.adam) > 1.05 * best_tile_us(mode, a.B, a.N, tun)) return p;
+    // (MF keeps the 5 %: its 32 x 32 tiles cost a round more than the model says on grids of just under three rounds --
+    // N = 2000, B = 384: 36.7 us measured, 29.6 estimated -- Langevin compares as estimated: N = 900, B = 800 resident
+    // 16.0 against 14.9 on 32 x 32 tiles, N = 1200, B = 512 19.3 against 18.2; DL in between: N = 1200, B = 1500 two
+    // resident slices 76.0 against 80.2)
+    const double margin = mode == MODE_MF ? 1.05 : mode == MODE_DL ? 1.03 : 1.0;
+    if (tun.ptile < 0 && slices * ptile_round_us(mode, a.N, tun.adam) > margin * best_tile_us(mode, a.B, a.N, tun)) return p;
     p.slices = slices;
     p.rbs = (nrb + slices - 1) / slices;
     return p;
