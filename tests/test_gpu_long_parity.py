@@ -35,6 +35,9 @@ CASES = [
     ("extra_mf_n640_b1000_adam", "mf", 640, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
     ("extra_pl_n768_b1000", "pl", 768, 1000, 400, None, None, 3e-4, 1e-5),
     ("extra_dl_n700_b1000", "dl", 700, 1000, 400, None, None, 3e-4, 1e-5),
+    # its half-chunk variant (round 5: K = 320 and 448; the DL case above is K = 704)
+    ("extra_langevin_n300_b1000", "langevin", 300, 1000, 500, None, None, 3e-4, 1e-5),
+    ("extra_mf_n448_b1000_adam", "mf", 448, 1000, 300, None, ADAM_A, 3e-4, 1e-5),
     # the persistent tile kernel's other solvers at the headline size (round 4): MF (mu, sigma in registers, the measured
     # amplitude handed over) and the Adam variants
     ("extra_mf_n1000_b1000", "mf", 1000, 1000, 400, None, None, 3e-4, 1e-5),
