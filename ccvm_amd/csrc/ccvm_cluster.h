@@ -165,7 +165,8 @@ typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 // (physical k = 32 g + t of that chunk holds logical k = 16 g + t for t < 16, nothing for t >= 16), so that the real k
 // are every lane group's FIRST sixteen operands: the chunk's second half-unit of MFMAs is all padding and is left out
 // (K in steps of 64 instead of 128: 1/6 of a step's MFMAs at K = 320, 1/12 at K = 704).  Fetch waves, ring and
-// barriers are the full kernel's; the results differ from it in nothing (the omitted products are zeros).
+// barriers are the full kernel's; the results differ from its results in summation order only (the omitted products are zeros,
+// the last chunk's real k meet the accumulators in another order).
 template <int MODE, bool ADAM, int KCH, bool REPLAY, bool HALF>
 __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: solver loops only");
