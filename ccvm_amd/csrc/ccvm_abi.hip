@@ -123,6 +123,7 @@ struct Tuning {
     int persist_ru = 0;  // 0: choose by batch size
     int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
+    int cluster_sets = 0;  // CCVM_AMD_CLUSTER_SETS=2|3 (tuning): that many row sets per cluster above K = 512; 0: cluster_sets()
     int cluster_half = 1;  // 0 (CCVM_AMD_CLUSTER_HALF=0, tuning): the full-chunk cluster kernel also where N mod 128 is in 1 .. 64
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
     int slab_cgrp = 0, slab_rg = 0;  // 0: choose (ccvm_slab.h: slab_plan)
@@ -159,6 +160,7 @@ Tuning read_tuning() {
     if (const char* e = std::getenv("CCVM_AMD_XCD")) t.xcd = e[0] != '0';
     if (const char* e = std::getenv("CCVM_AMD_XCD_XC")) t.xcd_xc = std::atoi(e);
     if (const char* e = std::getenv("CCVM_AMD_CLUSTER_HALF")) t.cluster_half = e[0] != '0';
+    if (const char* e = std::getenv("CCVM_AMD_CLUSTER_SETS")) t.cluster_sets = (e[0] == '2' || e[0] == '3') ? e[0] - '0' : 0;
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RU"))
         if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_KH"))
@@ -391,17 +393,33 @@ size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float);
 bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 768, every solver and Adam variant ---------
-// batch rows per cluster: two row sets of 16, three above K = 512 (ccvm_cluster.h: NSETS)
-int cluster_rows(int N) { return round_up(N, 128) > CL_LDS_K ? 3 * CL_ROWS : 2 * CL_ROWS; }
-int cluster_count(int B, int N) { return (B + cluster_rows(N) - 1) / cluster_rows(N); }
+// Row sets of 16 per cluster (ccvm_cluster.h: SETS).  K <= 512: two.  K = 640 / 768 (9-12 members): three where the batch
+// needs 48-row clusters to be on the chip at once (B = 1000: 21 clusters x 10 members), two where 32-row clusters are --
+// XCD by XCD or spread -- since a step is then two phases instead of three (round 5; measured, us per step, three sets ->
+// two: profiles/r05_ab_cluster_sets.txt).  `force` (CCVM_AMD_CLUSTER_SETS=2|3, tuning): that many above K = 512.
+int cluster_sets(int B, int N, const ChipGeometry& chip, int force = 0) {
+    if (round_up(N, 128) <= CL_LDS_K) return 2;
+    if (force == 2 || force == 3) return force;
+    const int G = (N + CL_COLS - 1) / CL_COLS, count2 = (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS);
+    const int xcds = chip.xcds > 0 ? chip.xcds : 1;
+    const bool pinned2 = (count2 + xcds - 1) / xcds * G <= chip.cus / xcds, spread2 = count2 * G <= chip.cus;
+    return (pinned2 || spread2) ? 2 : 3;
+}
+int cluster_rows(int B, int N, const ChipGeometry& chip, int force = 0) { return cluster_sets(B, N, chip, force) * CL_ROWS; }
+int cluster_count(int B, int N, const ChipGeometry& chip, int force = 0) {
+    const int rows = cluster_rows(B, N, chip, force);
+    return (B + rows - 1) / rows;
+}
 // the launch status word (its own 128-byte line), last in the workspace
 size_t cluster_sync_bytes(int) { return 128; }
 // the two exchange buffers of the cluster path: 8-byte {value, tag} packets (ccvm_cluster.h), one per element of
 // the clusters' rows; nothing at the sizes the cluster kernel does not serve
 // (planes: DL exchanges c and s, the one-stream solvers one array)
+// (sized for either number of row sets: a workspace does not know which one a call will take)
 size_t cluster_exchange_bytes(int B, int N, int planes) {
     if (N < CL_MIN_N || N > CL_MAX_N) return 0;
-    return 2 * (size_t)cluster_count(B, N) * cluster_rows(N) * planes * round_up(N, 128) * CL_XE;
+    const int rows2 = round_up(B, 2 * CL_ROWS), rows3 = round_up(N, 128) > CL_LDS_K ? round_up(B, 3 * CL_ROWS) : 0;
+    return 2 * (size_t)std::max(rows2, rows3) * planes * round_up(N, 128) * CL_XE;
 }
 // the persistent tile kernel's flag lines (ccvm_ptile.h): one 128-byte line of step counters per row block
 size_t ptile_flag_bytes(int B, int N) {
@@ -412,24 +430,29 @@ size_t exchange_bytes(int B, int N, int planes) {
     return std::max(std::max(cluster_exchange_bytes(B, N, planes), slab_exchange_bytes(B, N, planes)), ptile_flag_bytes(B, N));
 }
 // every cluster inside one XCD and all of them on the chip at once: ceil(clusters / XCDs) x members <= CUs per XCD
-bool cluster_resident_pinned(int B, int N, const ChipGeometry& chip) {
-    return (cluster_count(B, N) + chip.xcds - 1) / chip.xcds * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus / chip.xcds;
+bool cluster_resident_pinned(int B, int N, const ChipGeometry& chip, int force = 0) {
+    return (cluster_count(B, N, chip, force) + chip.xcds - 1) / chip.xcds * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus / chip.xcds;
 }
 // K > 512 and the XCD-pinned placement does not fit the chip at once while the plain one does: spread
-bool cluster_spread(int B, int N, const ChipGeometry& chip) {
-    return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip) &&
-           cluster_count(B, N) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
+bool cluster_spread(int B, int N, const ChipGeometry& chip, int force = 0) {
+    return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip, force) &&
+           cluster_count(B, N, chip, force) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
 }
+constexpr double CLUSTER_TWO_SETS = 0.70, CLUSTER_TWO_SETS_SPREAD = 0.80;
 // what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 320 / 384 / ... / 768 in
 // steps of 64 (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it; the odd
 // multiples of 64 are the half-chunk variant, profiles/r05_ab_cluster_half.txt)
-double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false, bool half = true) {
+double cluster_us(int mode, int B, int N, const ChipGeometry& chip, bool adam = false, bool half = true, int force_sets = 0) {
     static const double round_us[8][3] = {{7.16, 3.49, 3.37}, {7.9, 4.05, 3.77}, {9.57, 4.60, 4.40}, {10.1, 5.30, 4.85},
                                           {16.8, 8.69, 8.32}, {18.1, 9.5, 8.9},  {20.2, 10.6, 10.1}, {21.8, 11.2, 10.7}};
-    const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
-    const int per_round = cluster_spread(B, N, chip) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
+    const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N, chip, force_sets);
+    const int per_round = cluster_spread(B, N, chip, force_sets) ? count : chip.xcds * std::max(1, chip.cus / chip.xcds / G);
     const int k = (cluster_half(N, !half) ? G : round_up(N, 128) / 64) - 5;
-    return (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 7 ? 7 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
+    // (the table's K = 576 ... 768 rows are three row sets; two sets: two phases of the three -- 0.70-0.72 of the time
+    // measured XCD by XCD, 0.76-0.82 spread over the XCDs: two sets leave an input one phase to cross the fabric, three two)
+    const double sets = (round_up(N, 128) > CL_LDS_K && cluster_sets(B, N, chip, force_sets) == 2)
+                            ? (cluster_spread(B, N, chip, force_sets) ? CLUSTER_TWO_SETS_SPREAD : CLUSTER_TWO_SETS) : 1.0;
+    return sets * (adam ? 1.175 : 1.0) * ((count + per_round - 1) / per_round) * round_us[k < 0 ? 0 : k > 7 ? 7 : k][mode == MODE_DL ? 0 : mode == MODE_MF ? 1 : 2];
 }
 constexpr double CLUSTER_MARGIN = 0.98;  // (the audit: 0.95 kept six cells on the cluster path that one round of 32 x 64 tiles beats by 5-7 %; 1.0 loses Langevin + Adam N = 640, B = 2000 by 9 %)
 // mode: MODE_DL / MODE_MF / MODE_LANGEVIN of the run
@@ -461,13 +484,14 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // 2 rounds 18.0 vs 2 waves 24.3, MF 19.2 vs 28.5, DL 36.3 vs 44.9; B = 4000: 4 rounds 36.0 vs 3 waves 36.3; N = 768,
     // B = 2000: 3 rounds 31.8 vs 2 waves 27.9): the cluster path is taken when rounds < 1.3 x waves.
     const bool wide = round_up(N, 128) > CL_LDS_K;
-    const int count = cluster_count(B, N);
+    const int count = cluster_count(B, N, chip, tun.cluster_sets);
     const bool spread_fits = wide && count * G <= chip.cus;
     if (G > cus_per_xcd && !spread_fits) return false;  // a cluster must fit an XCD, or the whole grid the chip
-    const bool resident = cluster_resident_pinned(B, N, chip) || spread_fits;
+    const bool resident = cluster_resident_pinned(B, N, chip, tun.cluster_sets) || spread_fits;
     if (tun.cluster < 0 && planes == 2 && !wide && !resident) return false;
     if (tun.cluster < 0 && wide) {
-        if (B < 640) return false;
+        // (clusters of 32 rows -- two phases per step -- compete by their estimate alone, below)
+        if (B < 640 && cluster_sets(B, N, chip, tun.cluster_sets) == 3) return false;
         if (!resident) {
             const int per_round = chip.xcds * (cus_per_xcd / G);
             const int rounds = (count + per_round - 1) / per_round;
@@ -479,7 +503,7 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     // 32 x 32 tiles do -- DL N = 640, B = 768: 18.3 us against 14.6; N = 300, B = 768: 7.9 against 6.1; N = 768, B = 1500
     // (two rounds of clusters): 43.2 against 37.0 -- so by default the cluster path must not be estimated more than 2 %
     // behind the best per-step shape
-    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < CLUSTER_MARGIN * cluster_us(mode, B, N, chip, tun.adam, tun.cluster_half != 0)) return false;
+    if (tun.cluster < 0 && best_tile_us(mode, B, N, tun) < CLUSTER_MARGIN * cluster_us(mode, B, N, chip, tun.adam, tun.cluster_half != 0, tun.cluster_sets)) return false;
     return cluster_exchange_bytes(B, N, planes) / 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
 }
 // ---- the exchange area of the cluster / slab paths -----------------------------------------------------------
@@ -538,13 +562,15 @@ int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V,
     ca.xb0 = static_cast<float*>(area);
     ca.xb1 = reinterpret_cast<float*>(static_cast<char*>(area) + xb / 2);
     ca.status = reinterpret_cast<unsigned*>(static_cast<char*>(area) + exchange_bytes(B, N, planes));
-    xid = exchange_layout_id({1, B, N, planes, cluster_half(N, !tun.cluster_half) ? 1 : 0});
+    const ChipGeometry chip = chip_of(tun);
+    ca.sets = cluster_sets(B, N, chip, tun.cluster_sets);
+    xid = exchange_layout_id({1, B, N, planes, cluster_half(N, !tun.cluster_half) ? 1 : 0, ca.sets});
     if (exchange_prepare(area, xb, 0, 0, ca.status, xid, step0, st)) return CCVM_E_HIP;
     ca.seed = nz->seed; ca.row_offset = nz->row_offset; ca.replay = nz->mode == CCVM_NOISE_REPLAY;
     ca.B = B; ca.N = N; ca.ld = ld; ca.wld = (int)noise_pitch(nz, B);
-    ca.nclusters = cluster_count(B, N);
+    ca.nclusters = cluster_count(B, N, chip, tun.cluster_sets);
     ca.G = (N + CL_COLS - 1) / CL_COLS;
-    ca.spread = cluster_spread(B, N, chip_of(tun));
+    ca.spread = cluster_spread(B, N, chip, tun.cluster_sets);
     return CCVM_OK;
 }
 
@@ -656,7 +682,7 @@ bool want_ptile(const StepArgs& a, const Tuning& tun, int mode, bool vs) {
 // noise: the parts read their columns of the batch's blocks (ccvm_noise::w_ld).  Not with saturation arrays.
 double plan_us(int mode, int B, int N, const Tuning& tun) {
     if (const SlabPlan sp = want_slab(B, N, tun, mode); sp.ok) return (tun.adam ? 1.05 : 1.0) * sp.est_us;
-    if (want_cluster(B, N, tun, mode, tun.adam)) return cluster_us(mode, B, N, chip_of(tun), tun.adam, tun.cluster_half != 0);
+    if (want_cluster(B, N, tun, mode, tun.adam)) return cluster_us(mode, B, N, chip_of(tun), tun.adam, tun.cluster_half != 0, tun.cluster_sets);
     StepArgs a;
     base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, mode);
     if (const PtilePlan pp = plan_ptile(a, tun, false, mode); pp.slices) return pp.slices * ptile_round_us(mode, N, tun.adam);
@@ -677,7 +703,7 @@ int split_rows(int mode, int B, int N, const Tuning& tun) {
         // rounds, 9.8 us per step for Langevin; 32 resident clusters + 76 rows on the slab kernel: 6.7)
         const int G = (N + CL_COLS - 1) / CL_COLS;
         if (!tun.cluster || chip.xcds != 8 || chip.cus / chip.xcds < G) return 0;
-        rows_fit = chip.xcds * (chip.cus / chip.xcds / G) * cluster_rows(N);
+        rows_fit = chip.xcds * (chip.cus / chip.xcds / G) * 2 * CL_ROWS;
     } else {
         return 0;
     }
@@ -971,10 +997,13 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return CCVM_OK;
     }
     if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
-        const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N);
-        const bool spread = cluster_spread(B, N, chip_of(tun));
-        std::snprintf(buf, buf_len, "ccvm::cluster_kernel%s<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
-                      cluster_half(N, !tun.cluster_half) ? "_half" : "", solver, ad ? "true" : "false", ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
+        const ChipGeometry chip = chip_of(tun);
+        const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N, chip, tun.cluster_sets);
+        const bool spread = cluster_spread(B, N, chip, tun.cluster_sets);
+        const bool two_wide = ccvm_ld(N) > CL_LDS_K && cluster_sets(B, N, chip, tun.cluster_sets) == 2;
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel%s%s<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
+                      cluster_half(N, !tun.cluster_half) ? "_half" : "", two_wide ? "_2sets" : "", solver, ad ? "true" : "false",
+                      ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
                       spread ? ", spread over the XCDs" : "", TABLE_STEPS);
         return CCVM_OK;
     }

@@ -106,6 +106,7 @@ struct ClusterArgs {
     int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
     int half_off;        // host only (tuning): 1 = the full kernel also where the half-chunk variant applies
+    int sets;            // host only: row sets of 16 per cluster (2; K = 640 / 768: 3, or 2 where clusters of 32 rows fit the chip)
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;             // MF: clamp of the measured amplitude
@@ -167,13 +168,17 @@ typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 // (K in steps of 64 instead of 128: 1/6 of a step's MFMAs at K = 320, 1/12 at K = 704).  Fetch waves, ring and
 // barriers are the full kernel's; the results differ from its results in summation order only (the omitted products are zeros,
 // the last chunk's real k meet the accumulators in another order).
-template <int MODE, bool ADAM, int KCH, bool REPLAY, bool HALF>
+// SETS (round 5): row sets of 16 per cluster.  K <= 512: two.  K = 640 / 768: three where the batch needs them to fit the
+// chip (B = 1000: 21 clusters of 48 rows), two where clusters of 32 rows fit as well (B <= 672 ... 896 by member count):
+// a step is then two phases instead of three (ccvm_abi.hip: cluster_rows).
+template <int MODE, bool ADAM, int KCH, bool REPLAY, bool HALF, int SETS>
 __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "cluster kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant");
     static_assert(KCH >= 3 && KCH <= 6, "K = 384 ... 768");
     constexpr int K = KCH * CL_KC;
-    constexpr int NSETS = (KCH > 4) ? 3 : 2;       // row sets of 16 per cluster (ccvm_abi.hip: cluster_rows)
+    static_assert(SETS == 2 || (SETS == 3 && KCH > 4), "row sets per cluster");
+    constexpr int NSETS = SETS;                    // row sets of 16 per cluster (ccvm_abi.hip: cluster_rows)
     constexpr int CROWS = NSETS * CL_ROWS;
     constexpr int KL = (KCH > 4) ? 4 : KCH;        // panel chunks in LDS; chunks KL .. KCH-1 in registers
     // DL contracts two input planes (c, then s) against the same panel: 2 KCH chunks per phase, two accumulator sets
@@ -776,13 +781,25 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
 
 template <int MODE, bool ADAM, int KCH, bool REPLAY>
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
-    cluster_body<MODE, ADAM, KCH, REPLAY, false>(a);
+    cluster_body<MODE, ADAM, KCH, REPLAY, false, (KCH > 4) ? 3 : 2>(a);
 }
 
 // K = 128 KCH - 64 (an odd number of members)
 template <int MODE, bool ADAM, int KCH, bool REPLAY>
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel_half(const ClusterArgs a) {
-    cluster_body<MODE, ADAM, KCH, REPLAY, true>(a);
+    cluster_body<MODE, ADAM, KCH, REPLAY, true, (KCH > 4) ? 3 : 2>(a);
+}
+
+// K = 640 / 768 in clusters of 32 rows (two row sets)
+template <int MODE, bool ADAM, int KCH, bool REPLAY>
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel_2sets(const ClusterArgs a) {
+    static_assert(KCH > 4, "K <= 512 always runs two row sets");
+    cluster_body<MODE, ADAM, KCH, REPLAY, false, 2>(a);
+}
+template <int MODE, bool ADAM, int KCH, bool REPLAY>
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel_half_2sets(const ClusterArgs a) {
+    static_assert(KCH > 4, "K <= 512 always runs two row sets");
+    cluster_body<MODE, ADAM, KCH, REPLAY, true, 2>(a);
 }
 
 // K > 512 is served for every solver variant: with half-chunk operand units the MFMA waves' registers suffice (the
@@ -798,6 +815,16 @@ void cluster_launch_lv(const ClusterArgs& a, bool adam, hipStream_t st);
 template <int MODE, bool ADAM, bool REPLAY>
 void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
     const int kch = a.ld / CL_KC;
+    if (kch > 4 && a.sets == 2) {
+        if (cluster_half(a.N, a.half_off)) {
+            if (kch == 5) hipLaunchKernelGGL((cluster_kernel_half_2sets<MODE, ADAM, 5, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((cluster_kernel_half_2sets<MODE, ADAM, 6, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        } else {
+            if (kch == 5) hipLaunchKernelGGL((cluster_kernel_2sets<MODE, ADAM, 5, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((cluster_kernel_2sets<MODE, ADAM, 6, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
+        }
+        return;
+    }
     if (cluster_half(a.N, a.half_off)) {
         if (kch == 3) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 3, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);
         else if (kch == 4) hipLaunchKernelGGL((cluster_kernel_half<MODE, ADAM, 4, REPLAY>), dim3(grid), dim3(CL_THREADS), 0, st, a);

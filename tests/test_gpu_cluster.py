@@ -131,10 +131,10 @@ def test_half_chunk_variant_against_the_full_kernel(cluster, monkeypatch, kind, 
 
     hp = _ADAMS[adam]
     seed, row_offset = 0xAB5_1234, 3
-    assert "cluster_kernel_half<" in describe()
+    assert "cluster_kernel_half" in describe()
     half = _run_engine(kind, n, b, t, hp, seed, row_offset)
     monkeypatch.setenv("CCVM_AMD_CLUSTER_HALF", "0")
-    assert "cluster_kernel<" in describe()
+    assert "cluster_kernel<" in describe() or "cluster_kernel_2sets<" in describe()
     full = _run_engine(kind, n, b, t, hp, seed, row_offset)
     gate = (max(n, 20) / 20.0) ** 0.5
     for name, want in _run_oracle(kind, n, b, t, hp, seed, row_offset):
@@ -142,6 +142,36 @@ def test_half_chunk_variant_against_the_full_kernel(cluster, monkeypatch, kind, 
         for got in (half.compact(name).cpu(), full.compact(name).cpu()):
             assert float((got - want).abs().max()) <= ATOL_X * gate * scale, f"{kind} N={n} {name}"
         assert float((half.compact(name).cpu() - full.compact(name).cpu()).abs().max()) <= 2e-4 * gate * scale
+
+
+@pytest.mark.parametrize("kind,n,b,t,adam", [("langevin", 640, 500, 16, None), ("pl", 576, 700, 12, "second_moment"), ("dl", 704, 300, 10, None),
+                                              ("mf", 768, 512, 10, "add_assign"), ("dl", 768, 672, 8, None), ("mf", 600, 33, 12, None)])
+def test_two_and_three_row_sets_above_k_512_are_the_same_numbers(cluster, monkeypatch, kind, n, b, t, adam):
+    """K = 640 / 768 runs clusters of 32 rows (two row sets: two phases per step) where they fit the chip and clusters of
+    48 (three) where the batch needs them; CCVM_AMD_CLUSTER_SETS forces either.  A row's contraction does not depend on
+    how rows are grouped: both give the same bits, and both match the oracle."""
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    def describe():
+        buf = ctypes.create_string_buffer(1024)
+        assert _lib.load().ccvm_describe_launch({"dl": 0, "mf": 1}.get(kind, 2), b, n, 1 if adam else 0, 0, buf, 1024) == 0
+        return buf.value.decode()
+
+    hp = _ADAMS[adam]
+    seed, row_offset = 0x5E75_0002, 5
+    assert "_2sets<" in describe()  # (every case here fits the chip in clusters of 32 rows)
+    two = _run_engine(kind, n, b, t, hp, seed, row_offset)
+    monkeypatch.setenv("CCVM_AMD_CLUSTER_SETS", "3")
+    assert "_2sets<" not in describe() and "cluster_kernel" in describe()
+    three = _run_engine(kind, n, b, t, hp, seed, row_offset)
+    for name in two.state:
+        assert torch.equal(two.compact(name), three.compact(name)), name
+    gate = (max(n, 20) / 20.0) ** 0.5
+    for name, want in _run_oracle(kind, n, b, t, hp, seed, row_offset):
+        scale = max(1.0, float(want.abs().max()))
+        assert float((two.compact(name).cpu() - want).abs().max()) <= ATOL_X * gate * scale, f"{kind} N={n} {name}"
 
 
 def test_cluster_kernel_is_what_ran(cluster):
