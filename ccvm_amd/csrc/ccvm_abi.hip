@@ -393,17 +393,26 @@ size_t table_bytes() { return (size_t)TABLE_STEPS * TABLE_WORDS * sizeof(float);
 bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 768, every solver and Adam variant ---------
+constexpr double CLUSTER_TWO_SETS = 0.70, CLUSTER_TWO_SETS_SPREAD = 0.80;  // a step on two row sets relative to three (XCD by XCD / spread)
 // Row sets of 16 per cluster (ccvm_cluster.h: SETS).  K <= 512: two.  K = 640 / 768 (9-12 members): three where the batch
 // needs 48-row clusters to be on the chip at once (B = 1000: 21 clusters x 10 members), two where 32-row clusters are --
-// XCD by XCD or spread -- since a step is then two phases instead of three (round 5; measured, us per step, three sets ->
-// two: profiles/r05_ab_cluster_sets.txt).  `force` (CCVM_AMD_CLUSTER_SETS=2|3, tuning): that many above K = 512.
+// XCD by XCD or spread -- or run in no more rounds than the 48-row ones, since a step is then two phases instead of three
+// (round 5; measured, us per step, three sets -> two: profiles/r05_ab_cluster_sets.txt).  `force` (CCVM_AMD_CLUSTER_SETS=2|3, tuning): that many above K = 512.
 int cluster_sets(int B, int N, const ChipGeometry& chip, int force = 0) {
     if (round_up(N, 128) <= CL_LDS_K) return 2;
     if (force == 2 || force == 3) return force;
-    const int G = (N + CL_COLS - 1) / CL_COLS, count2 = (B + 2 * CL_ROWS - 1) / (2 * CL_ROWS);
-    const int xcds = chip.xcds > 0 ? chip.xcds : 1;
-    const bool pinned2 = (count2 + xcds - 1) / xcds * G <= chip.cus / xcds, spread2 = count2 * G <= chip.cus;
-    return (pinned2 || spread2) ? 2 : 3;
+    const int G = (N + CL_COLS - 1) / CL_COLS, xcds = chip.xcds > 0 ? chip.xcds : 1;
+    const int per_round = xcds * std::max(1, chip.cus / xcds / G);
+    // rounds of resident clusters x the time of a round relative to three row sets (ccvm_abi.hip: cluster_us); batches of
+    // several rounds count too: N = 640, B = 1500 = 32 clusters of 48 rows or 47 of 32, two rounds of 24 either way --
+    // MF 19.0 us per step on three sets, 13.2 on two (the per-step tiles: 15.4)
+    auto cost = [&](int sets) {
+        const int count = (B + sets * CL_ROWS - 1) / (sets * CL_ROWS);
+        const bool pinned = (count + xcds - 1) / xcds * G <= chip.cus / xcds, spread = !pinned && count * G <= chip.cus;
+        const int rounds = (pinned || spread) ? 1 : (count + per_round - 1) / per_round;
+        return rounds * (sets == 3 ? 1.0 : spread ? CLUSTER_TWO_SETS_SPREAD : CLUSTER_TWO_SETS);
+    };
+    return cost(2) < cost(3) ? 2 : 3;
 }
 int cluster_rows(int B, int N, const ChipGeometry& chip, int force = 0) { return cluster_sets(B, N, chip, force) * CL_ROWS; }
 int cluster_count(int B, int N, const ChipGeometry& chip, int force = 0) {
@@ -438,7 +447,6 @@ bool cluster_spread(int B, int N, const ChipGeometry& chip, int force = 0) {
     return round_up(N, 128) > CL_LDS_K && !cluster_resident_pinned(B, N, chip, force) &&
            cluster_count(B, N, chip, force) * ((N + CL_COLS - 1) / CL_COLS) <= chip.cus;
 }
-constexpr double CLUSTER_TWO_SETS = 0.70, CLUSTER_TWO_SETS_SPREAD = 0.80;
 // what a step costs on the cluster kernel (us): rounds of resident clusters, a round by K = 320 / 384 / ... / 768 in
 // steps of 64 (measured at B = 1000: docs/kernel-cluster.md; the audit's cluster cells lie within 3 % of it; the odd
 // multiples of 64 are the half-chunk variant, profiles/r05_ab_cluster_half.txt)
@@ -491,8 +499,9 @@ bool want_cluster(int B, int N, const Tuning& tun, int mode, bool adam) {
     if (tun.cluster < 0 && planes == 2 && !wide && !resident) return false;
     if (tun.cluster < 0 && wide) {
         // (clusters of 32 rows -- two phases per step -- compete by their estimate alone, below)
-        if (B < 640 && cluster_sets(B, N, chip, tun.cluster_sets) == 3) return false;
-        if (!resident) {
+        const bool three = cluster_sets(B, N, chip, tun.cluster_sets) == 3;
+        if (B < 640 && three) return false;
+        if (!resident && three) {
             const int per_round = chip.xcds * (cus_per_xcd / G);
             const int rounds = (count + per_round - 1) / per_round;
             const int waves = (((B + BM - 1) / BM) * ((N + BN - 1) / BN) + chip.cus - 1) / chip.cus;

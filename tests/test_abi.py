@@ -111,14 +111,15 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (2, 1000, 600, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 1): "ccvm::cluster_kernel<2, true, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (1, 1200, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 250 x 512 threads (25 clusters of 10 workgroups, spread over the XCDs)",
-        (1, 1300, 600, 0): "ccvm::step_kernel<1, false, 0, 1, false, 0> grid 205 x 512",
+        # two rounds of 32-row clusters (MF N = 640, B = 1500: 13.1 us per step against 15.1 on the per-step tiles)
+        (1, 1300, 600, 0): "ccvm::cluster_kernel_2sets<1, false, 5, false> grid 480 x 512 threads (41 clusters of 10 workgroups)",
         (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
         (0, 1000, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 252 x 512 threads (21 clusters of 12 workgroups, spread over the XCDs)",
         (2, 1000, 700, 1): "ccvm::cluster_kernel_half<2, true, 6, false> grid 231 x 512 threads (21 clusters of 11 workgroups, spread over the XCDs)",
         (0, 1100, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 210 x 512",
         (2, 2000, 640, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 480 x 512 threads (42 clusters of 10 workgroups)",
-        (2, 1500, 640, 0): "ccvm::step_kernel<2, false, 0, 1, false, 0> grid 235 x 512",
+        (2, 1500, 640, 0): "ccvm::cluster_kernel_2sets<2, false, 5, false> grid 480 x 512 threads (47 clusters of 10 workgroups)",  # 12.9 us vs 13.2
         (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 756 x 512",   # 3 rounds of 32 x 64 tiles < 2 of 32 x 128
         (0, 256, 1000, 0): "ccvm::step_kernel<0, false, 0, 4, false, 0> grid 256 x 512",   # 32 x 32 tiles fill the chip
         # K = 768 in clusters of 32 rows (two row sets) where they fit the chip: 7.3 us per step against 9.6 on 32 x 64 tiles
