@@ -226,8 +226,8 @@ def test_default_policy_against_the_regret_audit(hip_lib, clean_env):
     map, the measured time per step of every plan that can serve the cell (tools/policy_regret.py on an MI355X: the
     default and every forced family / tile shape).  Whatever the policy functions become, the plan they pick for a cell
     must not be measured more than 9 % behind the best plan of that cell (the audit itself lists what is beyond 5 %:
-    six cells of 754 with the Adam variants, the largest -- one exempted below aside -- 7.5 %: Langevin N = 900,
-    B = 800, resident tile kernel 16.0 us against three rounds of 32 x 32 tiles 14.9; run-to-run noise of a cell is
+    seven cells of 773 with the Adam variants, the largest without Adam 8 %: Langevin N = 640, B = 2500, four rounds of
+    32-row clusters 25.6 us against 32 x 32 tiles 23.7; run-to-run noise of a cell is
     about 2 %), and a larger batch must never be faster than a smaller one by more than 8 % under the picked plans.
     (The cells of N = 300, 448, 576 and 700 were measured after the cluster kernel's half-chunk variant went in, those of
     N = 1500 and 2000 after the blocked order of the 32 x 32 tiles.)"""
