@@ -49,6 +49,9 @@ WORKLOADS = {
     # the low end of the column-cluster kernel's range (K = 320: its half-chunk variant, ccvm_cluster.h)
     "langevin_n300_b1000": ("langevin", 300, 1000),
     "dl_n300_b1000": ("dl", 300, 1000),
+    # K = 640 in clusters of 32 rows (two row sets where they fit the chip: ccvm_abi.hip, cluster_sets)
+    "langevin_n640_b512": ("langevin", 640, 512),
+    "dl_n640_b512": ("dl", 640, 512),
     "langevin_n1000_b1000": ("langevin", 1000, 1000),  # the one-stream solvers at the headline's size
     "mf_n1000_b1000": ("mf", 1000, 1000),
     # small batches (the reference runs any batch_size through the same einsum, dl_solver.py:145-153): the

@@ -32,6 +32,8 @@ ROWS = [
     ("dl_n500_b1000", "DL at config 3's size (not a BASELINE configuration)", "16 N + 4 N²/B"),
     ("langevin_n300_b1000", "the low end of the cluster kernel's range (its half-chunk variant, K = 320)", "8 N + 4 N²/B"),
     ("dl_n300_b1000", "the same, DL", "16 N + 4 N²/B"),
+    ("langevin_n640_b512", "K = 640 at half the batch: clusters of 32 rows (two row sets)", "8 N + 4 N²/B"),
+    ("dl_n640_b512", "the same, DL", "16 N + 4 N²/B"),
     ("dl_n1000_b256", "mid-size batch", "16 N + 4 N²/B"),
     ("dl_n1000_b32", "small batch (the reference runs any batch_size)", "16 N (Q never moves)"),
     ("dl_n1000_b1", "a single trajectory", "16 N (Q never moves)"),
