@@ -370,13 +370,16 @@ def test_time_out_recovery_before_the_state_is_clamped_or_copied(monkeypatch, ki
         assert float(got.variables["problem_variables"].abs().max()) <= 1.0
 
 
-@pytest.mark.parametrize("kind,adam,n", [("langevin", None, 500), ("mf", "second_moment", 500), ("dl", None, 500),
-                                         ("langevin", None, 768), ("dl", None, 640), ("pl", None, 700)])
-def test_cluster_soak_is_deterministic(cluster, kind, adam, n):
+@pytest.mark.parametrize("kind,adam,n,b", [("langevin", None, 500, 1000), ("mf", "second_moment", 500, 1000), ("dl", None, 500, 1000),
+                                           ("langevin", None, 768, 1000), ("dl", None, 640, 1000), ("pl", None, 700, 1000),
+                                           # K > 512 on two row sets: XCD by XCD, spread over the XCDs, in two rounds; the half-chunk variant
+                                           ("mf", None, 640, 512), ("langevin", "add_assign", 768, 672), ("dl", None, 704, 500),
+                                           ("pl", None, 640, 1500), ("langevin", None, 300, 1000)])
+def test_cluster_soak_is_deterministic(cluster, kind, adam, n, b):
     """20 000 steps at the BASELINE config-3 shape (and at K = 640 / 768), twice (one in 4096-step launches, one in
     ragged chunks): bit-identical and finite.  The exchange is the only cross-workgroup traffic in the engine: a single
     stale or torn read anywhere in 10^10 exchanged words would show here."""
-    b, t = 1000, 20000
+    t = 20000
     first = _run_engine(kind, n, b, t, _ADAMS[adam], 4242, 0)
     second = _run_engine(kind, n, b, t, _ADAMS[adam], 4242, 0, chunks=[4096, 1, 4095, 5000, 6808])
     for name in first.state:
