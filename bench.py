@@ -71,7 +71,26 @@ WORKLOADS = {
     "dl_n1000_b4000": ("dl", 1000, 4000),
     "pl_n2000_b1024": ("pl", 2000, 1024),
     "pl_n2000_b2048": ("pl", 2000, 2048),
+    # the reference's own shipped regime (N = 20 ... 70: the only sizes with known optima, i.e. where TTS @ 99 % exists):
+    # BASELINE config 1 exactly (test020-100-10.in, batch 100, the schedule of a 15000-iteration run), the shipped example
+    # (examples/ccvm_boxqp_dl.py:12-24: tuningH020-100-0.in, batch 1000) for every solver, and the largest shipped size
+    "dl_n20_b100": ("dl", 20, 100),
+    "dl_n20_b1000": ("dl", 20, 1000),
+    "mf_n20_b1000": ("mf", 20, 1000),
+    "langevin_n20_b1000": ("langevin", 20, 1000),
+    "pl_n20_b1000": ("pl", 20, 1000),
+    "dl_n70_b1000": ("dl", 70, 1000),
 }
+#: workloads on a shipped instance (arrays: tests/golden/<instance>.npz, made from the reference's .in files) and / or
+#: inside the schedule of a longer run than the timed steps (`total`: the iterations of the run the steps belong to)
+WORKLOAD_EXTRAS = {
+    "dl_n20_b100": {"instance": "test020", "total": 15000},
+    "dl_n20_b1000": {"instance": "tuningH020"},
+    "mf_n20_b1000": {"instance": "tuningH020"},
+    "langevin_n20_b1000": {"instance": "tuningH020"},
+    "pl_n20_b1000": {"instance": "tuningH020"},
+}
+REPEATS = 9  # timed regions of exactly K steps per run; the line reports the median one
 SOLVER_ID = {"dl": 0, "mf": 1, "langevin": 2, "pl": 2}
 SATURATION = {"dl": 1.0, "mf": 20.0, "langevin": 0.5, "pl": 0.5}  # the example scripts' S (workloads.py)
 
@@ -223,43 +242,54 @@ def init_collectives(rank, world, dev, share, probe=None, timeout_s=None):
     return {"group": None, "device": cpu, "collective": f"gloo-fallback: {first}"}
 
 
-def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag):
-    """W untimed warm-up steps, then K steps of `traj` under the contract's clock -- barrier + device synchronisation on
-    both sides, HIP events on the launch stream around the same region -- repeated when the steps turn out INVALID: a
-    persistent kernel whose workgroups could not all become resident gives up a bounded wait and sets the run's status
-    word; its steps are garbage, and `traj.check` puts the trajectories back where the recovery snapshot was taken and
-    moves the run to the per-step kernel.  The snapshot is taken ONCE, in front of the warm-up steps (two
-    device-to-device copies: right in front of the timed region they would push Q and the state out of the L2s), the
-    status word is read ONCE, right after the clock stops (4 bytes; inside the region it would cost ~25 us of a 0.65 ms
-    run, between warm-up and timed steps it would leave the chip idle for as long), and a run that was recovered -- the
-    word is set by warm-up and timed steps alike and never cleared by a kernel -- starts over from the snapshot on the
-    path that then runs, so `value` never describes discarded work.  `any_rank(flag)`: True when the flag is set
-    on ANY rank: the ranks start over together (the barriers must pair up).
-    Returns (wall seconds, stream ms, attempts)."""
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()  # torch creates the HIP event at its first record (15-20 us): the measuring apparatus is set up
-    ev1.record()  # BEFORE the timed region (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
+def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag, repeats=1):
+    """W untimed warm-up steps, then `repeats` timed regions of EXACTLY K steps of `traj` each, every one under the
+    contract's clock -- barrier + device synchronisation on both sides, HIP events on the launch stream around the same
+    region -- and the whole sequence repeated when steps turn out INVALID: a persistent kernel whose workgroups could not
+    all become resident gives up a bounded wait and sets the run's status word; its steps are garbage, and `traj.check`
+    puts the trajectories back where the recovery snapshot was taken and moves the run to the per-step kernel.  The
+    snapshot is taken ONCE, in front of the warm-up steps (two device-to-device copies: right in front of a timed region
+    they would push Q and the state out of the L2s), the status word is read once per region, right after its clock
+    stops (4 bytes; inside the region it would cost ~25 us of a 0.65 ms run), and a run that was recovered -- the word is
+    set by warm-up and timed steps alike and never cleared by a kernel -- starts over from the snapshot on the path that
+    then runs, so no reported time ever describes discarded work.  `any_rank(flag)`: True when the flag is
+    set on ANY rank: the ranks start over together (the barriers must pair up).
+    Returns ([wall seconds per region], [stream ms per region], attempts)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repeats)]
+    for ev0, ev1 in evs:
+        ev0.record()  # torch creates the HIP event at its first record (15-20 us): the measuring apparatus is set up
+        ev1.record()  # BEFORE the timed regions (tools/sync_probe.py: 36.3 -> 35.5 us per step on a 20-step run)
     traj.arm(force=True)  # (forced: another rank may ask this one to start over although its own steps were valid)
     for attempt in (1, 2, 3):
         traj.advance(warmup)  # (not verified by itself: a status word set here is still set behind the timed steps)
-        torch.cuda.synchronize(dev)
-        barrier()     # every rank starts its K steps together ...
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ev0.record()
-        traj.advance(steps)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0  # ... and stops ITS OWN clock when its own K steps are done: no collective
-        #                                     inside the timed region (a 50-150 us barrier would read as a 7-20 % "scaling
-        #                                     loss" on the driver's 0.7 ms, VERDICT r3); the job's time is the MAX over ranks
-        recovered = traj.check(rerun=False, hold=True)  # True: back at the snapshot, on the per-step kernel from here on
-        if not any_rank(recovered):
+        walls, valid = [], True
+        for ev0, ev1 in evs:
+            torch.cuda.synchronize(dev)
+            barrier()     # every rank starts its K steps together ...
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ev0.record()
+            traj.advance(steps)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)  # ... and stops ITS OWN clock when its own K steps are done: no collective
+            #                                     inside a timed region (a 50-150 us barrier would read as a 7-20 % "scaling
+            #                                     loss" on the driver's 0.7 ms, VERDICT r3); the job's time is the MAX over ranks
+            recovered = traj.check(rerun=False, hold=True)  # True: back at the snapshot, on the per-step kernel from here on
+            if any_rank(recovered):
+                if not recovered:
+                    traj.rollback()  # another rank starts over: this one does with it
+                valid = False
+                break
+        if valid:
             traj.check()  # (drops the snapshot)
-            return elapsed, ev0.elapsed_time(ev1), attempt
-        if not recovered:
-            traj.rollback()  # another rank starts over: this one does with it
+            return walls, [ev0.elapsed_time(ev1) for ev0, ev1 in evs], attempt
     raise SystemExit("bench.py: the run was invalid three times in a row")
+
+
+def median(values):
+    v = sorted(values)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
 # --------------------------------------------------------------------------- #
@@ -285,14 +315,11 @@ def profiled_counters(workload):
         out["traffic_bytes_per_step"] = 1024.0 * (2.0 * c["FETCH_SIZE"]["mean_per_dispatch"]
                                                   + c["WRITE_SIZE"]["mean_per_dispatch"]) / doc.get("steps_per_dispatch", 1.0)
         out["dispatches"] = c["FETCH_SIZE"]["dispatches"]
-    m = re.search(r"persist_kernel<[^>]*> = .*B=(\d+)", doc.get("kernel") or "")
-    if "SQ_INSTS_VALU" in c and m:
-        # row-owner kernel: 256-thread workgroups of four waves; rows per workgroup from the kernel's own grid is not in
-        # the summary, but SQ_VALU_MFMA_BUSY_CYCLES / 8 cycles = MFMAs issued = waves x steps x 16 NCH
-        pk = re.search(r"persist_kernel<\d, \w+, \d+, \d+, (\d+), \d+(?:, (\d+))?>", doc["kernel"])
-        nch, kh = int(pk.group(1)), int(pk.group(2) or 1)   # K split: a wave runs 16 NCH / KH MFMAs per step
-        wave_steps = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / 8.0 / (16 * nch / kh)
-        out["valu_per_wave_step"] = c["SQ_INSTS_VALU"]["mean_per_dispatch"] / wave_steps
+    if "SQ_INSTS_VALU" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # executed vector instructions (MFMAs included) and matrix-pipe busy cycles, summed over the chip, per time step
+        per = doc.get("steps_per_dispatch", 1.0)
+        out["insts_valu_per_step"] = c["SQ_INSTS_VALU"]["mean_per_dispatch"] / per
+        out["mfma_busy_cycles_per_step"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / per
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # MFMA_BUSY is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (its
         # per-engine value is the kernel's length in cycles)
@@ -314,11 +341,28 @@ def workload_params(kind):
     return p
 
 
-def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None, adam=None):
-    from ccvm_amd import engine
-    from ccvm_amd.workloads import scaled_qv
+def problem_qv(kind, n, instance=None):
+    """(Q, V, scaled_by) of a workload: the synthetic recipe of SURVEY 8(d), or a shipped instance's arrays (fixtures
+    under tests/golden/, made from the reference's .in files) scaled the way the solver scales them
+    (ccvm_solver.py get_scaling_factor -> problem_instance.py scale_coefs)."""
+    from ccvm_amd.workloads import SCALING_MULTIPLIER, scaled_qv
 
-    q, v, _ = scaled_qv(n, kind)
+    if instance is None:
+        return scaled_qv(n, kind)
+    import numpy as np
+
+    arrays = np.load(os.path.join(ROOT, "tests", "golden", f"{instance}.npz"))
+    q = torch.from_numpy(arrays["q_matrix"]).to(torch.float32)
+    v = torch.from_numpy(arrays["v_vector"]).to(torch.float32)
+    assert q.shape == (n, n), (instance, q.shape, n)
+    f = torch.sqrt(torch.sum(torch.abs(q))) * SCALING_MULTIPLIER[kind]
+    return q / f, v / f, f
+
+
+def make_trajectories(kind, n, b, total_steps, rank, seed=1, row_offset=None, adam=None, instance=None):
+    from ccvm_amd import engine
+
+    q, v, _ = problem_qv(kind, n, instance)
     prob = engine.DeviceProblem(q, v)
     noise = engine.NoiseSpec(mode="fused", seed=seed, row_offset=rank * b if row_offset is None else row_offset)
     ekind = {"dl": "dl", "mf": "mf"}.get(kind, "langevin")
@@ -333,23 +377,28 @@ def cpu_model():
         return "unknown CPU"
 
 
-def cpu_baseline(kind, n, b, total_steps, budget_s=12.0, threads=None):
-    """The oracle (torch CPU restatement of the reference loop, bit-identical to it on this torch
-    build) timed on the host cores on a bounded sample of the same workload.  Threads: a 1-GPU box
-    exposes a 16-core CPU share of the host; profiles/r02_cpu_thread_sweep.md holds the 1..64-thread
-    sweep behind the default (more threads than the share only oversubscribe)."""
-    from ccvm_amd.workloads import scaled_qv
+def cpu_baseline(kind, n, b, total_steps, budget_s=30.0, threads=None, instance=None, min_steps=200, min_seconds=2.0,
+                 warm_steps=20):
+    """The oracle (torch CPU restatement of the reference loop, bit-identical to it on this torch build) timed on the
+    host cores on a bounded sample of the same workload: `warm_steps` untimed steps, then steps until BOTH at least
+    `min_steps` steps and `min_seconds` seconds are timed (>= 200 timed steps after >= 20
+    warm-up) -- whatever --steps says -- or `budget_s` seconds are spent.  Threads: a 1-GPU box exposes a share of the
+    host's cores; profiles/r06_cpu_thread_sweep.md holds the 1..64-thread sweep behind the default (more threads than
+    the share only oversubscribe).  `cores` = the threads used (the contract's field), `threads` the same,
+    `cores_visible` = the cores this process may run on."""
     from oracle import ccvm_oracle as oracle
 
     visible = len(os.sched_getaffinity(0))
     torch.set_num_threads(max(1, threads or min(16, visible)))
-    q, v, _ = scaled_qv(n, kind)
+    q, v, _ = problem_qv(kind, n, instance)
     p = workload_params(kind)
     torch.manual_seed(1)
     bounds = (0.0, 1.0)
+    chunk = 10
+    schedule_total = max(total_steps, 20000)  # (the sample's steps must exist in the schedule of the run)
     if kind == "dl":
         c = torch.zeros((b, n)); s = torch.zeros((b, n))
-        run = lambda step0, k: oracle.dl_loop(q, v, b, total_steps, p["pump"], p["dt"], p["noise_ratio"],
+        run = lambda step0, k: oracle.dl_loop(q, v, b, schedule_total, p["pump"], p["dt"], p["noise_ratio"],
                                               p["feedback_scale"], p["g"], bounds, True, None, step0, k, c, s)
     else:
         # the other loops run whole trajectories: time short runs of the same per-step work
@@ -360,21 +409,25 @@ def cpu_baseline(kind, n, b, total_steps, budget_s=12.0, threads=None):
                 oracle.langevin_loop(q, v, b, k, p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
             else:
                 oracle.pl_loop(q, v, b, k, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
-    run(0, 2)  # warm-up (first-call overheads)
-    done, t0 = 2, time.time()
-    while time.time() - t0 < budget_s and done + 5 <= max(total_steps, 12):
-        run(done, 5)
-        done += 5
-    dt = time.time() - t0
-    steps = done - 2
+    run(0, warm_steps)  # warm-up (first-call overheads, thread pool, caches)
+    done, t0 = warm_steps, time.time()
+    while True:
+        run(done, chunk)
+        done += chunk
+        dt = time.time() - t0
+        if (done - warm_steps >= min_steps and dt >= min_seconds) or dt >= budget_s or done + chunk > schedule_total:
+            break
+    steps = done - warm_steps
+    used = torch.get_num_threads()
     return {
-        "value": b * steps / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"{steps} steps of the same workload (N={n}, batch={b}) " if kind == "dl" else
-                   f"{steps // 5} whole 5-step runs (N={n}, batch={b}: the same per-step work, each run with its own "
-                   f"set-up and a 5-step schedule, not steps {total_steps - steps}.. of the benchmarked run) ")
+        "value": b * steps / dt, "unit": "row-steps/s", "cores": used, "threads": used, "cores_visible": visible,
+        "kind": "port", "timed_steps": steps, "warmup_steps": warm_steps, "seconds": dt,
+        "sample": (f"{steps} steps of the same workload (N={n}, batch={b}) after {warm_steps} warm-up steps " if kind == "dl" else
+                   f"{steps // chunk} whole {chunk}-step runs after {warm_steps} warm-up steps (N={n}, batch={b}: the same "
+                   f"per-step work, each run with its own set-up and a {chunk}-step schedule, not steps of the benchmarked run) ")
                   + f"with the torch-CPU oracle "
-                  f"(bit-identical to the reference's CPU path), {dt / steps * 1e3:.1f} ms/step, "
-                  f"{torch.get_num_threads()} torch threads on {cpu_model()} ({visible} cores visible to this "
+                  f"(bit-identical to the reference's CPU path), {dt / steps * 1e3:.2f} ms/step, "
+                  f"{used} torch threads on {cpu_model()} ({visible} cores visible to this "
                   f"process), torch {torch.__version__}",
     }
 
@@ -411,38 +464,34 @@ def tts99_leg():
     }
 
 
-def family_roof(launch, kind, n, b, step_us, wall_step_us):
-    """Extra roofline fields for the kernel families whose binding roof is not the fp32 MFMA peak.
+def family_model(launch, kind, n, b, step_us, wall_step_us, workload):
+    """Performance MODELS of the kernel families whose step is not explained by a hardware roof -- reported beside the
+    roofline (`roofline.model`, `roofline.model_frac`), never as `roofline.frac`: a model built from the kernel's own
+    instruction counts moves when the kernel changes.
 
-    slab_kernel (small batches, Q in registers, ccvm_slab.h): no byte of Q moves, the contraction of a member is
-    R C K MACs (a few hundred cycles); a step is one hand-off of the GEMM input between the cluster's workgroups
-    (own publish -> every peer's packets read: MI355X_MICROARCH.md price list, "handoff-1to1" 0.8-1.1 us idle /
-    "allgather" 2.4-2.9 us for 256 CUs) plus the member's matrix time.  bound "latency": peak = steps/s of that
-    floor, achieved = steps/s measured."""
-    import re
+    persist_kernel (row owners, N <= 256): a SIMD issues the instructions of its waves one after the other -- f32 MFMA
+    and VALU do not overlap on a SIMD (tools/coissue.hip) -- so a step cannot take less than the chip's executed vector
+    instructions of a step, spread evenly over the 1024 SIMDs: matrix-pipe busy cycles + 4 cycles per other VALU
+    instruction, both from the committed SQ pass of this workload (no pass, no model).
 
-    pm = re.search(r"persist_kernel<(\d), (true|false), (\d+), (\d+), (\d+), (\d+), (\d+)> grid (\d+) x (?:256|512)", launch)
-    if pm:
-        # Row-owner persistent kernel (N <= 256): a SIMD issues the instructions of its waves' steps one after the other
-        # (f32 MFMA and VALU do not overlap on a SIMD: tools/coissue.hip), so the roof is the ISSUE time of a step on the
-        # fullest SIMD: per wave 16 NCH / KH v_mfma_f32_4x4x1 x 8 cycles + the other vector instructions x 4 cycles,
-        # times the waves that SIMD holds (4 per workgroup over 1024 SIMDs: one, or two with the K split at B = 1000).
-        # The instruction count comes from the committed SQ pass of this workload; without one no roof is claimed.
-        nch, kh, grid = int(pm.group(5)), int(pm.group(7)), int(pm.group(8))
-        prof = profiled_counters(f"{kind}_n{n}_b{b}")
-        if not prof or "valu_per_wave_step" not in prof:
+    slab_kernel (small batches, Q in registers, ccvm_slab.h): no byte of Q moves, the contraction of a member is R C K
+    MACs (a few hundred cycles); a step is one hand-off of the GEMM input between the cluster's workgroups (own publish
+    -> every peer's packets read: MI355X_MICROARCH.md price list, "handoff-1to1" 0.8-1.1 us idle / "allgather" 2.4-2.9
+    us for 256 CUs) plus the member's matrix time."""
+    if "persist_kernel" in launch:
+        prof = profiled_counters(workload)
+        if not prof or "insts_valu_per_step" not in prof:
             return {}
-        waves_per_simd = -(-(8 if int(pm.group(4)) * kh > 4 else 4) * grid // 1024)
-        mfma = 16 * nch / kh * waves_per_simd
-        issue = 8.0 * mfma + 4.0 * (prof["valu_per_wave_step"] * waves_per_simd - mfma)
+        mfma_cycles = prof["mfma_busy_cycles_per_step"] / 1024.0
+        other = 4.0 * (prof["insts_valu_per_step"] - prof["mfma_busy_cycles_per_step"] / 8.0) / 1024.0
+        issue_us = (mfma_cycles + other) / 2400.0
         return {
-            "bound": "issue", "achieved": 1e6 / step_us, "peak": 2400.0e6 / issue, "unit": "steps/s",
-            "frac": issue / 2400.0 / step_us, "frac_wall": issue / 2400.0 / wall_step_us,
-            "issue_cycles_per_step": {"mfma": 8.0 * mfma, "other_valu": 4.0 * (prof["valu_per_wave_step"] * waves_per_simd - mfma),
-                                      "waves_per_simd": waves_per_simd,
-                                      "source": prof["source"] + " (SQ_INSTS_VALU per wave and step, MFMAs included)",
-                                      "clock_MHz": 2400},
-            "mfma_frac": 2.0 * (2 if kind == "dl" else 1) * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "model": {"bound": "issue", "floor_us_per_step": issue_us, "clock_MHz": 2400,
+                      "issue_cycles_per_simd_and_step": {"mfma": mfma_cycles, "other_valu": other},
+                      "source": prof["source"] + " (SQ_VALU_MFMA_BUSY_CYCLES + 4 x the other SQ_INSTS_VALU, chip sums / "
+                                                 "1024 SIMDs: an even spread, i.e. a lower bound of the fullest SIMD)",
+                      "kernel_profiled": prof.get("kernel")},
+            "model_frac": issue_us / step_us, "model_frac_wall": issue_us / wall_step_us,
         }
     m = re.search(r"slab_kernel<\d, (\d+), (\d+), \w+>.*\((\d+) clusters of (\d+) workgroups x (\d+) columns, (\d+) rows each, K = (\d+)(, each over \d+ XCDs)?",
                   launch)
@@ -454,14 +503,11 @@ def family_roof(launch, kind, n, b, step_us, wall_step_us):
     handoff_us = 2.4 if spread else 0.8                         # across the fabric / hand-off inside an XCD
     floor_us = handoff_us + mfma_us
     return {
-        "bound": "latency", "achieved": 1e6 / step_us, "peak": 1e6 / floor_us, "unit": "steps/s",
-        "frac": floor_us / step_us, "frac_wall": floor_us / wall_step_us,
-        "latency_floor_us": {"handoff": handoff_us, "member_mfma": mfma_us,
-                             "source": "MI355X_MICROARCH.md price list: handoff-1to1 0.8 us (one XCD, idle) / "
-                                       "allgather 2.4 us (256 CUs, 8 KB); v_mfma_f32_4x4x1 8 cycles"},
-        "mfma_frac": 2.0 * planes * n * n * b / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "q_bytes_moved_per_step": 0,
-        "exchange_bytes_per_member_per_step": planes * int(rows) * int(k) * 8,
+        "model": {"bound": "latency", "floor_us_per_step": floor_us, "handoff_us": handoff_us, "member_mfma_us": mfma_us,
+                  "source": "MI355X_MICROARCH.md price list: handoff-1to1 0.8 us (one XCD, idle) / allgather 2.4 us "
+                            "(256 CUs, 8 KB); v_mfma_f32_4x4x1 8 cycles",
+                  "q_bytes_moved_per_step": 0, "exchange_bytes_per_member_per_step": planes * int(rows) * int(k) * 8},
+        "model_frac": floor_us / step_us, "model_frac_wall": floor_us / wall_step_us,
     }
 
 
@@ -495,6 +541,9 @@ def main():
                          "[r * ceil(G / N), ...)); BASELINE config 5 at every N = --workload pl_n2000_b512 --post adam "
                          "--global-batch 4096, config 4 = --global-batch 8000.  Default: the workload's batch PER GPU "
                          "(weak scaling)")
+    ap.add_argument("--repeats", type=int, default=REPEATS,
+                    help="timed regions of exactly --steps steps each (every one verified, every one under the barrier + "
+                         "synchronise clock); ms_per_step / value are the MEDIAN region's, ms_per_step_repeats lists all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="torch threads of the cpu_baseline leg")
     args = ap.parse_args()
@@ -534,15 +583,20 @@ def main():
             raise SystemExit(f"--global-batch {args.global_batch} < {world} ranks")
         row0, b = shard_rows(args.global_batch, world, rank)
     global_rows = args.global_batch if args.global_batch is not None else b * world
-    total = args.warmup + args.steps
-    traj, q, v = make_trajectories(kind, n, b, total, rank, row_offset=row0)
+    extras = WORKLOAD_EXTRAS.get(args.workload, {})
+    instance = extras.get("instance")
+    repeats = max(1, args.repeats)
+    # the iterations of the run the steps belong to (its schedule: pump ramp, noise-ratio decay): the steps this
+    # process runs, or the workload's own run length when that is longer (config 1: 15000)
+    total = max(args.warmup + repeats * args.steps, extras.get("total", 0))
+    traj, q, v = make_trajectories(kind, n, b, total, rank, row_offset=row0, instance=instance)
 
     def barrier():  # the default (gloo) group: a rendez-vous of the host processes, never on the device's queue
         if world > 1:
             dist.barrier()
 
     if args.spinup_ms > 0:
-        scratch, _, _ = make_trajectories(kind, n, b, 1 << 20, rank, seed=2, row_offset=row0)
+        scratch, _, _ = make_trajectories(kind, n, b, 1 << 20, rank, seed=2, row_offset=row0, instance=instance)
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
             scratch.advance(256)
@@ -556,22 +610,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item())
 
-    elapsed, stream_ms, attempts = timed_steps(traj, args.warmup, args.steps, dev, barrier, any_rank)
-    gpu_ms_per_step = stream_ms / args.steps  # stream time of the timed region / steps
+    walls, stream_ms_all, attempts = timed_steps(traj, args.warmup, args.steps, dev, barrier, any_rank, repeats)
+    gpu_ms_per_step_all = [ms / args.steps for ms in stream_ms_all]  # stream time of each timed region / steps
+    gpu_ms_per_step = median(gpu_ms_per_step_all)
 
-    per_rank_elapsed = [elapsed]
+    per_rank_walls = [walls]  # [rank][region]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)  # host scalars over the default (gloo) group
+        t = torch.tensor(walls, dtype=torch.float64)  # host scalars over the default (gloo) group
         each = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(each, t)
-        per_rank_elapsed = [float(x.item()) for x in each]
-    elapsed = max(per_rank_elapsed)
+        per_rank_walls = [[float(x) for x in e.tolist()] for e in each]
+    # a region's time for the JOB is the slowest rank's; the line reports the median region
+    job_walls = [max(per_rank_walls[r][i] for r in range(world)) for i in range(repeats)]
+    elapsed = median(job_walls)
+    mid = min(range(repeats), key=lambda i: abs(job_walls[i] - elapsed))  # (the region the per-rank list is quoted from)
+    per_rank_elapsed = [per_rank_walls[r][mid] for r in range(world)]
 
     # the steps right after the loop (device-side finalize: clamp, change of variables, optional
     # post-processor, energy) + the one collective: all-gather of the objective values (RCCL)
-    from ccvm_amd.workloads import scaled_qv
-
-    _, _, f = scaled_qv(n, kind)
+    _, _, f = problem_qv(kind, n, instance)
     pp_seconds = 0.0
     name = "mu_tilde" if kind == "mf" else "c"
     # (DL's final clamp, dl_solver.py:567, inside the finalize: behind score's own verification of the state, never on
@@ -614,12 +671,25 @@ def main():
         metric = "SDE row-steps/s (Euler-Maruyama steps/s x batch)"
         if args.workload == "dl_n1000_b1000":
             metric += ", DL-CCVM N=1000 batch=1000 per GPU"
+        # The hardware roof that binds: by arithmetic intensity against the ridge of the two peaks (157.3 TFLOP/s fp32
+        # MFMA / 8 TB/s HBM = 19.7 flop/B).  `frac` is ALWAYS a fraction of a hardware peak: of the MFMA
+        # peak above the ridge, of the HBM peak below it (N < ~85: the shipped instances); both fractions are in the
+        # line either way (`mfma_frac`, `hbm_frac`), the families' instruction-count / latency models under `model`.
+        hbm_gbs = bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9
+        ai, ridge = flops_per_step / bytes_per_step, PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        wall_scale = gpu_ms_per_step / wall_ms_per_step
+        if ai >= ridge:
+            head = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            head = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS}
         roofline = {
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            # frac: the kernel (HIP events on the launch stream); frac_wall: the same flops over this line's own
+            **head,
+            # frac: the kernel (HIP events on the launch stream); frac_wall: the same over this line's own
             # ms_per_step (host wall clock incl. the two synchronisations and post-idle launches)
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "frac_wall": flops_per_step / (wall_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "frac_wall": head["frac"] * wall_scale,
+            "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+            "mfma_frac": achieved / PEAK_FP32_MFMA_TFLOPS, "mfma_TFLOPs": achieved,
             "traffic": None,  # HBM bytes need separate rocprofv3 --pmc passes: see "profiled"
             "algorithmic_bytes": ((bytes_per_step - 4.0 * n * n) / slices + 4.0 * n * n) * steps_per_launch,
             "algorithmic_flops": flops_per_step * steps_per_launch / slices,
@@ -628,11 +698,12 @@ def main():
             "launches": launches * slices,
             "avg_launch_us": gpu_ms_per_step * 1e3 * steps_per_launch / slices,
             "avg_step_us": gpu_ms_per_step * 1e3,
-            "timing": "HIP events on the launch stream around the timed region / launches in it",
+            "avg_step_us_repeats": [ms * 1e3 for ms in gpu_ms_per_step_all],
+            "timing": "HIP events on the launch stream around each timed region / launches in it; the median region",
             "peak_note": "157.3 TFLOP/s = fp32 MFMA spec (v_mfma_f32_32x32x2_f32); a bare MFMA loop "
-                         "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip)",
-            "hbm_algorithmic_GBps": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9,
-            "hbm_frac": bytes_per_step / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "sustains ~141 TFLOP/s at steady-state clocks on this chip (tools/ablate.hip); 8000 GB/s = HBM3E spec",
+            "hbm_algorithmic_GBps": hbm_gbs,
+            "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
         }
         if launch.startswith("batch cut in two"):
             # two run plans one after the other (rows of whole resident grids + the rest): the line prices the step of
@@ -640,7 +711,7 @@ def main():
             for key in ("algorithmic_bytes", "algorithmic_flops", "steps_per_launch", "launches", "avg_launch_us"):
                 roofline[key] = None
         else:
-            roofline.update(family_roof(launch, kind, n, b, gpu_ms_per_step * 1e3, wall_ms_per_step * 1e3))
+            roofline.update(family_model(launch, kind, n, b, gpu_ms_per_step * 1e3, wall_ms_per_step * 1e3, args.workload))
         out = {
             "metric": metric,
             "value": args.steps * global_rows / elapsed,
@@ -649,6 +720,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall_ms_per_step,
+            "ms_per_step_repeats": [w / args.steps * 1e3 for w in job_walls],
+            "repeats": repeats,
+            "timing": f"{repeats} timed regions of exactly {args.steps} steps each (barrier + device synchronisation on "
+                      "both sides of every one, every one verified); ms_per_step / value = the MEDIAN region (max over "
+                      "ranks per region), ms_per_step_repeats = all of them in order",
             "ms_per_step_per_rank": [e / args.steps * 1e3 for e in per_rank_elapsed],
             "higher_is_better": True,
             "scaling": "strong" if args.global_batch is not None else "weak",
@@ -661,6 +737,7 @@ def main():
                 "workload": f"{args.workload}: {kind.upper()} solver, N={n} dense symmetric BoxQP, "
                             + (f"global batch {global_rows} split over {world} GPU ({b} rows on rank 0), "
                                if args.global_batch is not None else f"batch {b} per GPU x {world} GPU, ")
+                            + (f"shipped instance {instance} (tests/golden fixture), " if instance else "")
                             + f"fp32 state, fused Threefry noise, schedule of a {total}-step run"
                             + (f", {args.post} post-processor on device after the loop" if args.post else ""),
                 "global_batch": global_rows,
@@ -687,7 +764,7 @@ def main():
         if world == 1 and args.workload == "dl_n1000_b1000":
             out["tts99"] = tts99_leg()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, n, b, total, threads=args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(kind, n, b, total, threads=args.cpu_threads, instance=instance)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

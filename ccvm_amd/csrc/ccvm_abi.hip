@@ -112,6 +112,7 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 //   CCVM_AMD_XCD=0            linear block -> tile map instead of the XCD rectangles
 //   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
 //   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
+//   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
 constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
 
 struct Tuning {
@@ -122,6 +123,7 @@ struct Tuning {
     int xcd_xc = 0;      // 0: choose by L2 footprint
     int persist_ru = 0;  // 0: choose by batch size
     int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
+    int persist_pw = 0;  // noise producer waves of the row-owner kernel: 1 off, 2 on, 0: by shape and batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     int cluster_sets = 0;  // CCVM_AMD_CLUSTER_SETS=2|3 (tuning): that many row sets per cluster above K = 512; 0: cluster_sets()
     int cluster_half = 1;  // 0 (CCVM_AMD_CLUSTER_HALF=0, tuning): the full-chunk cluster kernel also where N mod 128 is in 1 .. 64
@@ -165,6 +167,8 @@ Tuning read_tuning() {
         if (e[0] == '2' || e[0] == '4') t.persist_ru = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_KH"))
         if (e[0] == '1' || e[0] == '2') t.persist_kh = e[0] - '0';
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_PW"))
+        if (e[0] == '0' || e[0] == '1') t.persist_pw = e[0] - '0' + 1;
     // CCVM_AMD_FAULT=cluster_drop: the cluster path launches without its last 8 workgroups, so the last member of
     // up to 8 clusters never runs and their peers' bounded waits must give up (status word, ~1 s): the error path
     // of tests/test_gpu_cluster.py -- never set in production
@@ -1017,10 +1021,14 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         return CCVM_OK;
     }
     if (want_persist(N, tun)) {
-        const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus);
-        std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d> grid %d x %d threads, up to %d steps per launch",
-                      solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid,
-                      sh.ncg * sh.kh > 4 ? 512 : 256, TABLE_STEPS);
+        const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus,
+                                              tun.persist_pw);
+        if (sh.pw)
+            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 1> grid %d x %d threads (noise producer waves), up to %d steps per launch",
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
+        else
+            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d> grid %d x %d threads, up to %d steps per launch",
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
     } else {
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, solver);
@@ -1134,6 +1142,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.B = B; pa.N = N; pa.ld = ld; pa.wld = (int)noise_pitch(nz, B); pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
+        pa.pw_override = tun.persist_pw;
         pa.simds = 4 * chip_of(tun).cus;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
@@ -1419,6 +1428,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.S = (float)S_eff;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
+        pa.pw_override = tun.persist_pw;
         pa.simds = 4 * chip_of(tun).cus;
         pa.s_cols = s_cols;
         AdamSched asc;
@@ -1742,6 +1752,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         pa.B = B; pa.N = N; pa.ld = ld; pa.wld = (int)noise_pitch(nz, B); pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
+        pa.pw_override = tun.persist_pw;
         pa.simds = 4 * chip_of(tun).cus;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);

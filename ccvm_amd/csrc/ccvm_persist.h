@@ -71,13 +71,16 @@ struct PersistArgs {
     int ru_override;     // host only: 2 / 4 forces the rows in use per group (tuning), 0 = by batch size
     int kh_override;     // host only: 1 / 2 forces the K split off / on (tuning), 0 = by batch size
     int simds;           // host only: SIMDs of the chip the shape is planned for (4 per CU; 0 = 1024)
+    int pw_override;     // host only: 1 / 2 forces the noise producer waves off / on (tuning), 0 = by shape and batch size
     AdamConsts ad;
+    unsigned long long* dbg;  // tools/persist_ablate.hip, CCVM_PERSIST_ABL & 16: s_memtime sums, [grid][16]
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // Ablation bits for tools/persist_ablate.hip (0 in the product): 1 no MFMA, 2 no noise, 4 no update
-// arithmetic, 8 no barrier / LDS round trip.
+// arithmetic, 8 no barrier / LDS round trip, 16 s_memtime stamps of the step's segments (consumer wave 0 and
+// producer wave 0 of every workgroup, summed over the launch into PersistArgs::dbg).
 #ifndef CCVM_PERSIST_ABL
 #define CCVM_PERSIST_ABL 0
 #endif
@@ -119,10 +122,29 @@ __device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf
 #ifndef CCVM_PERSIST_KTAIL
 #define CCVM_PERSIST_KTAIL 0   // measured: DL N = 100 0.967 / 0.980 us per step without, 0.978 / 0.956 with -- no gain, off
 #endif
+// ... but for ONE-wave row sets (N <= 64) the step is a single wave's serial chain, and every MFMA left out is 10 cycles
+// off it (N = 20: 20 instead of 32 per step): on by default there (round 6)
+#ifndef CCVM_PERSIST_KTAIL1
+#define CCVM_PERSIST_KTAIL1 1
+#endif
 
-template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1>
-__global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_kernel(const PersistArgs a) {
+__device__ __forceinline__ unsigned long long persist_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// PW = 1 (round 6): NOISE PRODUCER waves.  The normals of step t + 1 do not depend on the state, and below N = 64 (one
+// wave per row set) a batch of 1000 leaves half of the chip's SIMDs without a wave while every wave issues ONE serial
+// chain per step -- LDS read -> MFMAs -> generator (~65 dependent VALU instructions) -> update -> LDS write.  With PW a
+// workgroup holds as many producer waves as consumer waves: producer p has consumer p's lane -> element map, makes the
+// noise set of the NEXT step (the same generator calls: bit-identical results) into a double-buffered LDS slot and
+// meets the consumers at ONE workgroup barrier per step; the consumer's chain loses the generator (and, in replay
+// mode, the global loads of the noise blocks).
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0>
+__global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW) : 256) void persist_kernel(const PersistArgs a) {
     static_assert(KH == 1 || (KH == 2 && (NCG == 2 || NCG == 4) && RU == 4), "K split: waves side by side, all four rows in use");
+    static_assert(PW == 0 || (PW == 1 && NCG * KH <= 4), "producer waves: at most eight waves per workgroup");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
     static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || ((NCG == 2 || NCG == 4) && CW == 64)), "shape");
@@ -143,13 +165,25 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
     // (N > 64) or four one-wave sets.  Smaller workgroups landed unevenly on the SIMDs (DL N=100:
     // 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with two of these waves takes twice as
     // long.  The sets of a workgroup share nothing (N > 64: but the barrier).
-    constexpr int RSW = (NCG * KH > 4) ? 1 : 4 / (NCG * KH);  // (four waves side by side x two K halves: eight waves)
+    constexpr int WPS = NCG * KH * (1 + PW);                   // waves per row set, producers included
+    constexpr int RSW = (WPS > 4) ? 1 : 4 / WPS;               // (four waves side by side x two K halves: eight waves)
+    constexpr int NWC = RSW * NCG * KH;                        // consumer waves per workgroup
     constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums
-    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF];
+    constexpr int NV = ((MODE == MODE_DL) ? 2 : 1) * NE;       // normals per lane and step
+    constexpr int NZF = PW ? 2 * NWC * NV * 64 : 0;            // producer waves: [step parity][consumer][value][lane]
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF + NZF];
     float* const px = xs_all + RSW * 2 * ROWS * LDX;
+    float* const nzl = px + PXF;
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Four-wave workgroups put consumers and producers on DIFFERENT SIMDs (wave w -> SIMD w mod 4), and a chip-filling
+    // grid runs two workgroups per CU: the second round of workgroups swaps the roles' wave slots, so a SIMD holds one
+    // consumer and one producer instead of two consumers (DL N = 100, B = 1000, whole chains: 1.055 us per step without
+    // the swap).  Which CU a workgroup lands on is the dispatcher's business: a wrong guess costs time, nothing else.
+    const bool swap_roles = PW && WPS <= 4 && ((blockIdx.x / (a.simds > 0 ? a.simds / 4 : 256)) & 1);
+    const bool producer = PW && ((wave_all >= NWC) != swap_roles);  // (wave-uniform)
+    const int wave = (PW && wave_all >= NWC) ? wave_all - NWC : wave_all;  // a producer has its consumer's index and element map
     const int cg = wave % NCG;
     const int kh = (KH == 2) ? wave / NCG : 0;  // K half (wave-uniform)
     float* const xs = xs_all + (wave / (NCG * KH)) * (2 * ROWS * LDX);
@@ -167,7 +201,11 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
     const int koff = kh * KSPLIT;
     float qf[KQ];
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+    for (int k = 0; k < KQ; ++k) qf[k] = 0.0f;
+    if (!producer) {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+    }
     const float vj = col_ok ? a.V[col] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[col];  // shift * colsum(Q)[j]
     const float sat_j = (a.s_cols && col_ok) ? a.s_cols[col] : 1.0f;  // per-variable saturation
@@ -188,13 +226,16 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
     float mt[NE], wc[NE];   // MF: measured amplitude (GEMM input) and the normals that made it
     float am[NE], av[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        s0[e] = a.x0[gidx[e]];
-        s1[e] = (MODE == MODE_LANGEVIN) ? 0.0f : a.x1[gidx[e]];
-        mt[e] = wc[e] = am[e] = av[e] = 0.0f;
-        if constexpr (ADAM) {
-            am[e] = a.am[gidx[e]];
-            av[e] = a.ad.use_v ? a.av[gidx[e]] : 0.0f;
+    for (int e = 0; e < NE; ++e) s0[e] = s1[e] = mt[e] = wc[e] = am[e] = av[e] = 0.0f;
+    if (!producer) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            s0[e] = a.x0[gidx[e]];
+            s1[e] = (MODE == MODE_LANGEVIN) ? 0.0f : a.x1[gidx[e]];
+            if constexpr (ADAM) {
+                am[e] = a.am[gidx[e]];
+                av[e] = a.ad.use_v ? a.av[gidx[e]] : 0.0f;
+            }
         }
     }
 
@@ -215,6 +256,87 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
             }
         }
     };
+
+    // the noise set a step consumes -- DL: (W_c, W_s) per element; MF: the NEXT step's normals; Langevin: this step's
+    auto gen_noise = [&](int step, int it, float* nz0, float* nz1) {
+        if constexpr (MODE == MODE_DL) {
+            if (a.replay) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const size_t w = ((size_t)it * N + col) * a.wld + brow[e];
+                    nz0[e] = ok[e] ? a.w0[w] : 0.0f;
+                    nz1[e] = ok[e] ? a.w1[w] : 0.0f;
+                }
+            } else {
+                if constexpr (CCVM_PERSIST_ABL & 2) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.25f;
+                } else if constexpr (NE == 2) {  // two generator calls in lockstep
+                    NormalPair pa, pb;
+                    normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
+                    nz0[0] = pa.n0; nz1[0] = pa.n1; nz0[1] = pb.n0; nz1[1] = pb.n1;
+                } else {
+                    const NormalPair p = normal_pair(a.seed, a.row_offset + brow[0], step, col);
+                    nz0[0] = p.n0;
+                    nz1[0] = p.n1;
+                }
+            }
+        } else if constexpr (MODE == MODE_MF) {
+            if (it + 1 < a.nsteps) stream_normals(step + 1, it + 1, nz0);  // (the launch's last step draws none)
+        } else {
+            stream_normals(step, it, nz0);
+        }
+    };
+
+    // ---- producer waves: the noise set of step it + 1 while the consumers run step it ------------------------------
+    // slot (parity of it, consumer wave): NV values per lane.  The consumers read slot it & 1 during step it and pass the
+    // step's last barrier only after the update that consumed it, so the write of step it + 2's set behind that barrier
+    // cannot overtake a read; a producer executes exactly the consumers' barriers (one per step, two with the K split).
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;  // (ablation stamps)
+    auto stamp = [&](int k) {
+        if constexpr (CCVM_PERSIST_ABL & 16) {
+            const unsigned long long t = persist_stamp();
+            st_sum[k] += t - st_last;
+            st_last = t;
+        }
+    };
+    auto stamps_out = [&](int base) {
+        if constexpr (CCVM_PERSIST_ABL & 16) {
+            if (wave == 0 && lane == 0 && a.dbg)
+                for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 16 + base + k] = st_sum[k];
+        }
+    };
+    if constexpr (PW) {
+        if (producer) {
+            float o0[NE], o1[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) o0[e] = o1[e] = 0.0f;
+            auto put = [&](int parity) {
+                float* d = nzl + (parity * NWC + wave) * (NV * 64) + lane;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    d[e * 64] = o0[e];
+                    if constexpr (MODE == MODE_DL) d[(NE + e) * 64] = o1[e];
+                }
+            };
+            gen_noise(a.step0, 0, o0, o1);
+            put(0);
+            __syncthreads();
+            if constexpr (CCVM_PERSIST_ABL & 16) st_last = persist_stamp();
+            for (int it = 0; it < a.nsteps; ++it) {
+                if (it + 1 < a.nsteps) {
+                    gen_noise(a.step0 + it + 1, it + 1, o0, o1);
+                    put((it + 1) & 1);
+                }
+                stamp(0);
+                if constexpr (KH == 2) __syncthreads();
+                __syncthreads();
+                stamp(1);
+            }
+            stamps_out(8);
+            return;
+        }
+    }
 
     // ---- GEMM input of the first step into LDS buffer 0 ----------------------------------------
     if constexpr (MODE == MODE_MF) {
@@ -239,7 +361,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
         }
     };
     publish(xs);
-    if constexpr (NCG > 1) __syncthreads();
+    if constexpr (NCG > 1 || PW) __syncthreads();
 
     const int arow = rs * RU + (i4 < RU ? i4 : 0);  // rows >= RU of a group are unused: any finite row
     int cur = 0;
@@ -271,51 +393,38 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
         float af[16 * NCH / KC];
 #pragma unroll
         for (int c = K0 / KC; c <= (K1 - 1) / KC; ++c) af[c] = xb[c * KC];
+        float nzp[PW ? NV : 1];  // producer waves: this step's noise set comes out of its LDS slot with the A operands
+        if constexpr (PW) {
+            const float* nzr = nzl + ((it & 1) * NWC + wave) * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) nzp[v] = nzr[v * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);  // all reads in flight before anything else (one latency, not NCH)
+        stamp(0);
         // ---- this step's normals -- DL: (W_c, W_s) per element; MF: the NEXT step's; Langevin: this step's.
         // One-wave row sets make them HERE, while the A reads are in flight (they do not depend on them:
         // DL N=20 0.53 -> 0.46 us/step, N=64 0.63 -> 0.56); with two or four waves side by side the same
         // order was 3-12 % slower (same-box A/B), so those make them after the contraction.
-        constexpr bool NOISE_FIRST = (NCG == 1);
+        constexpr bool NOISE_FIRST = (NCG == 1) && !PW;
         // waves side by side: the NEXT step's normals are made between this step's LDS publish and its barrier (below),
         // where the faster wave of a row set would only wait; nzn0 / nzn1 carry them over
-        constexpr bool NOISE_AHEAD = CCVM_PERSIST_NOISE_AHEAD && NCG > 1 && MODE != MODE_MF;
+        constexpr bool NOISE_AHEAD = CCVM_PERSIST_NOISE_AHEAD && NCG > 1 && MODE != MODE_MF && !PW;
         float nz0[NE], nz1[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.0f;
-        auto make_step_noise = [&](int step, int it) {
-            if constexpr (MODE == MODE_DL) {
-                if (a.replay) {
-    #pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        const size_t w = ((size_t)it * N + col) * a.wld + brow[e];
-                        nz0[e] = ok[e] ? a.w0[w] : 0.0f;
-                        nz1[e] = ok[e] ? a.w1[w] : 0.0f;
-                    }
-                } else {
-                    if constexpr (CCVM_PERSIST_ABL & 2) {
-    #pragma unroll
-                        for (int e = 0; e < NE; ++e) nz0[e] = nz1[e] = 0.25f;
-                    } else if constexpr (NE == 2) {  // two generator calls in lockstep
-                        NormalPair pa, pb;
-                        normal_pair_x2(a.seed, a.row_offset + brow[0], a.row_offset + brow[1], step, col, pa, pb);
-                        nz0[0] = pa.n0; nz1[0] = pa.n1; nz0[1] = pb.n0; nz1[1] = pb.n1;
-                    } else {
-                        const NormalPair p = normal_pair(a.seed, a.row_offset + brow[0], step, col);
-                        nz0[0] = p.n0;
-                        nz1[0] = p.n1;
-                    }
-                }
-            } else if constexpr (MODE == MODE_MF) {
-                if (it + 1 < a.nsteps) stream_normals(step + 1, it + 1, nz0);  // (the launch's last step draws none)
-            } else {
-                stream_normals(step, it, nz0);
-            }
-        };
+        auto make_step_noise = [&](int step, int it) { gen_noise(step, it, nz0, nz1); };
         if constexpr (NOISE_FIRST) make_step_noise(step, it);
+        if constexpr (PW) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                nz0[e] = nzp[e];
+                if constexpr (MODE == MODE_DL) nz1[e] = nzp[NE + e];
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        stamp(1);
         if constexpr (!(CCVM_PERSIST_ABL & 1)) {
-            if constexpr (CCVM_PERSIST_KTAIL) {
+            if constexpr (CCVM_PERSIST_KTAIL || (CCVM_PERSIST_KTAIL1 && NCG == 1)) {
                 constexpr int FULL = 16 * (NCH - 1);
                 mfma_chain<CBSZ, KC>(af, qf, acc, std::make_integer_sequence<int, FULL + 4>{});
                 const int rem = N - FULL;  // 1 .. 16 k-steps of the last chunk are real
@@ -342,6 +451,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
             px[((H * NCG + cg) * 2 + 0) * 64 + lane] = part[2 * (1 - H)];
             px[((H * NCG + cg) * 2 + 1) * 64 + lane] = part[2 * (1 - H) + 1];
         }
+        stamp(2);  // (the partial sums above wait for the MFMAs)
         if constexpr (NOISE_AHEAD) {
             if (it == 0) {
                 make_step_noise(step, it);
@@ -349,14 +459,16 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
 #pragma unroll
                 for (int e = 0; e < NE; ++e) { nz0[e] = nzn0[e]; nz1[e] = nzn1[e]; }
             }
-        } else if constexpr (!NOISE_FIRST) {
+        } else if constexpr (!NOISE_FIRST && !PW) {
             make_step_noise(step, it);
         }
+        stamp(3);
         float qx[4];
         if constexpr (KH == 2) {
             // the halves swap partial sums: this wave finishes rows 2 H, 2 H + 1 (its NE elements) and hands the other
             // two to its twin; sum = (half 0) + (half 1)
             __syncthreads();
+            stamp(4);
             const float o0 = px[(((1 - H) * NCG + cg) * 2 + 0) * 64 + lane], o1 = px[(((1 - H) * NCG + cg) * 2 + 1) * 64 + lane];
             const float t0 = (H == 0) ? part[0] + o0 : o0 + part[2], t1 = (H == 0) ? part[1] + o1 : o1 + part[3];
             qx[0] = __builtin_fmaf(a.in_scale, t0, shift_j);
@@ -432,6 +544,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
         }
         if constexpr (!(CCVM_PERSIST_ABL & 8)) {
             cur ^= 1;
+            stamp(5);
             publish(xs + cur * ROWS * LDX);
             if constexpr (NOISE_AHEAD) {
                 if (it + 1 < a.nsteps) {
@@ -441,10 +554,13 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
                 }
             }
             // one-wave sets: a wave's LDS instructions execute in order, its reads see its own writes
-            if constexpr (NCG > 1) __syncthreads();
+            stamp(6);
+            if constexpr (NCG > 1 || PW) __syncthreads();
+            stamp(7);
         }
     }
     };  // run_steps
+    if constexpr (CCVM_PERSIST_ABL & 16) st_last = persist_stamp();
     if constexpr (KH == 2) {
         if (kh == 0) run_steps(std::integral_constant<int, 0>{});
         else run_steps(std::integral_constant<int, 1>{});
@@ -452,6 +568,7 @@ __global__ __launch_bounds__((NCG * KH > 4) ? 64 * NCG * KH : 256) void persist_
         run_steps(std::integral_constant<int, 0>{});
     }
 
+    stamps_out(0);
     // ---- write the state back -----------------------------------------------------------------
 #pragma unroll
     for (int e = 0; e < NE; ++e) {

@@ -19,11 +19,14 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 // The launch shape of the persistent kernel for (solver, B, N): ONE definition, used by the launcher below and
 // by ccvm_describe_launch (so that the name a benchmark line reports is the instantiation that runs).
 struct PersistShape {
-    int cw, ncg, nch, ru, grid, kh;
+    int cw, ncg, nch, ru, grid, kh, pw, threads;
 };
+constexpr int PERSIST_PW_MAX_NCG = 2;  // noise producer waves are instantiated for one and two waves side by side
 // kh_override: 1 / 2 forces the K split off / on (where the shape has one), 0 = by batch size
 // solver: 0 DL, 1 MF, 2 Langevin / pumped Langevin (the C ABI's numbering)
-inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_override, int kh_override = 0, int simds = 1024) {
+// pw_override: 1 / 2 forces the noise producer waves off / on (where the shape has them), 0 = by shape and batch size
+inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_override, int kh_override = 0, int simds = 1024,
+                                  int pw_override = 0) {
     const bool dl = solver == 0;
     if (simds <= 0) simds = 1024;
     PersistShape s;
@@ -58,9 +61,26 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         if (kh_override == 2) s.kh = 2;
         if (s.kh == 2) s.ru = 4;
     }
-    const int sets = s.ncg * s.kh > 4 ? 1 : 4 / (s.ncg * s.kh);      // row sets per workgroup
+    // Noise producer waves (ccvm_persist.h, PW): one-wave row sets whose consumers AND producers all find a SIMD of
+    // their own -- the chain of a step loses the generator.  (policy: tools/time_small.py A/B, round 6)
+    s.pw = 0;
+    if (s.ncg == 1) {
+        const int consumers = (B + br4 * s.ru / 4 - 1) / (br4 * s.ru / 4);
+        if (consumers <= simds) s.pw = 1;  // (up to one consumer and one producer per SIMD)
+    } else if (s.ncg == 2 && s.kh == 2) {
+        const int consumers = ((B + br4 - 1) / br4) * s.ncg * 2;  // half-chain waves
+        if (consumers <= 2 * simds) s.pw = 1;
+    }
+    if (pw_override == 1) s.pw = 0;
+    // (two waves side by side: producers only next to the K split -- with whole chains the consumers and producers of a
+    // four-wave workgroup sit on different SIMDs and two such workgroups per CU cost more than they save: DL N = 100,
+    // B = 1000 1.06 us per step against 0.93 without, role swap or not)
+    if (pw_override == 2 && (s.ncg == 1 || (s.ncg == 2 && s.kh == 2))) s.pw = 1;
+    const int wps = s.ncg * s.kh * (1 + s.pw);                       // waves per row set
+    const int sets = wps > 4 ? 1 : 4 / wps;                          // row sets per workgroup
     const int per = br4 * s.ru / 4 * sets;                           // batch rows per workgroup
     s.grid = (B + per - 1) / per;
+    s.threads = wps > 4 ? 64 * wps : 256;
     return s;
 }
 
@@ -70,12 +90,24 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
     const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, ADAM, a.B, a.N, a.ru_override,
-                                          a.kh_override, a.simds);  // sh.cw == CW etc. by construction
-    const dim3 block(256);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
+                                          a.kh_override, a.simds, a.pw_override);  // sh.cw == CW etc. by construction
+    const dim3 block(sh.threads);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
+    if constexpr (NCG <= PERSIST_PW_MAX_NCG) {
+        if (sh.pw) {  // as many producer waves as consumer waves
+            if constexpr (NCG >= 2) {  // (next to the K split only: persist_shape)
+                hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 1>), dim3(sh.grid), block, 0, st, a);
+            } else {
+                if (sh.ru == 4)
+                    hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 1, 1>), dim3(sh.grid), block, 0, st, a);
+                else
+                    hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2, 1, 1>), dim3(sh.grid), block, 0, st, a);
+            }
+            return;
+        }
+    }
     if constexpr (NCG >= 2) {
         if (sh.kh == 2) {  // one row set of NCG x 2 waves
-            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), dim3(NCG == 4 ? 512 : 256), 0,
-                               st, a);
+            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), block, 0, st, a);
             return;
         }
     }

@@ -662,7 +662,12 @@ class Trajectories:
             if not hold:
                 self._snap = None  # verified: the next run call snapshots anew
             return False
-        snap, self._snap = self._snap, None
+        snap = self._snap
+        if not hold:
+            self._snap = None
+        # (hold: the snapshot outlives the recovery too -- the step counter is back at it, the policy is now
+        # no_exchange, so advance() never re-arms, and a caller that repeats verified steps, bench.py's ranks when
+        # ANOTHER rank times out in a later attempt, still needs something to roll back to: ADVICE r5)
         if snap is None:
             raise _lib.EngineError(
                 f"ccvm_{self.kind}_run: a persistent kernel whose workgroups wait for each other (column-cluster, "

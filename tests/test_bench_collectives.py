@@ -126,8 +126,8 @@ def test_an_invalid_run_starts_over(monkeypatch):
     barriers = []
     # the first attempt's steps (warm-up or timed: one status word) are invalid
     traj = _FakeTraj(invalid_checks=[True])
-    elapsed, stream_ms, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
-    assert attempts == 2 and stream_ms == 1.25 and elapsed >= 0
+    walls, stream_ms, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1))
+    assert attempts == 2 and stream_ms == [1.25] and len(walls) == 1 and walls[0] >= 0
     assert traj.calls == [(0, 5), (5, 20), (0, 5), (5, 20)]  # warm-up and timed steps again, from the snapshot
     assert traj.step == 25 and len(barriers) == 2  # one opening barrier per timed region
 
@@ -141,3 +141,93 @@ def test_an_invalid_run_starts_over(monkeypatch):
     traj = _FakeTraj(invalid_checks=[True, True, True])
     with pytest.raises(SystemExit):
         bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None)
+
+
+def test_repeated_timed_regions(monkeypatch):
+    """R regions of exactly K steps, each behind its own barrier and verified; a region that turns out invalid sends
+    the whole sequence (warm-up included) back to the snapshot."""
+    import bench
+
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda dev=None: None)
+    barriers = []
+    traj = _FakeTraj(invalid_checks=[])
+    walls, stream_ms, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: barriers.append(1), repeats=9)
+    assert attempts == 1 and len(walls) == 9 and stream_ms == [1.25] * 9 and len(barriers) == 9
+    assert traj.calls == [(0, 5)] + [(5 + 20 * i, 20) for i in range(9)] and traj.step == 185
+    # the third region of the first attempt is invalid
+    traj = _FakeTraj(invalid_checks=[False, False, True])
+    walls, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None, repeats=4)
+    assert attempts == 2 and len(walls) == 4
+    assert traj.calls == [(0, 5), (5, 20), (25, 20), (45, 20), (0, 5), (5, 20), (25, 20), (45, 20), (65, 20)]
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 3.0, 2.0]) == 2.5
+
+
+class _StubEngineTraj:
+    """The state Trajectories.check / rollback / arm work on, without a GPU: a status word on the host, a snapshot that
+    is just the step counter."""
+
+    kind = "dl"
+    fallbacks = 0
+    no_exchange = False
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.step = 0
+        self._snap = None
+        self._status = torch.zeros(1, dtype=torch.int32)
+        self.restored = []
+
+    def _exchange_kernel(self):
+        return True
+
+    def _snapshot(self):
+        return {"step": self.step}
+
+    def _restore(self, snap):
+        self.restored.append(snap["step"])
+        self.step = snap["step"]
+
+    def advance(self, n):
+        # (what engine.Trajectories.advance does around a run call: re-arm unless the run is off the exchange kernels)
+        from ccvm_amd import engine
+
+        engine.Trajectories.arm(self)
+        self.step += n
+
+
+def test_recoveries_on_different_ranks_in_successive_attempts(monkeypatch):
+    """a rank that recovered a time-out in attempt 1 (no_exchange from then on: advance never re-arms) must
+    still be able to roll back when ANOTHER rank times out in attempt 2 -- check(hold=True) keeps the snapshot on the
+    recovery path as well."""
+    import contextlib
+    import warnings
+
+    import bench
+    from ccvm_amd import engine
+
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda dev=None: None)
+    monkeypatch.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(engine, "_exchange_blocked_until", {})
+    traj = _StubEngineTraj()
+    for name in ("arm", "rollback", "check"):
+        setattr(traj, name, getattr(engine.Trajectories, name).__get__(traj))
+    fail_next = [True]   # this rank's first timed region times out
+
+    real_advance = traj.advance
+
+    def advance(n):
+        real_advance(n)
+        if n == 20 and fail_next and fail_next.pop(0):
+            traj._status.fill_(1)
+
+    traj.advance = advance
+    other_rank = iter([True, False])  # (asked when this rank's steps were valid) attempt 2: the OTHER rank times out; attempt 3: clean
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        walls, _, attempts = bench.timed_steps(traj, 5, 20, torch.device("cpu"), lambda: None,
+                                               any_rank=lambda flag: flag or next(other_rank))
+    assert attempts == 3 and len(walls) == 1
+    assert traj.restored == [0, 0]       # recovery in attempt 1, roll-back with the other rank in attempt 2
+    assert traj.no_exchange and traj.fallbacks == 1 and traj.step == 25 and traj._snap is None

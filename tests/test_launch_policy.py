@@ -175,7 +175,7 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
     assert not bad, bad
     regs = {}
     for k in ks:
-        m = re.search(r"persist_kernel<(\d), (true|false), 64, 4, (\d+), 4, 1>", k["name"])
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, 4, (\d+), 4, 1, 0>", k["name"])
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")

@@ -24,6 +24,12 @@ ROWS = [
     ("mf_n500_b1000", "config 3", "16 N + 4 N²/B"),
     ("langevin_n500_b1000", "config 3", "8 N + 4 N²/B"),
     ("dl_n100_b1000", "config 2", "16 N + 4 N²/B"),
+    ("dl_n20_b100", "**config 1** exactly: `test020-100-10`, batch 100, inside the schedule of a 15000-iteration run", "16 N + 4 N²/B"),
+    ("dl_n20_b1000", "the shipped example (`examples/ccvm_boxqp_dl.py:12-24`: `tuningH020-100-0`, batch 1000)", "16 N + 4 N²/B"),
+    ("mf_n20_b1000", "the same instance, MF (`examples/ccvm_boxqp_mf.py`)", "16 N + 4 N²/B"),
+    ("langevin_n20_b1000", "the same instance, Langevin (`examples/langevin_boxqp.py`)", "8 N + 4 N²/B"),
+    ("pl_n20_b1000", "the same instance, pumped Langevin (`examples/pumped_langevin_boxqp.py`)", "8 N + 4 N²/B"),
+    ("dl_n70_b1000", "the largest shipped size (synthetic N = 70)", "16 N + 4 N²/B"),
     ("dl_n1000_b2000", "config 4 per GPU on 4 GPUs (strong scaling)", "16 N + 4 N²/B"),
     ("dl_n1000_b4000", "config 4 per GPU on 2 GPUs", "16 N + 4 N²/B"),
     ("pl_n2000_b1024", "config 5 per GPU on 4 GPUs", "8 N + 4 N²/B"),
@@ -75,8 +81,8 @@ def short_kernel(k):
 
 
 def roofline_block():
-    out = ["| workload (`python bench.py --workload …`) | what | kernel | µs/step (HIP events) | row-steps/s | bound | achieved / peak | frac (kernel) | frac (wall) | matrix pipe busy | HBM-side bytes per step (PMC) vs algorithmic | source |",
-           "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    out = ["| workload (`python bench.py --workload …`) | what | kernel | µs/step (HIP events) | row-steps/s | hardware roof | achieved / peak | frac (kernel) | frac (wall) | model: bound, frac | matrix pipe busy | HBM-side bytes per step (PMC) vs algorithmic | source |",
+           "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for workload, what, _ in ROWS:
         d, src = bench_line(workload)
         if d is None:
@@ -97,9 +103,10 @@ def roofline_block():
                 traffic = "%.1f MB" % (per_step / 1e6) + (" vs %.1f MB" % (alg / spl / 1e6) if alg else "")
             src = f"{src}, {csrc}"
         unit = r["unit"]
+        model = f"{r['model']['bound']} {r['model_frac']:.2f}" if "model" in r else ""
         ach = f"{r['achieved']:.1f} / {r['peak']:.1f} {unit}" if unit == "TFLOP/s" else f"{r['achieved']:.3g} / {r['peak']:.3g} {unit}"
         out.append(f"| `{workload.split('@')[0].replace('_adam', '')}` | {what} | {short_kernel(r['kernel'])} | {r['avg_step_us']:.2f} | "
-                   f"{d['value']:.3e} | {r['bound']} | {ach} | {r['frac']:.3f} | {r.get('frac_wall', float('nan')):.3f} | {busy} | "
+                   f"{d['value']:.3e} | {r['bound']} | {ach} | {r['frac']:.3f} | {r.get('frac_wall', float('nan')):.3f} | {model} | {busy} | "
                    f"{traffic} | `{src}` |")
     return "\n".join(out)
 
