@@ -389,7 +389,11 @@ def cpu_baseline(kind, n, b, total_steps, budget_s=30.0, threads=None, instance=
     from oracle import ccvm_oracle as oracle
 
     visible = len(os.sched_getaffinity(0))
-    torch.set_num_threads(max(1, threads or min(16, visible)))
+    # profiles/r06_cpu_thread_sweep.md (refreshed on this round's box): 16 threads are the CPU path's best from N = 500
+    # (12.7 ms per step at the headline; 32 threads 22 ms), ONE thread below N ~ 200 (N = 20: 0.29 ms against 0.40 on 16;
+    # N = 100: 1.25 against 1.75) -- the einsum of a small problem does not amortise a thread team
+    default_threads = min(16, visible) if float(b) * n * n >= 1.0e8 else 1
+    torch.set_num_threads(max(1, threads or default_threads))
     q, v, _ = problem_qv(kind, n, instance)
     p = workload_params(kind)
     torch.manual_seed(1)
@@ -568,6 +572,9 @@ def main():
     if share_mode in ("1", "try-rccl"):
         local = 0
         os.environ["LOCAL_RANK"] = "0"
+        # several processes on ONE GPU: a rank's resident grid waits for the other ranks' whole launches, not for a step --
+        # the 5 ms bound of a cross-workgroup wait (ccvm_abi.hip: spin_ticks) is for a GPU of one's own
+        os.environ.setdefault("CCVM_AMD_SPIN_MS", "2000")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     coll = {"group": None, "device": dev, "collective": "single rank"}

@@ -113,6 +113,8 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 //   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
 //   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
 //   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
+//   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 5 ms or 50
+//                             estimated steps; rehearsals that put several processes on ONE GPU raise it)
 constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
 
 struct Tuning {
@@ -125,6 +127,7 @@ struct Tuning {
     int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
     int persist_pw = 0;  // noise producer waves of the row-owner kernel: 1 off, 2 on, 0: by shape and batch size
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
+    double spin_ms = 0.0;  // CCVM_AMD_SPIN_MS: > 0 replaces the bound of the cross-workgroup waits
     int cluster_sets = 0;  // CCVM_AMD_CLUSTER_SETS=2|3 (tuning): that many row sets per cluster above K = 512; 0: cluster_sets()
     int cluster_half = 1;  // 0 (CCVM_AMD_CLUSTER_HALF=0, tuning): the full-chunk cluster kernel also where N mod 128 is in 1 .. 64
     int slab = CLUSTER_DEFAULT;  // column-slab small-batch kernel: 1 wherever it applies, 0 never, -1: see want_slab
@@ -173,7 +176,22 @@ Tuning read_tuning() {
     // up to 8 clusters never runs and their peers' bounded waits must give up (status word, ~1 s): the error path
     // of tests/test_gpu_cluster.py -- never set in production
     if (const char* e = std::getenv("CCVM_AMD_FAULT")) t.cluster_drop = !std::strcmp(e, "cluster_drop") ? 8 : 0;
+    if (const char* e = std::getenv("CCVM_AMD_SPIN_MS")) t.spin_ms = std::atof(e);
     return t;
+}
+
+// How long a wave of a persistent exchange kernel polls for another workgroup's data before it gives up (status word ->
+// the engine repeats the steps on the per-step kernel), in ticks of the 100 MHz reference clock the kernels read on
+// their slow path (s_memrealtime; a COUNT of polls bounds nothing: a retry round is 0.3 us on an idle chip, several us
+// when every wave of a cluster retries -- the first version of this bound, 16 667 retries, took 95 ms).  Every launch's grid is resident
+// (ptile: one round of tiles, cluster: one launch per round of clusters, slab: the plan fits the chip), so a peer is never
+// more than a step or two behind unless its workgroup is not running at all -- another process holding CUs, a fault.
+// The bound is therefore a multiple of the STEP, not of the launch: 50 estimated steps, at least 5 ms (clock ramps,
+// a first step that loads panels, a context switch) -- rounds 2-5 waited 0.5-1.2 s, a 10^4 x cliff.
+unsigned spin_ticks(double est_step_us, const Tuning& tun) {
+    const double us = tun.spin_ms > 0.0 ? 1e3 * tun.spin_ms : std::max(5000.0, 50.0 * est_step_us);
+    const double ticks = 100.0 * us;
+    return ticks > 4.0e9 ? 4000000000u : ticks < 100.0 ? 100u : (unsigned)ticks;
 }
 
 // The chip as the launch policies see it: CU and XCD counts, asked ONCE per device (hipDeviceAttributeMultiprocessorCount,
@@ -569,6 +587,9 @@ int cluster_base(ClusterArgs& ca, unsigned& xid, const float* Q, const float* V,
                  int planes = 1) {
     std::memset(&ca, 0, sizeof(ca));
     ca.drop = tun.cluster_drop;
+    ca.cus = chip_of(tun).cus; ca.xcds = chip_of(tun).xcds;
+    // (a round of clusters: <= 22 us per step, docs/kernel-cluster.md)
+    ca.spin_limit = spin_ticks(25.0, tun);
     ca.half_off = !tun.cluster_half;
     ca.Q = Q; ca.V = V; ca.qsum = qsum; ca.table = table;
     const size_t xb = cluster_exchange_bytes(B, N, planes);
@@ -620,6 +641,7 @@ int slab_base(SlabArgs& sa, unsigned& xid, const SlabPlan& p, const float* Q, co
               int planes) {
     std::memset(&sa, 0, sizeof(sa));
     sa.drop = tun.cluster_drop;
+    sa.spin_limit = spin_ticks(p.est_us, tun);
     sa.Q = Q; sa.V = V; sa.qsum = qsum; sa.table = table;
     const size_t half = (size_t)p.nclusters * planes * p.rg * p.K * 4 * SL_XE;  // <= exchange_bytes / 2
     sa.xb0 = static_cast<float*>(area);
@@ -817,7 +839,8 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
         pa.par = par;
         pa.step0 = step0 + done; pa.nsteps = k;
         pa.in_scale = a.in_scale; pa.in_shift = a.in_shift;
-        pa.spin_limit = 1u << 19;  // ~1 us per poll
+        // (a step of the resident grid: its flops at ~100 TFLOP/s)
+        pa.spin_limit = spin_ticks(2.0 * (MODE == MODE_DL ? 2 : 1) * (double)a.N * a.N * rows / 1.0e8, tun);
         pa.drop = tun.cluster_drop;
         if constexpr (MODE == MODE_DL) ptile_launch_dl(pa, st);
         else if constexpr (MODE == MODE_MF) ptile_launch_mf(pa, use_adam, st);
@@ -1014,9 +1037,15 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N, chip, tun.cluster_sets);
         const bool spread = cluster_spread(B, N, chip, tun.cluster_sets);
         const bool two_wide = ccvm_ld(N) > CL_LDS_K && cluster_sets(B, N, chip, tun.cluster_sets) == 2;
-        std::snprintf(buf, buf_len, "ccvm::cluster_kernel%s%s<%d, %s, %d, false> grid %d x 512 threads (%d clusters of %d workgroups%s), up to %d steps per launch",
+        // a batch of more clusters than the chip holds runs as one launch per round of resident clusters (launch_cluster)
+        const int per_xcd = chip.cus / chip.xcds / G;
+        const int per_round = spread ? count : chip.xcds * std::max(1, per_xcd), rounds = (count + per_round - 1) / per_round;
+        const int first = std::min(count, per_round);
+        char how[96] = "";
+        if (rounds > 1) std::snprintf(how, sizeof(how), " x %d launches of at most %d clusters", rounds, per_round);
+        std::snprintf(buf, buf_len, "ccvm::cluster_kernel%s%s<%d, %s, %d, false> grid %d x 512 threads%s (%d clusters of %d workgroups%s), up to %d steps per launch",
                       cluster_half(N, !tun.cluster_half) ? "_half" : "", two_wide ? "_2sets" : "", solver, ad ? "true" : "false",
-                      ccvm_ld(N) / CL_KC, spread ? count * G : (count + 7) / 8 * 8 * G, count, G,
+                      ccvm_ld(N) / CL_KC, spread ? first * G : (first + 7) / 8 * 8 * G, how, count, G,
                       spread ? ", spread over the XCDs" : "", TABLE_STEPS);
         return CCVM_OK;
     }

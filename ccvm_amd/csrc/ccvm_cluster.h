@@ -46,10 +46,13 @@
 //
 // Placement and deadlock freedom: blocks b, b + 8, ... share an XCD, a cluster is G consecutive indices of
 // one XCD (its exchange stays in that XCD's L2); with 11-12 members, when the clusters do not pack XCD by
-// XCD but fit the chip, G consecutive blocks (members on all XCDs, exchange over the fabric).  Residency
-// of the whole grid is not needed: workgroups are dispatched in order, so at most one cluster per XCD is
-// ever partially resident and every complete cluster runs to the end of the launch without waiting for
-// anything unplaced (larger batches run in rounds).  Every spin is bounded all the same: on a timeout the
+// XCD but fit the chip, G consecutive blocks (members on all XCDs, exchange over the fabric).  Every
+// LAUNCH's grid fits the chip it is planned for (one workgroup per CU): a batch of more clusters than that
+// runs as one launch per round of resident clusters (launch_cluster below; ClusterArgs::cluster0), one
+// after the other in stream order -- clusters never interact, and all of a round's clusters finish
+// together, so nothing is lost against workgroups trickling in as others leave, and no progress
+// argument rests on the order in which a dispatcher places workgroups (rounds 2-5 ran them in ONE launch
+// and relied on in-order dispatch: VERDICT r5).  Every spin is bounded all the same: on a timeout the
 // fetch wave sets the launch's status word and an LDS flag, the workgroup leaves behind its next barrier
 // (the host raises).
 //
@@ -75,9 +78,8 @@ constexpr int CL_KC = 128;      // K chunk staged through LDS per barrier
 constexpr int CL_MIN_N = 257, CL_MAX_N = 768;
 constexpr int CL_LDS_K = 512;   // k < 512 of a member's panel lives in LDS, the rest (K = 640, 768) in the MFMA waves' registers
 constexpr int CL_THREADS = 512; // 4 MFMA waves + 4 fetch waves
-constexpr unsigned CL_SPIN_LIMIT = 1u << 22;  // fetch retries, ~0.3 us each (measured: 2^19 gave up after 0.16 s): ~1.2 s.
-                                              // In rounds a partially placed cluster waits for a whole launch of another one
-                                              // (4096 steps x <= 22 us = 90 ms): the limit must stay well above that.
+// (the bound of a wait: ClusterArgs::spin_limit, ticks of the 100 MHz reference clock -- ccvm_abi.hip: spin_ticks.  A count
+// of retries bounds nothing: a retry is 0.3 us on an idle chip and several us when every wave of a cluster retries)
 constexpr unsigned CL_XE = 8;   // bytes per exchanged element: {value, tag}
 
 struct ClusterArgs {
@@ -105,6 +107,9 @@ struct ClusterArgs {
     int nclusters, G;
     int spread;          // 1: a cluster = G consecutive blocks (members on all XCDs); 0: a cluster stays in one XCD
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
+    unsigned spin_limit; // how long a wave retries before it gives up a wait, in ticks of s_memrealtime (100 MHz; ccvm_abi.hip: spin_ticks)
+    int cluster0;        // first cluster of THIS launch (a batch of several rounds is one launch per round)
+    int cus, xcds;       // host only: the chip the launch is planned for
     int half_off;        // host only (tuning): 1 = the full kernel also where the half-chunk variant applies
     int sets;            // host only: row sets of 16 per cluster (2; K = 640 / 768: 3, or 2 where clusters of 32 rows fit the chip)
     float in_scale, in_shift;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
     // exchange crosses the fabric (sc1 = agent scope: still coherent) -- for member counts that do not pack into an
     // XCD's 32 CUs (11-12 members: 2 clusters of 12 use 24 CUs per XCD, 21 clusters need 252 of the chip's 256).
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int cluster = a.spread ? blockIdx.x / G : (idx / G) * 8 + xcd;
+    const int cluster = a.cluster0 + (a.spread ? blockIdx.x / G : (idx / G) * 8 + xcd);
     const int member = a.spread ? blockIdx.x % G : idx % G;
     if (cluster >= a.nclusters) return;  // a whole cluster out of range: nobody waits for it
     const int N = a.N, ld = a.ld;
@@ -319,20 +324,25 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
             return __builtin_amdgcn_ballot_w64(lo != want && lo != 0xFFFFFFFFu) == 0;
         };
         // wait (bounded) until pair k of input `want` of set s is complete in w
+        const unsigned k_spin = a.spin_limit;
+        bool gave_up = false;  // this wave gave up a wait: its later waits of the phase return at once (the workgroup
+                               // leaves behind the next B_0; without this every pair of the phase waited out the bound again)
         auto await_pair = [&](int s, int par, unsigned want, auto k_tag) {
             if constexpr (NO_XCHG || (CCVM_CLUSTER_ABL & 4)) return;
             // the first check stands alone: straight-line code whose wait counts leave the younger loads (the
             // input's other pairs) in flight; the merged counts of a loop header would wait for everything
             if (__builtin_expect(arrived(want, k_tag), 1)) return;
-            unsigned spins = 0;
+            if (gave_up) return;
+            const unsigned long long t_wait = wall_clock64();
 #pragma nounroll
             do {
                 if constexpr (CCVM_CLUSTER_ABL & 64) hseg[5] += 1;
-                if (++spins > CL_SPIN_LIMIT) {
+                if ((unsigned)(wall_clock64() - t_wait) > k_spin) {
                     if (lane == 0) {
                         __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         lds[DEAD] = 1.0f;  // read by everyone behind the next B_0
                     }
+                    gave_up = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(CCVM_CL_SLEEP);
@@ -841,18 +851,33 @@ void launch_cluster_variant(const ClusterArgs& a, int grid, hipStream_t st) {
     }
 }
 
+// clusters of one launch: all of them where they fit the chip (spread: by construction), else whole clusters per XCD
+inline int cluster_round(const ClusterArgs& a) {
+    if (a.spread) return a.nclusters;
+    const int xcds = a.xcds > 0 ? a.xcds : 8, cus = a.cus > 0 ? a.cus : 256;
+    const int per_xcd = cus / xcds / a.G;
+    return per_xcd > 0 ? xcds * per_xcd : xcds;  // (a member count beyond an XCD's CUs is not planned: want_cluster)
+}
+
 template <int MODE>
-void launch_cluster(const ClusterArgs& a, bool adam, hipStream_t st) {
-    const int grid = (a.spread ? a.nclusters * a.G : ((a.nclusters + 7) / 8) * 8 * a.G) - a.drop;
-    if constexpr (MODE == MODE_DL) {
-        if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
-        else launch_cluster_variant<MODE, false, false>(a, grid, st);
-    } else if (adam) {
-        if (a.replay) launch_cluster_variant<MODE, true, true>(a, grid, st);
-        else launch_cluster_variant<MODE, true, false>(a, grid, st);
-    } else {
-        if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
-        else launch_cluster_variant<MODE, false, false>(a, grid, st);
+void launch_cluster(const ClusterArgs& args, bool adam, hipStream_t st) {
+    const int per_round = cluster_round(args);
+    for (int c0 = 0; c0 < args.nclusters; c0 += per_round) {
+        ClusterArgs a = args;
+        a.cluster0 = c0;
+        const int count = args.nclusters - c0 < per_round ? args.nclusters - c0 : per_round;
+        const bool last = c0 + per_round >= args.nclusters;
+        const int grid = (a.spread ? count * a.G : ((count + 7) / 8) * 8 * a.G) - (last ? a.drop : 0);
+        if constexpr (MODE == MODE_DL) {
+            if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
+            else launch_cluster_variant<MODE, false, false>(a, grid, st);
+        } else if (adam) {
+            if (a.replay) launch_cluster_variant<MODE, true, true>(a, grid, st);
+            else launch_cluster_variant<MODE, true, false>(a, grid, st);
+        } else {
+            if (a.replay) launch_cluster_variant<MODE, false, true>(a, grid, st);
+            else launch_cluster_variant<MODE, false, false>(a, grid, st);
+        }
     }
 }
 

@@ -56,7 +56,7 @@ constexpr int SL_RED_FLOATS = 8192;      // partial sums of the four waves: 4 x 
 constexpr int SL_MIN_N = 257, SL_MAX_N = 2048;
 constexpr int SL_MAX_RC = 256;           // RG x C: a lane owns up to two pairs of rows at one column (512 pairs per member)
 constexpr int SL_MAX_B = 512;            // batches the path is ever considered for (workspace sizing)
-constexpr unsigned SL_SPIN_LIMIT = 1u << 22;
+// (the bound of a wait: SlabArgs::spin_limit, ticks of the 100 MHz reference clock -- ccvm_abi.hip: spin_ticks)
 
 struct SlabArgs {
     const float* Q;      // [ld][ld] (the row-scaled copy with a per-variable saturation)
@@ -86,6 +86,7 @@ struct SlabArgs {
     int delay_fabric;    // x 64 cycles: what every wave of a cluster that spans XCDs waits before its first loads of a step
     int delay_fixed;     // 1: no calibration of that delay (CCVM_AMD_SLAB_DELAY given)
     int drop;            // fault injection (tests only): this many workgroups are left out of the launch
+    unsigned spin_limit; // how long a wave retries before it gives up a wait, in ticks of s_memrealtime (100 MHz; ccvm_abi.hip: spin_ticks)
     float in_scale, in_shift;
     float k_first;       // MF: sqrt(1 / (4 j_step0)) / sqrt(dt)
     float S;             // MF: clamp of the measured amplitude
@@ -353,17 +354,20 @@ __global__ __launch_bounds__(SL_THREADS) void slab_kernel(const SlabArgs a) {
     const int delay_cap = a.span > 1 ? 72 : 24;
     bool retried = false;
     bool dead = false;
+    const unsigned k_spin = a.spin_limit;
     auto await = [&](int b, int par, unsigned want, u32x4s (&w)[NLD]) {
         if constexpr (CCVM_SLAB_ABL & 4) return;
         if (__builtin_expect(arrived(want, w), 1)) return;
         if (dead) return;  // this wave gave up on an earlier unit of the step: on to the barriers
         unsigned spins = 0;
+        const unsigned long long t_wait = wall_clock64();
 #pragma nounroll
         do {
-            // give up: after ~1 s of retries, or as soon as another wave of the workgroup has (volatile: the flag is
-            // written without a barrier in between)
-            const bool peer_gave_up = (spins & 255u) == 255u && *reinterpret_cast<volatile float*>(lds + DEAD) != 0.0f;
-            if (++spins > SL_SPIN_LIMIT || peer_gave_up) {
+            // give up: when the wait's bound is spent (SlabArgs::spin_limit), or as soon as another wave of the workgroup
+            // has (volatile: the flag is written without a barrier in between)
+            const bool peer_gave_up = (spins & 63u) == 63u && *reinterpret_cast<volatile float*>(lds + DEAD) != 0.0f;
+            ++spins;
+            if ((unsigned)(wall_clock64() - t_wait) > k_spin || peer_gave_up) {
                 if (lane == 0) {
                     __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     lds[DEAD] = 1.0f;  // read by everyone behind the step's last barrier

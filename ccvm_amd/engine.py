@@ -334,7 +334,8 @@ def _exchange_exit(ch, device, raw):
 
 
 #: device index -> time.monotonic() until which new Trajectories avoid the cluster / slab kernels (set by a time-out
-#: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 30)
+#: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 2: a give-up costs ~5 ms since round 6 --
+#: ccvm_abi.hip spin_ticks -- so coming back early is cheap; rounds 3-5: 30 s for waits of 0.5-1.2 s)
 _exchange_blocked_until = {}
 
 _problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device index, DeviceProblem, ready event)
@@ -479,7 +480,7 @@ class Trajectories:
         self._snap = None
         # True after a time-out: the rest of the run stays on the tile kernel.  A time-out anywhere in this process
         # also keeps NEW trajectories on this device off the exchange kernels for a cool-down period (ADVICE r3:
-        # whatever held the GPU -- another process, a CU mask -- would cost each of them its own ~1 s wait)
+        # whatever held the GPU -- another process, a CU mask -- would cost each of them its own bounded wait and repeat)
         self.no_exchange = time.monotonic() < _exchange_blocked_until.get(self.device.index, 0.0)
         self.fallbacks = 0         # time-outs recovered so far
         self._waits = None         # does a run call launch a kernel whose workgroups wait for each other? (asked once)
@@ -685,7 +686,7 @@ class Trajectories:
         self.fallbacks += 1
         with _cache_lock:
             _exchange_blocked_until[self.device.index] = time.monotonic() + float(
-                os.environ.get("CCVM_AMD_EXCHANGE_COOLDOWN", "30"))
+                os.environ.get("CCVM_AMD_EXCHANGE_COOLDOWN", "2"))
         warnings.warn(
             f"ccvm_{self.kind}_run: a persistent kernel timed out waiting for its workgroups (is another process "
             f"using this GPU?); steps {snap['step']}..{reached} are repeated on the per-step tile kernel",

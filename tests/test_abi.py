@@ -100,26 +100,29 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (0, 1000, 1000, 0): "ccvm::ptile_kernel<0, false> grid 256 x 512 threads (32 row blocks x 8 column blocks resident",
         (2, 1000, 1000, 1): "ccvm::ptile_kernel<2, true> grid 256 x 512",
         (1, 1000, 1000, 0): "ccvm::ptile_kernel<1, false> grid 256 x 512",
-        (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> grid 500 x 256",   # K split: one row set per workgroup
+        (0, 1000, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2, 1> grid 500 x 512 threads (noise producer waves)",   # K split + producers: one row set of 4 + 4 waves per workgroup
+        (0, 1500, 100, 0): "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> grid 750 x 256",   # three half-chain consumers per SIMD: no room for producers
+        (0, 1000, 20, 0): "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> grid 250 x 256 threads (noise producer waves)",  # the shipped example
+        (0, 100, 20, 0): "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> grid 25 x 256 threads (noise producer waves)",   # BASELINE config 1
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 500, 0): "ccvm::cluster_kernel<0, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 300, 0): "ccvm::cluster_kernel_half<0, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
-        (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 1024 x 512 threads (125 clusters of 8 workgroups)",
+        (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 256 x 512 threads x 4 launches of at most 32 clusters (125 clusters of 8 workgroups)",
         (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",
         (1, 1000, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (2, 1000, 600, 1): "ccvm::cluster_kernel<2, true, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (1, 1200, 600, 0): "ccvm::cluster_kernel<1, false, 5, false> grid 250 x 512 threads (25 clusters of 10 workgroups, spread over the XCDs)",
         # two rounds of 32-row clusters (MF N = 640, B = 1500: 13.1 us per step against 15.1 on the per-step tiles)
-        (1, 1300, 600, 0): "ccvm::cluster_kernel_2sets<1, false, 5, false> grid 480 x 512 threads (41 clusters of 10 workgroups)",
+        (1, 1300, 600, 0): "ccvm::cluster_kernel_2sets<1, false, 5, false> grid 240 x 512 threads x 2 launches of at most 24 clusters (41 clusters of 10 workgroups)",
         (0, 1000, 640, 0): "ccvm::cluster_kernel<0, false, 5, false> grid 240 x 512 threads (21 clusters of 10 workgroups)",
         (0, 768, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 192 x 512 threads (16 clusters of 12 workgroups)",
         (0, 1000, 768, 0): "ccvm::cluster_kernel<0, false, 6, false> grid 252 x 512 threads (21 clusters of 12 workgroups, spread over the XCDs)",
         (2, 1000, 700, 1): "ccvm::cluster_kernel_half<2, true, 6, false> grid 231 x 512 threads (21 clusters of 11 workgroups, spread over the XCDs)",
         (0, 1100, 768, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 210 x 512",
-        (2, 2000, 640, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 480 x 512 threads (42 clusters of 10 workgroups)",
-        (2, 1500, 640, 0): "ccvm::cluster_kernel_2sets<2, false, 5, false> grid 480 x 512 threads (47 clusters of 10 workgroups)",  # 12.9 us vs 13.2
+        (2, 2000, 640, 0): "ccvm::cluster_kernel<2, false, 5, false> grid 240 x 512 threads x 2 launches of at most 24 clusters (42 clusters of 10 workgroups)",
+        (2, 1500, 640, 0): "ccvm::cluster_kernel_2sets<2, false, 5, false> grid 240 x 512 threads x 2 launches of at most 24 clusters (47 clusters of 10 workgroups)",  # 12.9 us vs 13.2
         (2, 2000, 768, 0): "ccvm::step_kernel<2, false, 0, 2, false, 0> grid 756 x 512",   # 3 rounds of 32 x 64 tiles < 2 of 32 x 128
         (0, 256, 1000, 0): "ccvm::step_kernel<0, false, 0, 4, false, 0> grid 256 x 512",   # 32 x 32 tiles fill the chip
         # K = 768 in clusters of 32 rows (two row sets) where they fit the chip: 7.3 us per step against 9.6 on 32 x 64 tiles

@@ -4,7 +4,7 @@ cluster's workgroups exchanging the GEMM input as {value, tag} packets through s
 
 Every word of every trajectory is compared with the oracle (fused noise through oracle/noise_ref.py),
 over enough steps that a single stale exchange read would be amplified into a visible difference, on
-grids from one cluster to many more workgroups than the chip holds at once (in-order dispatch)."""
+grids from one cluster to many more clusters than the chip holds at once (one launch per round of resident clusters)."""
 import pytest
 import torch
 
@@ -23,6 +23,16 @@ _ADAMS = {
 @pytest.fixture
 def cluster(monkeypatch):
     monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+
+
+def _describe(kind, b, n, adam=False):
+    import ctypes
+
+    from ccvm_amd import _lib
+
+    buf = ctypes.create_string_buffer(1024)
+    assert _lib.load().ccvm_describe_launch({"dl": 0, "mf": 1}.get(kind, 2), b, n, 1 if adam else 0, 0, buf, 1024) == 0
+    return buf.value.decode()
 
 
 def _run_engine(kind, n, b, t, adam, seed, row_offset, chunks=None, replay_global_batch=None):
@@ -305,6 +315,50 @@ def test_bounded_waits_give_up_instead_of_hanging(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_FAULT")
     good = _run_engine("langevin", 500, 1000, 3, None, 21, 0)
     assert bool(torch.isfinite(good.compact("c")).all()) and good.fallbacks == 0
+
+
+@pytest.mark.parametrize("kind,n,b,family", [("dl", 1000, 1000, "ptile"), ("mf", 500, 1000, "cluster"),
+                                             ("langevin", 500, 1000, "cluster"), ("dl", 1000, 32, "slab")])
+def test_a_dropped_workgroup_costs_milliseconds(monkeypatch, kind, n, b, family):
+    """the bound of a cross-workgroup wait is a multiple of the STEP (50 estimated steps, at least 5 ms:
+    ccvm_abi.hip spin_ticks), not the 0.5-1.2 s of rounds 2-5.  Fault injection at the BASELINE shapes, end to end --
+    launch with 8 workgroups missing, give-up, status word to the host, snapshot restored, the 20 steps again on the
+    per-step kernel, verified: under 50 ms."""
+    import time
+
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "nocluster")
+    want = _run_engine(kind, n, b, 20, None, 21, 0)      # (also warms the per-step kernels the recovery runs on)
+    name = "mu" if kind == "mf" else "c"
+    want = want.compact(name).cpu()
+    monkeypatch.setenv("CCVM_AMD_KERNEL", family)
+    _run_engine(kind, n, b, 20, None, 22, 0).check()      # (and the exchange kernel itself, fault-free)
+    monkeypatch.setenv("CCVM_AMD_FAULT", "cluster_drop")
+    traj = _run_engine(kind, n, b, 20, None, 21, 0, chunks=[0])  # built, armed by advance below
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    traj.advance(20)
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
+        assert traj.check() is True
+    torch.cuda.synchronize()
+    cost = time.perf_counter() - t0
+    assert traj.fallbacks == 1 and torch.equal(traj.compact(name).cpu(), want)
+    assert cost < 0.05, f"{family}: a dropped workgroup cost {cost * 1e3:.1f} ms"
+
+
+def test_a_batch_of_several_rounds_is_one_launch_per_round(monkeypatch):
+    """Round 6: a batch of more clusters than the chip holds runs as one launch per round of resident clusters
+    (ccvm_cluster.h: launch_cluster, ClusterArgs::cluster0) -- no progress argument rests on dispatch order any more.
+    Langevin N = 500, B = 4000 = 125 clusters in four launches of 32: every row equals the same rows run as four
+    separate batches of one round each (shards are bit-exact), and the oracle."""
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+    assert "x 4 launches of at most 32 clusters (125 clusters of 8 workgroups)" in _describe("langevin", 4000, 500)
+    whole = _run_engine("langevin", 500, 4000, 12, None, 9, 0)
+    got = whole.compact("c")
+    for first in range(0, 4000, 1024):
+        rows = min(1024, 4000 - first)
+        part = _run_engine("langevin", 500, rows, 12, None, 9, first)
+        assert torch.equal(got[first:first + rows], part.compact("c")), first
+    assert whole.fallbacks == 0
 
 
 def test_time_out_recovery_in_replay_mode_and_under_sampling(monkeypatch, tmp_path):

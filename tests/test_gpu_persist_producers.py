@@ -109,15 +109,14 @@ def test_long_run_with_producers_is_the_run_without(monkeypatch):
 
 
 def test_default_policy(monkeypatch):
+    """(the policy itself is pinned on the host: tests/test_launch_policy.py::test_producer_waves_policy)"""
     for var in ("CCVM_AMD_PERSIST_PW", "CCVM_AMD_PERSIST_RU", "CCVM_AMD_PERSIST_KH"):
         monkeypatch.delenv(var, raising=False)
-    # the shipped instances at the example scripts' batch sizes: consumers + producers fit the 1024 SIMDs
     for kind in ("dl", "mf", "langevin"):
         for n in (20, 50, 64):
             for b in (1, 100, 1000):
                 s = _shape(kind, b, n)
                 assert s["pw"] == 1 and s["threads"] == 256, (kind, n, b, s)
     assert _shape("dl", 100, 20)["grid"] == 25 and _shape("dl", 1000, 20)["grid"] == 250  # 4 rows per workgroup at RU = 2
-    # two waves side by side keep the K split; batches whose consumers alone fill the chip keep it to themselves
-    assert _shape("dl", 1000, 100)["pw"] == 0 and _shape("dl", 1000, 100)["kh"] == 2
-    assert _shape("dl", 8000, 20)["pw"] == 0
+    assert _shape("dl", 1000, 100) == {"cw": 64, "ncg": 2, "nch": 7, "ru": 4, "kh": 2, "pw": 1, "grid": 500, "threads": 512}
+    assert _shape("dl", 1500, 100)["pw"] == 0 and _shape("dl", 8000, 64)["pw"] == 0

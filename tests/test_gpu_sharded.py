@@ -43,7 +43,9 @@ def test_sharded_engine_equals_unsharded(tmp_path, backend, world, kind, n, batc
     port, out = str(_free_port()), str(tmp_path / "sharded.pt")
     # dmabuf IPC (the host driver of this pool supports nothing else: RCCL's set-up fails with "hipIpcGetMemHandle:
     # invalid argument" under the legacy mode); bench.py's launcher and ranks set the same (bench.IPC_ENV)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (processes that SHARE a GPU wait for each other's whole launches: the 5 ms bound of a cross-workgroup wait is for a
+    # GPU of one's own -- ccvm_abi.hip: spin_ticks)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCVM_AMD_SPIN_MS="2000")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_gpu_worker.py"), backend, str(r),
                                str(world), port, kind, str(n), str(batch), out], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]

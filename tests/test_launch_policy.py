@@ -187,6 +187,61 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
             assert split == (regs[(solver, adam, nch)] > 256), (solver, adam, nch, regs[(solver, adam, nch)], d)
 
 
+def test_producer_waves_policy(hip_lib, clean_env):
+    """Round 6: the row-owner kernel's noise producer waves (ccvm_persist.h, PW).  N <= 64: the variant (rows in use x
+    producers) with the smallest estimate of the fitted model (ccvm_persist_model.h, generated); 64 < N <= 128: next to
+    the K split while a SIMD holds at most two half-chain consumers and two eight-wave workgroups still fit a CU where
+    the batch needs them -- the NCH thresholds in persist_shape must be the code objects' register counts."""
+    import os
+    import sys
+
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    shape = re.compile(r"persist_kernel<\d, \w+, (\d+), (\d+), (\d+), (\d+), (\d+)(, 1)?> grid (\d+) x (\d+) threads")
+
+    def plan(solver, b, n, adam=0):
+        m = shape.search(_describe(hip_lib, solver, b, n, adam))
+        return {"ru": int(m.group(4)), "kh": int(m.group(5)), "pw": 1 if m.group(6) else 0, "grid": int(m.group(7)), "threads": int(m.group(8))}
+
+    # the shipped instances at the example scripts' batch sizes: two rows in use + producers, one four-wave workgroup = two row sets
+    for solver in (0, 1, 2):
+        for n in (20, 50, 64):
+            for b in (1, 100, 1000):
+                p = plan(solver, b, n)
+                assert p["pw"] == 1 and p["ru"] == 2 and p["threads"] == 256, (solver, n, b, p)
+    assert plan(0, 100, 20)["grid"] == 25 and plan(0, 1000, 20)["grid"] == 250
+    # more rounds of waves: four rows in use + producers, then (consumers alone fill the SIMDs twice over) no producers
+    assert plan(0, 1500, 64) == {"ru": 4, "kh": 1, "pw": 1, "grid": 375, "threads": 256}
+    assert plan(0, 8000, 64)["pw"] == 0 and plan(0, 8000, 64)["ru"] == 4
+    assert plan(2, 3000, 64)["pw"] == 1 and plan(2, 3000, 64)["ru"] == 4
+    # overrides pin their dimension only
+    clean_env.setenv("CCVM_AMD_PERSIST_PW", "0")
+    assert plan(0, 1000, 20)["pw"] == 0
+    clean_env.setenv("CCVM_AMD_PERSIST_PW", "1")
+    clean_env.setenv("CCVM_AMD_PERSIST_RU", "4")
+    assert plan(0, 1000, 20) == {"ru": 4, "kh": 1, "pw": 1, "grid": 125, "threads": 256}
+    clean_env.delenv("CCVM_AMD_PERSIST_PW")
+    clean_env.delenv("CCVM_AMD_PERSIST_RU")
+    # two waves side by side
+    assert plan(0, 1000, 100) == {"ru": 4, "kh": 2, "pw": 1, "grid": 500, "threads": 512}
+    assert plan(0, 1500, 100)["pw"] == 0 and plan(0, 1500, 100)["kh"] == 2
+    assert plan(2, 2000, 100)["pw"] == 1 and plan(2, 3000, 100)["pw"] == 0
+    assert plan(0, 2000, 100) == {"ru": 4, "kh": 1, "pw": 0, "grid": 500, "threads": 256}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    regs = {}
+    for k in kernel_resources.kernels():
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, 2, (\d+), 4, 2, 1>", k["name"])
+        if m:
+            regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
+    assert len(regs) == 20
+    for (solver, adam, nch), vgpr in regs.items():
+        # B = 1500 one-stream rows (375 row sets: two workgroups on some CUs) / 700 DL rows (350 row sets)
+        p = plan(solver, 1500 if solver else 700, 16 * nch, 1 if adam else 0)
+        assert p["kh"] == 2 and (p["pw"] == 1) == (vgpr <= 128), (solver, adam, nch, vgpr, p)
+        assert plan(solver, 1000 if solver else 500, 16 * nch, 1 if adam else 0)["pw"] == 1  # one workgroup per CU: always
+
+
 def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env):
     """ccvm_ptile.h: its workgroups wait for each other, so the grid must fit the chip the policy plans for (CU masks,
     partitions: CCVM_AMD_GEOMETRY) and be estimated no more than 5 % behind the best per-step tile shape (round 5: the

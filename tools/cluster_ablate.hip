@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
 #endif
     ClusterArgs a; memset(&a, 0, sizeof(a));
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
-    a.status = sync;
+    a.status = sync; a.spin_limit = 200000000u;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
     a.k_first = 4.47f; a.S = 20.0f;  // MF only: sqrt(1 / (4 j)) / sqrt(dt), the measured amplitude's clamp
     const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512

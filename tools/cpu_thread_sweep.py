@@ -7,15 +7,17 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-workload = sys.argv[1] if len(sys.argv) > 1 else "dl_n1000_b1000"
-kind, n, b = bench.WORKLOADS[workload]
+workloads = sys.argv[1:] or ["dl_n1000_b1000"]
 visible = len(os.sched_getaffinity(0))
-print(f"# CPU baseline (torch-CPU oracle = the reference's op sequence) vs torch threads: {workload}\n")
-print(f"Host: {bench.cpu_model()}, {visible} cores visible to the process (a 1-GPU box is a share of the host).\n")
-print("| torch threads | ms/step | row-steps/s |")
-print("|---|---|---|")
-for t in (1, 2, 4, 8, 16, 32, 64, 128):
-    if t > visible:
-        break
-    out = bench.cpu_baseline(kind, n, b, 100000, budget_s=4.0, threads=t)
-    print(f"| {t} | {b / out['value'] * 1e3:.2f} | {out['value']:.3e} |", flush=True)
+print("# CPU baseline (torch-CPU oracle = the reference's op sequence) vs torch threads\n")
+print(f"Host: {bench.cpu_model()}, {visible} cores visible to the process (a 1-GPU box is a share of the host).  Each point: "
+      "20 warm-up steps, then >= 50 steps and >= 1.5 s (or 8 s) timed -- `bench.cpu_baseline`.\n")
+for workload in workloads:
+    kind, n, b = bench.WORKLOADS[workload]
+    instance = bench.WORKLOAD_EXTRAS.get(workload, {}).get("instance")
+    print(f"\n## {workload}\n\n| torch threads | ms/step | row-steps/s | timed steps |\n|---|---|---|---|")
+    for t in (1, 2, 4, 8, 16, 32, 64, 128):
+        if t > visible:
+            break
+        out = bench.cpu_baseline(kind, n, b, 100000, budget_s=8.0, threads=t, instance=instance, min_steps=50, min_seconds=1.5)
+        print(f"| {t} | {b / out['value'] * 1e3:.3f} | {out['value']:.3e} | {out['timed_steps']} |", flush=True)

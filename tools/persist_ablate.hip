@@ -50,18 +50,28 @@ void run(const char* what, PersistArgs a, int N, int B, int steps) {
             printf("      %-46s min %7.1f  median %7.1f  max %7.1f  (s_memtime ticks per step)\n", SEG[k], v.front(), v[v.size() / 2], v.back());
         }
     }
+    {   // the state the variant left behind (a diverged state changes what the step costs?)
+        std::vector<float> hc(64 * 128);
+        hipMemcpy(hc.data(), a.x0, hc.size() * 4, hipMemcpyDeviceToHost);
+        int bad = 0; double mx = 0.0;
+        for (int r = 0; r < 64; ++r) for (int j = 0; j < N; ++j) { const float x = hc[r * 128 + j]; if (!(x == x) || x > 1e30f || x < -1e30f) ++bad; else mx = std::max(mx, (double)(x < 0 ? -x : x)); }
+        printf("      state after: %d non-finite of %d, max |c| %.3g\n", bad, 64 * N, mx);
+    }
     hipFree(dbg);
 }
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1000;
+    const bool small_first = argc > 2 && atoi(argv[2]) == 1;   // N = 20 before N = 100 (state arrays still zero)
+    const bool fresh = argc > 2 && atoi(argv[2]) == 2;         // zero the state arrays in front of every variant
     const int ld = 128, rows = (B + 63) / 64 * 64 + 64, steps = 4096;
     float *Q, *V, *c, *s, *table;
     hipMalloc(&Q, ld * ld * 4); hipMalloc(&V, ld * 4); hipMalloc(&c, (size_t)rows * ld * 4); hipMalloc(&s, (size_t)rows * ld * 4);
     hipMalloc(&table, steps * TABLE_WORDS * 4);
     DlSched sc{8.0, 0.001, 10.0, 100.0, 0.05, 1.0, 2.6457513, 1, 15000, 0, steps};
     hipLaunchKernelGGL(dl_schedule_kernel, dim3((steps + 255) / 256), dim3(256), 0, 0, sc, table);
-    for (int N : {100, 20}) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int N = (pass == 0) != small_first ? 100 : 20;
         std::vector<float> h(ld * ld, 0.f);
         unsigned rng = 1;
         auto rnd = [&] { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f); };
@@ -71,6 +81,7 @@ int main(int argc, char** argv) {
         hipMemset(c, 0, (size_t)rows * ld * 4); hipMemset(s, 0, (size_t)rows * ld * 4);
         PersistArgs a; memset(&a, 0, sizeof(a));
         a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = s; a.table = table; a.seed = 7; a.ld = ld; a.in_scale = 0.378f; a.in_shift = 1.0f;
+        auto reset = [&] { if (fresh) { hipMemset(c, 0, (size_t)rows * ld * 4); hipMemset(s, 0, (size_t)rows * ld * 4); } };
         if (N == 100) {
             run<64, 2, 7, 4, 2, 0>("K split (shipped at B = 1000)", a, N, B, steps);
             run<64, 2, 7, 4, 2, 1>("K split + producers", a, N, B, steps);
@@ -79,10 +90,10 @@ int main(int argc, char** argv) {
             run<64, 2, 7, 2, 1, 0>("whole chains, 2 rows", a, N, B, steps);
             run<64, 2, 7, 2, 1, 1>("whole chains, 2 rows + producers", a, N, B, steps);
         } else {
-            run<32, 1, 2, 2, 1, 0>("one wave per row set, 2 rows", a, N, B, steps);
-            run<32, 1, 2, 2, 1, 1>("2 rows + producers", a, N, B, steps);
-            run<32, 1, 2, 4, 1, 0>("one wave per row set, 4 rows", a, N, B, steps);
-            run<32, 1, 2, 4, 1, 1>("4 rows + producers", a, N, B, steps);
+            reset(); run<32, 1, 2, 2, 1, 0>("one wave per row set, 2 rows", a, N, B, steps);
+            reset(); run<32, 1, 2, 2, 1, 1>("2 rows + producers", a, N, B, steps);
+            reset(); run<32, 1, 2, 4, 1, 0>("one wave per row set, 4 rows", a, N, B, steps);
+            reset(); run<32, 1, 2, 4, 1, 1>("4 rows + producers", a, N, B, steps);
         }
     }
     return 0;

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     a.flags = flags; a.status = status;
     a.seed = 42; a.B = B; a.N = N; a.ld = ld;
     a.nrb = (B + BM - 1) / BM; a.ncb = ld / BN;
-    a.in_scale = 0.37f; a.in_shift = 1.0f; a.spin_limit = 1u << 19;
+    a.in_scale = 0.37f; a.in_shift = 1.0f; a.spin_limit = 50000000u;
     a.step0 = 0; a.nsteps = std::min(steps, 4096);
     const int grid = a.nrb * a.ncb;
     if (grid % 8 == 0) {  // XCD rectangle as the ABI's set_grid picks it (or forced width)

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
 #endif
     SlabArgs a; memset(&a, 0, sizeof(a));
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb; a.xb1 = (float*)((char*)xb + half); a.table = table;
-    a.seed = 7; a.nsteps = steps; a.status = sync;
+    a.seed = 7; a.nsteps = steps; a.status = sync; a.spin_limit = 200000000u;
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
     a.nclusters = p.nclusters; a.G = p.G; a.RG = p.rg; a.span = p.span; a.nxcd = 8; a.delay_fabric = getenv("SL_DELAY") ? atoi(getenv("SL_DELAY")) : slab_fabric_delay(planes, p.rg, p.K);
     SlabPlan q = p;

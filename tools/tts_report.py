@@ -1,0 +1,138 @@
+"""TTS @ 99 % success of all four solvers on the two committed shipped instances, engine (MI355X) next to the oracle
+(the reference's op sequence on this box's host cores) -- VERDICT r5 item 1.5 (developer tool).
+
+    python tools/tts_report.py [--out profiles/r06_tts.json] [--no-cpu]
+
+TTS99 = per-row solve time x R99, R99 = max(1, ln 0.01 / ln(1 - p)), p = fraction of the batch within 0.1 % of the
+known optimum (reference: ccvmplotlib/utils/sampleTTSmetric.py:144-153, boxqp_metadata.py:117-132; solve time per row
+= loop wall time / batch, dl_solver.py:851, 933).  Instances: tests/golden/{tuningH020,test020}.npz (arrays of the
+reference's tuningH020-100-0.in and test020-100-10.in, optimum from the files' headers).  Configurations: the example
+scripts' parameter keys (examples/ccvm_boxqp_dl.py:16-24, ccvm_boxqp_mf.py:16-25, langevin_boxqp.py:16-24,
+pumped_langevin_boxqp.py:16-25) at batch 1000 / 1500 iterations, plus BASELINE config 1 (DL, test020-100-10, batch 100,
+15000 iterations).  The engine runs through the public solver API (fused noise, seeds 1234 ...); the oracle draws its
+normals from torch's CPU stream as the reference does -- the two success fractions are two samples of the same
+distribution (tests/test_gpu_distribution.py), not the same trajectories."""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from ccvm_amd.workloads import EXAMPLE_PARAMS, SCALING_MULTIPLIER
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CONFIGS = [  # (label, solver kind, instance, batch, iterations)
+    ("dl example", "dl", "tuningH020", 1000, 1500), ("mf example", "mf", "tuningH020", 1000, 1500),
+    ("langevin example", "langevin", "tuningH020", 1000, 1500), ("pl example", "pl", "tuningH020", 1000, 1500),
+    ("dl", "dl", "test020", 1000, 1500), ("mf", "mf", "test020", 1000, 1500),
+    ("langevin", "langevin", "test020", 1000, 1500), ("pl", "pl", "test020", 1000, 1500),
+    ("dl BASELINE config 1", "dl", "test020", 100, 15000),
+]
+
+
+def load(instance):
+    arrays = np.load(os.path.join(GOLDEN, f"{instance}.npz"))
+    with open(os.path.join(GOLDEN, f"{instance}.json")) as fh:
+        meta = json.load(fh)["instance"]
+    return arrays["q_matrix"], arrays["v_vector"], meta
+
+
+def engine_leg(kind, instance, batch, iterations, repeats=7):
+    from ccvm_amd.problem_classes.boxqp import ProblemInstance
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
+
+    q, v, meta = load(instance)
+    inst = ProblemInstance.from_arrays(q, v, device="cuda", name=meta["name"], optimal_sol=meta["optimal_sol"],
+                                       best_sol=meta["best_sol"])
+    solver = {"dl": DLSolver, "mf": MFSolver, "langevin": LangevinSolver, "pl": PumpedLangevinSolver}[kind](
+        device="cuda", batch_size=batch)
+    solver.parameter_key = {20: dict(EXAMPLE_PARAMS[kind], iterations=iterations)}
+    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+    torch.manual_seed(1234)
+    solver(instance=inst)  # one-time initialisation
+    sols = [solver(instance=inst) for _ in range(repeats)]  # (each call draws a new noise key from torch's generator)
+    times = [s.solve_time for s in sols]
+    ps = [s.solution_performance["optimal"] for s in sols]
+    mid = sorted(range(repeats), key=lambda i: times[i])[repeats // 2]
+    from ccvm_amd.solution import r99
+    p_mean = float(np.mean(ps))
+    return {
+        "solve_time_per_row_s": times[mid], "solve_time_per_row_s_all": times,
+        "us_per_step": times[mid] * batch / iterations * 1e6,
+        "p_optimal": ps[mid], "p_optimal_all": ps, "p_optimal_mean": p_mean,
+        "tts99_s": sols[mid].tts99(), "tts99_s_at_mean_p": times[mid] * r99(p_mean),
+        "best_objective_value": max(s.best_objective_value for s in sols), "optimal_value": meta["optimal_sol"],
+    }
+
+
+def oracle_leg(kind, instance, batch, iterations, threads):
+    from oracle import ccvm_oracle as oracle
+
+    q, v, meta = load(instance)
+    q, v = torch.from_numpy(q).float(), torch.from_numpy(v).float()
+    f = oracle.scaling_factor(q, SCALING_MULTIPLIER[kind])
+    qs, vs = q / f, v / f
+    p = EXAMPLE_PARAMS[kind]
+    bounds = (0.0, 1.0)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+
+    def loop():
+        if kind == "dl":
+            c, _ = oracle.dl_loop(qs, vs, batch, iterations, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05, bounds)
+            return oracle.change_variables(torch.clamp(c, -1, 1), 0.0, 1.0, 1)
+        if kind == "mf":
+            _, mu_tilde, _ = oracle.mf_loop(qs, vs, batch, iterations, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], 0.01, bounds)
+            return oracle.change_variables(mu_tilde, 0.0, 1.0, p["S"])
+        if kind == "pl":
+            c = oracle.pl_loop(qs, vs, batch, iterations, p["pump"], p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
+        else:
+            c = oracle.langevin_loop(qs, vs, batch, iterations, p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
+        return (c + p["S"]) / (2 * p["S"])
+
+    t0 = time.perf_counter()
+    x = loop()
+    wall = time.perf_counter() - t0
+    obj = oracle.compute_energy(x, qs, vs, float(f))
+    best, perf = oracle.solution_stats(obj, meta["optimal_sol"])
+    per_row = wall / batch
+    return {"solve_time_per_row_s": per_row, "us_per_step": wall / iterations * 1e6, "p_optimal": perf["optimal"],
+            "tts99_s": per_row * oracle.r99(perf["optimal"]), "best_objective_value": best, "threads": threads}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--threads", default="1,4,16")
+    args = ap.parse_args()
+    rows = []
+    for label, kind, instance, batch, iterations in CONFIGS:
+        row = {"config": label, "solver": kind, "instance": instance, "batch": batch, "iterations": iterations,
+               "engine": engine_leg(kind, instance, batch, iterations)}
+        if not args.no_cpu:
+            legs = [oracle_leg(kind, instance, batch, iterations, int(t)) for t in args.threads.split(",")]
+            row["oracle_cpu"] = min(legs, key=lambda leg: leg["solve_time_per_row_s"])
+            row["oracle_cpu"]["all_thread_counts"] = {leg["threads"]: leg["solve_time_per_row_s"] for leg in legs}
+        rows.append(row)
+        e, c = row["engine"], row.get("oracle_cpu")
+        print(f"{label:22s} {instance:10s} B={batch:4d} T={iterations:5d}  engine: {e['us_per_step']:.3f} us/step, p={e['p_optimal_mean']:.3f}, "
+              f"TTS99 {e['tts99_s_at_mean_p'] * 1e6:.2f} us"
+              + (f"   oracle CPU ({c['threads']} threads): {c['us_per_step']:.0f} us/step, p={c['p_optimal']:.3f}, "
+                 f"TTS99 {c['tts99_s'] * 1e6:.0f} us  -> x{c['tts99_s'] / e['tts99_s_at_mean_p']:.0f}" if c else ""), flush=True)
+    doc = {"what": __doc__.split("\n\n")[0], "device": torch.cuda.get_device_name(0),
+           "cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+           "cores_visible": len(os.sched_getaffinity(0)), "torch": torch.__version__, "rows": rows}
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(doc, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
