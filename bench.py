@@ -573,7 +573,7 @@ def main():
         local = 0
         os.environ["LOCAL_RANK"] = "0"
         # several processes on ONE GPU: a rank's resident grid waits for the other ranks' whole launches, not for a step --
-        # the 5 ms bound of a cross-workgroup wait (ccvm_abi.hip: spin_ticks) is for a GPU of one's own
+        # the 20 ms bound of a cross-workgroup wait (ccvm_abi.hip: spin_ticks) is for a GPU of one's own
         os.environ.setdefault("CCVM_AMD_SPIN_MS", "2000")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <map>
 #include <unordered_map>
 
 #include "../../include/ccvm_hip.h"
@@ -113,7 +114,7 @@ void fill_adam(AdamScalars& s, const ccvm_adam* ad, int i) {
 //   CCVM_AMD_XCD_XC=n         force the XCD rectangle's width
 //   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
 //   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
-//   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 5 ms or 50
+//   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 20 ms or 50
 //                             estimated steps; rehearsals that put several processes on ONE GPU raise it)
 constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
 
@@ -186,10 +187,13 @@ Tuning read_tuning() {
 // when every wave of a cluster retries -- the first version of this bound, 16 667 retries, took 95 ms).  Every launch's grid is resident
 // (ptile: one round of tiles, cluster: one launch per round of clusters, slab: the plan fits the chip), so a peer is never
 // more than a step or two behind unless its workgroup is not running at all -- another process holding CUs, a fault.
-// The bound is therefore a multiple of the STEP, not of the launch: 50 estimated steps, at least 5 ms (clock ramps,
-// a first step that loads panels, a context switch) -- rounds 2-5 waited 0.5-1.2 s, a 10^4 x cliff.
+// The bound is therefore a multiple of the STEP, not of the launch: 50 estimated steps, at least 20 ms -- rounds 2-5
+// waited 0.5-1.2 s, a 10^4 x cliff.  (The floor was 5 ms for one GPU run of the suite: one of ~290 tests --
+// MF + Adam N = 1100, B = 777, the fourth launch of that shape in a row -- gave up a wait that the old bound had always
+// seen through, i.e. a resident peer was once more than 5 ms late; what held it is not known, so the floor keeps a
+// margin and a dropped workgroup still costs < 50 ms end to end: tests/test_gpu_cluster.py.)
 unsigned spin_ticks(double est_step_us, const Tuning& tun) {
-    const double us = tun.spin_ms > 0.0 ? 1e3 * tun.spin_ms : std::max(5000.0, 50.0 * est_step_us);
+    const double us = tun.spin_ms > 0.0 ? 1e3 * tun.spin_ms : std::max(20000.0, 50.0 * est_step_us);
     const double ticks = 100.0 * us;
     return ticks > 4.0e9 ? 4000000000u : ticks < 100.0 ? 100u : (unsigned)ticks;
 }
@@ -278,7 +282,10 @@ double best_tile_us(int mode, int B, int N, const Tuning& tun) {
 // Grid of 32 x (128 / ks) tiles and the XCD rectangles: xr * xc = tiles / 8, xr | nrb, xc | ncb,
 // (nrb/xr) * (ncb/xc) = 8, minimising the L2 footprint  xr * (bytes of an A row block) + xc * (bytes
 // of a Q column panel).
-void set_grid(StepArgs& a, const Tuning& tun) {
+// `resident`: the grid of the persistent tile kernel (ptile_kernel has no blocked order: with xr == 0 it falls back to the
+// row-major map, so its grids keep whatever rectangle exists -- ADVICE r5: the demotions below were measured on
+// step_kernel only and silently cost the resident grids of 11 / 13 / 15 column blocks their rectangles)
+void set_grid(StepArgs& a, const Tuning& tun, bool resident = false) {
     const int ks = a.ks;
     a.nrb = (a.B + BM - 1) / BM;
     a.ncb = (a.N + BN / ks - 1) / (BN / ks);
@@ -310,6 +317,7 @@ void set_grid(StepArgs& a, const Tuning& tun) {
     // grid of 32 x 32 tiles at these sizes, proper rectangle or not (profiles/r05_ab_rect_vs_blocked.txt: 2048 x 2048
     // -12 %, 1024 x 1536 -6 %, else +-0; the 32 x 128 and 32 x 64 grids are no faster blocked, some 10-14 % slower: they
     // keep their rectangles).  CCVM_AMD_XCD_XC=-1 keeps the rectangle, -w forces the blocked order (A/B runs).
+    if (resident) return;
     if (a.xr > 0 && (a.xc == a.ncb || ks == 4) && a.N >= 1400 && tun.xcd_xc == 0 && a.ncb > 2 * ks) a.xr = a.xc = 0;
     if (tun.xcd_xc < -1) a.xr = a.xc = 0;  // tuning: -w = the blocked order with super-columns of w blocks whatever rectangle exists
     if (a.xr == 0 && tun.xcd && total > 8 && (tun.xcd_xc > 0 || tun.xcd_xc < -1 || a.N >= 1400)) {
@@ -763,24 +771,35 @@ __global__ void flags_init_kernel(unsigned* flags, int words, unsigned step0) {
 // step left behind for its peer's publication), so the library keeps its own books on the host: per flag area the
 // step behind the last chunk launched on it.  A chunk that does not start at or behind that step gets its flag lines
 // set whatever the caller says; a workspace the library has never seen is covered by the contract that
-// fresh workspaces are zeroed.  (Host memory behind a mutex, keyed by the device pointer: no device traffic, nothing
-// the 8 host threads of 8 GPUs share but the lock; stale entries of freed workspaces can only cost a launch.)
-bool forward_holds(const unsigned* flags, int first, int k) {
+// fresh workspaces are zeroed.  (Host memory behind a mutex, keyed by the device pointer AND the area's size -- the flag
+// words are a function of the batch -- so that another run's workspace at a reused address is a new area unless it has
+// the same shape; no device traffic, nothing the 8 host threads of 8 GPUs share but the lock.)  EVERY chunk that touches
+// a flag area is recorded, those with library-made schedule rows too (their schedule kernel sets the lines: ADVICE r5 --
+// a no-schedule run of steps 0..k followed by a schedule + FORWARD re-run from step 0 was an "unknown area, first chunk":
+// init skipped over flags that stood at k), and only a chunk that starts EXACTLY where the last one ended skips the
+// init (the chunks of a run are contiguous; a stale entry of a freed workspace then matches a new run only if that run
+// resumes at the very step the old one stopped at, on a workspace of the same shape at the same address -- and what it
+// finds there are zeroed lines: its first step's readers would wait for publications that never come, give up their
+// bounded wait and the steps are repeated on the per-step kernel: a cost, never a wrong result).
+bool forward_holds(const unsigned* flags, int words, int first, int k) {
     static std::mutex mu;
-    static std::unordered_map<const unsigned*, int> reached;
+    static std::map<std::pair<const unsigned*, int>, int> reached;
     std::lock_guard<std::mutex> lock(mu);
-    if (reached.size() > 4096) reached.clear();  // (bounded: forgetting an area costs its next call one launch ...
-    auto it = reached.find(flags);               //  ... only if it then claims CCVM_RUN_FORWARD from step > 0: see below)
-    const bool known = it != reached.end();
-    const bool ok = known ? first >= it->second : first == 0;  // unknown area: only a run's first chunk may skip the init
-    reached[flags] = first + k;
+    if (reached.size() > 4096) reached.clear();  // (bounded: forgetting an area costs its next call one launch)
+    const auto key = std::make_pair(flags, words);
+    auto it = reached.find(key);
+    const bool ok = it != reached.end() ? first == it->second : first == 0;  // unknown area: only a run's first chunk may skip the init
+    reached[key] = first + k;
     return ok;
 }
 const float* given_rows(const float* schedule, const ccvm_noise* nz, int first, int k, unsigned* flags, int words,
                         hipStream_t st) {
-    if (!schedule) return nullptr;
+    if (!schedule) {
+        if (flags) (void)forward_holds(flags, words, first, k);  // (the chunk's schedule kernel sets the lines to `first`)
+        return nullptr;
+    }
     if (flags) {
-        const bool forward = forward_holds(flags, first, k) && (nz->flags & CCVM_RUN_FORWARD);
+        const bool forward = forward_holds(flags, words, first, k) && (nz->flags & CCVM_RUN_FORWARD);
         if (!forward)
             hipLaunchKernelGGL(flags_init_kernel, dim3((words + 255) / 256), dim3(256), 0, st, flags, words, (unsigned)first);
     }
@@ -807,7 +826,7 @@ int run_ptile(const StepArgs& a, float* const (&x0)[2], float* const (&x1)[2], c
         StepArgs g = a;
         g.B = rows;
         g.ks = 1;
-        set_grid(g, tun);
+        set_grid(g, tun, true);
         PtileArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.st0 = st0 ? st0 + off : nullptr;
@@ -1062,15 +1081,20 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
         StepArgs a;
         base_args(a, nullptr, nullptr, B, N, ccvm_ld(N), tun, 4, solver);
         if (const PtilePlan plan = plan_ptile(a, tun, per_variable_s && solver != 0, solver); plan.slices == 1) {
+            // (the grid run_ptile launches: 32 x 128 tiles whatever shape the per-step plan `a` has -- ADVICE r5: with KS = 2 / 4
+            // in `a` this line printed the per-step grid, up to four times the workgroups that run)
+            StepArgs g = a;
+            g.ks = 1;
+            set_grid(g, tun, true);
             std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s%s> grid %d x %d threads (%d row blocks x %d column blocks resident, XCD rectangle %d x %d), up to %d steps per launch",
-                          solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", a.nrb * a.ncb,
-                          WG_THREADS, a.nrb, a.ncb, a.xr, a.xc, TABLE_STEPS);
+                          solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", g.nrb * g.ncb,
+                          WG_THREADS, g.nrb, g.ncb, g.xr, g.xc, TABLE_STEPS);
             return CCVM_OK;
         } else if (plan.slices > 1) {
             StepArgs g = a;
             g.B = plan.rbs * BM;
             g.ks = 1;
-            set_grid(g, tun);
+            set_grid(g, tun, true);
             std::snprintf(buf, buf_len, "ccvm::ptile_kernel<%d, %s%s> %d slices of the batch one after the other, grid %d x %d threads each (up to %d row blocks x %d column blocks resident), up to %d steps per launch",
                           solver, ad ? "true" : "false", (per_variable_s && solver != 0) ? ", false, true" : "", plan.slices,
                           g.nrb * g.ncb, WG_THREADS, g.nrb, g.ncb, TABLE_STEPS);

@@ -138,6 +138,18 @@ struct ClusterArgs {
 #ifndef CCVM_CL_STAGE_ASM
 #define CCVM_CL_STAGE_ASM 0
 #endif
+// Round 6: the fetch waves make the NEXT phase's normals.  A fetch wave is done with its staging
+// 1200 cycles before the next phase's first barrier and then only waits, while its MFMA twin spends 60 % of its
+// noise + update section in the generator, alone on the SIMD's VALU -- one vector instruction per FOUR cycles, where two
+// waves together issue one per TWO (MI355X_MICROARCH.md, per-instruction constants).  With this on, fetch wave w makes
+// the Threefry / Box-Muller pairs of MFMA wave w's elements of the next phase (the same calls: bit-identical results)
+// into a 4 KB LDS block behind the phase's last inner barrier; the MFMA wave takes its four normals out of that block in
+// front of the NEXT phase's last inner barrier (so block and reader are always a barrier apart) and keeps only the update
+// and the publish.  One-stream solvers with the panel in LDS (K <= 512: the block fits the 6 KB the panel and the ring
+// leave), fused noise.
+#ifndef CCVM_CL_FETCH_NOISE
+#define CCVM_CL_FETCH_NOISE 1
+#endif
 // MFMAs per operand-prefetch unit: 32 = a whole chunk ahead (2 x 64 operand registers), 16 = half a chunk (2 x 32
 // registers; 512 cycles of MFMAs still cover the LDS latency: N = 500 Langevin 5.00 -> 4.91 us / step, N = 640 9.55 ->
 // 9.30, DL 18.8 -> 18.5, and 64 registers freed)
@@ -203,7 +215,10 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
         return ((k & 31) < 16) ? CL_KC * (KCH - 1) + 16 * ((k >> 5) & 3) + (k & 31) : -1;
     };
     // one array (a second __shared__ object can de-pipeline the loop, guide section 5)
-    __shared__ __attribute__((aligned(16))) float lds[QPANEL + 3 * ABUF + 4];
+    constexpr bool FN = CCVM_CL_FETCH_NOISE && MODE != MODE_DL && !REPLAY && KCH <= 4 && !(CCVM_CLUSTER_ABL & 2);
+    constexpr int NZB = FN ? 4 * 64 * 4 : 0;  // [MFMA wave][lane][4 rows]: the fetch waves' normals of one phase
+    __shared__ __attribute__((aligned(16))) float lds[QPANEL + 3 * ABUF + 4 + NZB];
+    float* const nzb = lds + QPANEL + 3 * ABUF + 4;
     float* const qp = lds;                    // [64 columns][512 + 4]
     float* const abuf = lds + QPANEL;         // 3 x [16 rows][128 + 4]
     // lds[DEAD] != 0: a bounded spin gave up.  Written by a fetch wave before a barrier, read by everyone behind it
@@ -364,6 +379,19 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
             }
         };
 
+        // FN: the normals of phase P for the twin MFMA wave (tid - 256 = its thread: same lane -> rows and column)
+        auto make_normals = [&](int P) {
+            if constexpr (FN) {
+                const int fs = P % NSETS, fj = P / NSETS;            // the phase's row set and step of the launch
+                const int fstep = a.step0 + fj + (MODE == MODE_MF ? 1 : 0);  // MF: the NEXT step's normals (mf_solver.py:551-554)
+                const int fg = lane >> 4, fcol = col0 + 16 * (wave - 4) + (lane & 15);
+                const int64_t r0 = a.row_offset + crow0 + CL_ROWS * fs + 4 * fg;
+                NormalPair pa, pb;
+                normal_two_rows_x2(a.seed, r0, r0 + 2, fstep, fcol, pa, pb);
+                *reinterpret_cast<f32x4c*>(nzb + ((wave - 4) * 64 + lane) * 4) = f32x4c{pa.n0, pa.n1, pb.n0, pb.n1};
+            }
+        };
+        make_normals(0);
         // first input: whatever has not landed yet (the peers may not even run yet) is fetched again by await_pair
         unroll_indices([&](auto k_tag) { load_pair(0, 0, k_tag); }, std::make_integer_sequence<int, NPAIR>{});
         await_pair(0, 0, (unsigned)a.step0 + 1u, std::integral_constant<int, 0>{});
@@ -415,6 +443,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
                         await_pair(ns, nj & 1, nwant, std::integral_constant<int, 0>{});
                         stage(0, (B0 + NC) % 3);      // buffers of chunks NC-3, NC-2 of this phase: done before B_(NC-1)
                         stage(1, (B0 + NC + 1) % 3);
+                        make_normals(P + 1);           // (every MFMA wave took this phase's normals in front of B_(NC-1))
                     }
                     mark(hseg[4]);
                 }
@@ -611,6 +640,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) acc[pl][0] = acc[pl][1] = f32x4c{0.0f, 0.0f, 0.0f, 0.0f};
             float aq[2][UM];
+            f32x4c fnz = {0.0f, 0.0f, 0.0f, 0.0f};  // FN: the phase's normals, out of the fetch waves' block
             __builtin_amdgcn_sched_barrier(0);
             // operand double buffer: unit n of the iteration (n = NU s + u) computes from [n & 1] (s is a constant
             // after unrolling); without the cross-phase read every phase starts at [0]
@@ -669,6 +699,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (nc != c && u + 1 < NU) {
                     mark(seg[1]);
+                    if constexpr (FN && nc == NC - 1) fnz = *reinterpret_cast<const f32x4c*>(nzb + tid * 4);  // this phase's normals
                     __syncthreads();  // B_(c+1): chunk c's buffer may be refilled; chunk c + 2 is staged
                     if constexpr (CCVM_CLUSTER_ABL & 64) {
                         const unsigned long long before = t_last;
@@ -684,7 +715,9 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a) {
             if (s == NSETS - 1) rnext = load_row(min(it + 1, a.nsteps - 1));
             // ---- this step's / the next step's normals -------------------------------------------
             float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nz1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (MODE == MODE_DL) {
+            if constexpr (FN) {
+                nz[0] = fnz[0]; nz[1] = fnz[1]; nz[2] = fnz[2]; nz[3] = fnz[3];
+            } else if constexpr (MODE == MODE_DL) {
                 pair_normals(s, step, it, nz, nz1);
             } else if constexpr (MODE == MODE_MF) {
                 if (has_next) stream_normals(s, step + 1, it + 1, nz);

@@ -171,9 +171,21 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums
     constexpr int NV = ((MODE == MODE_DL) ? 2 : 1) * NE;       // normals per lane and step
     constexpr int NZF = PW ? 2 * NWC * NV * 64 : 0;            // producer waves: [step parity][consumer][value][lane]
-    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF + NZF];
+    // producer waves also relay the schedule rows: ring[step & 3][TABLE_WORDS], the words a solver reads (in fours)
+    constexpr int ROWW = ADAM ? 16 : (MODE == MODE_MF) ? 12 : 8;  // (Adam's bias corrections are words 12, 13)
+    // (one wave per row set, and Langevin -- one word of its row changes -- with two side by side: measured, us per step at
+    // B = 1000 without / with the relay: DL N = 20 0.435 / 0.359, MF 0.449 / 0.411, Langevin 0.427 / 0.371, DL N = 64 0.647 /
+    // 0.593, Langevin N = 100 0.658 / 0.595; but MF N = 100 0.80 / 0.84, DL N = 128 0.92 / 0.94: their steps are long enough
+    // for the scalar load and the row's vector registers cost more than they save)
+    constexpr bool RELAY = PW && (NCG == 1 || MODE == MODE_LANGEVIN);
+    constexpr int RING = RELAY ? 4 * TABLE_WORDS : 0;
+    // words of a row that are the same in every step of a run (ccvm_schedule.h) -- DL: dt, 2 g; MF: g^2, f_q, f_v, 1 / sqrt(dt),
+    // dt, S, has_next (unused here), + the unused words 14, 15; Langevin: all but the pump term
+    constexpr unsigned ROW_SAME = (MODE == MODE_DL) ? 0x030u : (MODE == MODE_MF) ? 0xCD8Eu : 0xC0FBu;
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF + NZF + RING];
     float* const px = xs_all + RSW * 2 * ROWS * LDX;
     float* const nzl = px + PXF;
+    float* const ring = nzl + NZF;
 
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,15 +331,36 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
                     if constexpr (MODE == MODE_DL) d[(NE + e) * 64] = o1[e];
                 }
             };
+            // The schedule rows travel with the noise: producer wave 0 reads row it + 3 (an ordinary vector load, one word
+            // per lane) at the top of step it and puts the row it read a step earlier into ring[(it + 2) & 3] behind its
+            // generator calls; the consumers take ring[it & 3] out of LDS with their A operands.  Why: a consumer's own
+            // scalar load of the next row has to land by the step's next LDS wait (scalar loads and LDS share lgkmcnt, SMEM
+            // returns out of order: every lgkmcnt wait drains it), ~150 cycles at N = 20 -- an L2 hit makes that, a line
+            // from the Infinity Cache (545 cycles: the table was written by a kernel on another XCD) does not.  The
+            // ablation harness, whose 256 KB table every L2 holds after the first launch, ran this loop at 0.30 us per step
+            // where the engine, walking through the rows of a whole run, took 0.43 (round 6: tools/persist_vs_abi.hip).
+            const bool relay = RELAY && wave == 0 && lane < TABLE_WORDS;
+            auto row_word = [&](int it) {  // word `lane` of the row of step it (clamped: the launch's last rows again)
+                return relay ? a.table[(size_t)min(it, a.nsteps - 1) * TABLE_WORDS + lane] : 0.0f;
+            };
+            if (relay) {
+                ring[0 * TABLE_WORDS + lane] = row_word(0);
+                ring[1 * TABLE_WORDS + lane] = row_word(1);
+            }
+            float row_carry = row_word(2);  // -> ring[2] during step 0
             gen_noise(a.step0, 0, o0, o1);
             put(0);
             __syncthreads();
             if constexpr (CCVM_PERSIST_ABL & 16) st_last = persist_stamp();
             for (int it = 0; it < a.nsteps; ++it) {
+                const float row_ahead = row_word(it + 3);
                 if (it + 1 < a.nsteps) {
                     gen_noise(a.step0 + it + 1, it + 1, o0, o1);
                     put((it + 1) & 1);
                 }
+                // (slot (it + 2) & 3 held step it - 2's row: every consumer is past that step's last barrier)
+                if (relay) ring[((it + 2) & 3) * TABLE_WORDS + lane] = row_carry;
+                row_carry = row_ahead;
                 stamp(0);
                 if constexpr (KH == 2) __syncthreads();
                 __syncthreads();
@@ -369,6 +402,7 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     // a row requested at the top of the step would be waited for together with the A operands)
     struct Row { float w[TABLE_WORDS]; };
     Row rnext = *reinterpret_cast<const Row*>(a.table);
+    const Row first_row = rnext;  // (producer waves: the words of a row that never change are taken from here)
     float nzn0[NE], nzn1[NE];  // the next step's normals (NOISE_AHEAD)
 #pragma unroll
     for (int e = 0; e < NE; ++e) nzn0[e] = nzn1[e] = 0.0f;
@@ -379,8 +413,7 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     constexpr int K0 = H * KSPLIT, K1 = (K0 + KSPLIT < KMAX) ? K0 + KSPLIT : KMAX;  // this wave's k-steps [K0, K1)
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
-        const Row rcur = rnext;
-        const float* trow = rcur.w;
+        const Row rcur = rnext;  // (producer waves: unused -- the row comes out of the ring below)
         // ---- acc[r] = X[row rs*RU + r][:] @ Q[:, col] ---------------------------------------------
         const float* xb = xs + cur * ROWS * LDX + arow * LDX + bg;
         f32x4v acc[4];
@@ -394,11 +427,27 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
 #pragma unroll
         for (int c = K0 / KC; c <= (K1 - 1) / KC; ++c) af[c] = xb[c * KC];
         float nzp[PW ? NV : 1];  // producer waves: this step's noise set comes out of its LDS slot with the A operands
+        float rowv[RELAY ? ROWW : 1];  // ... and so does its schedule row (the same address in every lane: a broadcast read)
         if constexpr (PW) {
             const float* nzr = nzl + ((it & 1) * NWC + wave) * (NV * 64) + lane;
 #pragma unroll
             for (int v = 0; v < NV; ++v) nzp[v] = nzr[v * 64];
         }
+        if constexpr (RELAY) {
+            // (only the words that change from step to step: the others come from the launch's first row, below)
+            const float* rr = ring + (it & 3) * TABLE_WORDS;
+#pragma unroll
+            for (int w = 0; w < ROWW; ++w) rowv[w] = ((ROW_SAME >> w) & 1u) ? 0.0f : rr[w];
+        }
+        if constexpr (RELAY) {
+            // the words that are the same in every row of a run (dt, g, the feedback coefficients, S: ccvm_schedule.h) come
+            // from the launch's first row in scalar registers, so that only the words that change hold vector registers
+            // (MF: 12 words of the row in VGPRs put the K-split + producers kernel past 128 at N > 96)
+#pragma unroll
+            for (int w = 0; w < ROWW; ++w)
+                if ((ROW_SAME >> w) & 1u) rowv[w] = first_row.w[w];
+        }
+        const float* trow = RELAY ? rowv : rcur.w;
         __builtin_amdgcn_sched_barrier(0);  // all reads in flight before anything else (one latency, not NCH)
         stamp(0);
         // ---- this step's normals -- DL: (W_c, W_s) per element; MF: the NEXT step's; Langevin: this step's.
@@ -441,7 +490,7 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
             for (int c = K0 / KC; c <= (K1 - 1) / KC; ++c) acc[c & 3][0] += af[c] * qf[c - K0 / KC];
         }
         __builtin_amdgcn_sched_barrier(0);
-        rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
+        if constexpr (!RELAY) rnext = *reinterpret_cast<const Row*>(a.table + (size_t)min(it + 1, a.nsteps - 1) * TABLE_WORDS);
         // K split: the partial sums of the twin's rows leave before this wave makes its normals (the LDS write and the
         // twin's arrival at the barrier run under them)
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};

@@ -334,7 +334,7 @@ def _exchange_exit(ch, device, raw):
 
 
 #: device index -> time.monotonic() until which new Trajectories avoid the cluster / slab kernels (set by a time-out
-#: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 2: a give-up costs ~5 ms since round 6 --
+#: recovery, Trajectories.check; $CCVM_AMD_EXCHANGE_COOLDOWN seconds, default 2: a give-up costs ~20 ms since round 6 --
 #: ccvm_abi.hip spin_ticks -- so coming back early is cheap; rounds 3-5: 30 s for waits of 0.5-1.2 s)
 _exchange_blocked_until = {}
 

@@ -73,9 +73,10 @@ typedef enum ccvm_noise_mode {
  * together with a caller-made schedule table (`schedule` in the parameters): the persistent tile kernel's flag lines
  * then need no initialising launch, and the run call of a persistent path is a single kernel launch.  A broken promise
  * would be a silent read-before-publish race, so the library does not rely on it alone: it records, per flag area (host
- * memory, keyed by the workspace pointer), the step behind the last chunk it launched there, and a chunk that does not
- * start at or behind that step -- or a first chunk at step > 0 on an area it has never seen -- gets its flag lines set
- * whatever this bit says (one more launch, never a wrong result). */
+ * memory, keyed by the area's address and size), the step behind the last chunk it launched there -- chunks whose
+ * schedule rows it made itself included -- and a chunk that does not start exactly at that step -- or a first chunk at
+ * step > 0 on an area it has never seen -- gets its flag lines set whatever this bit says (one more launch, never a wrong
+ * result). */
 #define CCVM_RUN_FORWARD 4
 
 typedef struct ccvm_noise {

@@ -320,7 +320,7 @@ def test_bounded_waits_give_up_instead_of_hanging(monkeypatch):
 @pytest.mark.parametrize("kind,n,b,family", [("dl", 1000, 1000, "ptile"), ("mf", 500, 1000, "cluster"),
                                              ("langevin", 500, 1000, "cluster"), ("dl", 1000, 32, "slab")])
 def test_a_dropped_workgroup_costs_milliseconds(monkeypatch, kind, n, b, family):
-    """the bound of a cross-workgroup wait is a multiple of the STEP (50 estimated steps, at least 5 ms:
+    """the bound of a cross-workgroup wait is a multiple of the STEP (50 estimated steps, at least 20 ms:
     ccvm_abi.hip spin_ticks), not the 0.5-1.2 s of rounds 2-5.  Fault injection at the BASELINE shapes, end to end --
     launch with 8 workgroups missing, give-up, status word to the host, snapshot restored, the 20 steps again on the
     per-step kernel, verified: under 50 ms."""
@@ -337,12 +337,16 @@ def test_a_dropped_workgroup_costs_milliseconds(monkeypatch, kind, n, b, family)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     traj.advance(20)
+    t_launched = time.perf_counter() - t0
+    torch.cuda.synchronize()               # (the faulty launch has ended: its waves gave up)
+    t_kernel = time.perf_counter() - t0
     with pytest.warns(RuntimeWarning, match="timed out waiting for its workgroups"):
-        assert traj.check() is True
+        assert traj.check() is True       # status word -> restore -> the 20 steps again on the per-step kernel -> verified
     torch.cuda.synchronize()
     cost = time.perf_counter() - t0
     assert traj.fallbacks == 1 and torch.equal(traj.compact(name).cpu(), want)
-    assert cost < 0.05, f"{family}: a dropped workgroup cost {cost * 1e3:.1f} ms"
+    assert cost < 0.05, (f"{family}: a dropped workgroup cost {cost * 1e3:.1f} ms (launch call {t_launched * 1e3:.1f} ms, "
+                         f"faulty kernel ended at {t_kernel * 1e3:.1f} ms)")
 
 
 def test_a_batch_of_several_rounds_is_one_launch_per_round(monkeypatch):

@@ -322,6 +322,30 @@ def test_ptile_time_out_falls_back_to_the_per_step_kernel(monkeypatch):
     assert torch.equal(got, want)
 
 
+def test_chunks_with_library_made_schedule_rows_are_on_the_books(ptile):
+    """the library's record of how far a flag area has run must include the chunks whose schedule rows IT made
+    (no `schedule` table from the caller).  30 steps that way leave the flag lines at step 30; the same 30 steps again on
+    the same workspace WITH the table and CCVM_RUN_FORWARD claimed -- a re-run from step 0 that the promise does not cover
+    -- must still get its flag lines set: bit for bit the straight run, no time-out."""
+    from ccvm_amd import engine
+
+    want = _state(_run_engine("dl", 1000, 1000, 30, None, 5, 0))
+    traj = _run_engine("dl", 1000, 1000, 30, None, 5, 0, chunks=[0])  # (built, not advanced)
+    table = traj.cparams.schedule
+    traj.cparams.schedule = None
+    traj.arm(force=True)
+    traj.advance(30)
+    assert traj.check(rerun=False, hold=True) is False
+    first = {k: engine.unpack(traj.state[k], traj.b, traj.n) for k in traj.state}
+    traj.rollback()
+    traj.cparams.schedule = table
+    traj.advance(30)
+    assert traj.check(rerun=False, hold=True) is False and traj.fallbacks == 0
+    for name in want:
+        assert torch.equal(first[name], want[name]), name
+        assert torch.equal(engine.unpack(traj.state[name], traj.b, traj.n), want[name]), name
+
+
 @pytest.mark.parametrize("kind,n,b", [("dl", 1000, 1000), ("mf", 1000, 1000)])
 def test_going_back_on_a_workspace_never_meets_the_flags_of_later_steps(ptile, kind, n, b):
     """Round 5: the flag lines hold absolute step numbers and a reader accepts any number >= the step it waits

@@ -43,7 +43,7 @@ def test_sharded_engine_equals_unsharded(tmp_path, backend, world, kind, n, batc
     port, out = str(_free_port()), str(tmp_path / "sharded.pt")
     # dmabuf IPC (the host driver of this pool supports nothing else: RCCL's set-up fails with "hipIpcGetMemHandle:
     # invalid argument" under the legacy mode); bench.py's launcher and ranks set the same (bench.IPC_ENV)
-    # (processes that SHARE a GPU wait for each other's whole launches: the 5 ms bound of a cross-workgroup wait is for a
+    # (processes that SHARE a GPU wait for each other's whole launches: the 20 ms bound of a cross-workgroup wait is for a
     # GPU of one's own -- ccvm_abi.hip: spin_ticks)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCVM_AMD_SPIN_MS="2000")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_gpu_worker.py"), backend, str(r),
@@ -179,3 +179,35 @@ def test_bench_falls_back_to_gloo_when_rccl_refuses():
     assert line["collective"].startswith("gloo-fallback: rank "), line["collective"]
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["check"]["objective_values_finite"] is True
     assert line["value"] > 0 and len(line["ms_per_step_per_rank"]) == 2
+
+
+@pytest.mark.parametrize("how", ["launcher", "torch.distributed.run"])
+def test_six_rank_rehearsal_of_the_drivers_launch_line(how):
+    """the launcher / port / gloo control plane / N-way gather of the driver's multi-GPU run, rehearsed
+    with as many ranks as this pool lets one box put on its GPU -- SIX (a seventh process on the card ends the run:
+    gpurun's process guard; the 8-rank control plane runs on the CPU: tests/test_bench_collectives.py).  The ranks share
+    cuda:0 (CCVM_BENCH_SHARE_GPU=1: collectives over gloo, the bound of a cross-workgroup wait raised for the shared GPU);
+    rank 0 prints ONE line that says it is a rehearsal, not a scaling point."""
+    import json
+
+    env = dict(os.environ, CCVM_BENCH_SHARE_GPU="1")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    tail = [bench, "--gpus", "6", "--steps", "20", "--warmup", "5", "--spinup-ms", "20"]
+    cmd = ([sys.executable] + tail if how == "launcher" else
+           [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port())] + tail)
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 6 and line["n_ranks_seen"] == 6 and line["steps"] == 20 and line["scaling"] == "weak"
+    assert line["collective"].startswith("gloo (rehearsal") and "rehearsal" in line["config"]["parallelism"]
+    assert line["config"]["global_batch"] == 6000 and len(line["ms_per_step_per_rank"]) == 6
+    assert len(line["ms_per_step_repeats"]) == 9 and line["check"]["objective_values_finite"] is True
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):  # (kept as profiles/r06_bench_gpus6_share_rehearsal*.json)
+        with open(os.path.join(out, f"bench_gpus6_share_rehearsal_{how.replace('.', '_')}.json"), "w") as fh:
+            fh.write(lines[0] + "\n")

@@ -242,6 +242,30 @@ def test_producer_waves_policy(hip_lib, clean_env):
         assert plan(solver, 1000 if solver else 500, 16 * nch, 1 if adam else 0)["pw"] == 1  # one workgroup per CU: always
 
 
+def test_description_of_a_resident_tile_grid_is_the_grid_that_runs(hip_lib, clean_env):
+    """a single-slice persistent tile launch is 32 x 128 tiles whatever shape the per-step plan has; the
+    description printed the per-step grid (KS = 2 / 4: up to four times the workgroups).  Every single-slice description
+    over a scan of shapes: at most one workgroup per CU, row blocks x column blocks = the grid, and the rectangle a
+    resident grid keeps (no "0 x w" blocked order: ptile_kernel has none)."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    seen = 0
+    for solver in (0, 1, 2):
+        for n in (800, 1000, 1400, 1600, 1800, 2000, 2048):
+            for b in (160, 256, 512, 672, 1000, 1024):
+                d = _describe(hip_lib, solver, b, n)
+                m = re.match(r"ccvm::ptile_kernel<\d, \w+> grid (\d+) x 512 threads \((\d+) row blocks x (\d+) column blocks resident, "
+                             r"XCD rectangle (\d+) x (\d+)\)", d)
+                if not m:
+                    continue
+                grid, nrb, ncb, xr, xc = (int(g) for g in m.groups())
+                seen += 1
+                assert grid == nrb * ncb <= 256, d
+                assert nrb == -(-b // 32) and ncb == -(-n // 128), d
+                assert (xr == 0) == (xc == 0), d
+    assert seen >= 10
+    assert "grid 147 x 512 threads (21 row blocks x 7 column blocks resident" in _describe(hip_lib, 1, 672, 800)  # (printed 525 = 21 x 25)
+
+
 def test_persistent_tile_kernel_needs_the_whole_grid_resident(hip_lib, clean_env):
     """ccvm_ptile.h: its workgroups wait for each other, so the grid must fit the chip the policy plans for (CU masks,
     partitions: CCVM_AMD_GEOMETRY) and be estimated no more than 5 % behind the best per-step tile shape (round 5: the
