@@ -147,8 +147,17 @@ struct ClusterArgs {
 // front of the NEXT phase's last inner barrier (so block and reader are always a barrier apart) and keeps only the update
 // and the publish.  One-stream solvers with the panel in LDS (K <= 512: the block fits the 6 KB the panel and the ring
 // leave), fused noise.
+// MEASURED AND LEFT OFF (same-box A/B of the library, profiles/r06_ab_fetch_noise.txt; stamps:
+// profiles/r06_cluster_fetch_noise.txt, tools/cluster_fetch_noise.sh): Langevin N = 500, B = 1000 4.85 -> 5.04 us per step, MF
+// 5.03 -> 5.09, Langevin N = 300 3.36 -> 3.57; results bit-identical (tests/test_gpu_cluster.py green either way).  Per
+// phase the MFMA wave's noise + update section shrinks by 637 cycles (1364 -> 727; MF 1794 -> 928), but the fetch wave's
+// "check pair 0 + stage + normals" grows by 865 (1195 -> 2060) -- 6.6 cycles per generator instruction although its twin
+// runs its own ~120 update / publish instructions in the same window: the two waves of a SIMD issued one VALU instruction
+// per ~4 cycles BETWEEN them, not one per 2 -- and the MFMA waves now wait for it at the next phase's first barrier (236
+// -> 628 cycles) and lose 85 cycles of matrix time to its first instructions.  A sibling's VALU work is paid at full
+// price on this chip; it can only shrink.
 #ifndef CCVM_CL_FETCH_NOISE
-#define CCVM_CL_FETCH_NOISE 1
+#define CCVM_CL_FETCH_NOISE 0
 #endif
 // MFMAs per operand-prefetch unit: 32 = a whole chunk ahead (2 x 64 operand registers), 16 = half a chunk (2 x 32
 // registers; 512 cycles of MFMAs still cover the LDS latency: N = 500 Langevin 5.00 -> 4.91 us / step, N = 640 9.55 ->

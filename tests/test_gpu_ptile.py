@@ -374,3 +374,33 @@ def test_going_back_on_a_workspace_never_meets_the_flags_of_later_steps(ptile, k
         got = logical()
         for name in want:
             assert torch.equal(got[name], first[name]) and torch.equal(got[name], want[name]), (again, name)
+
+
+def test_sc1_lds_dma_stress(tmp_path):
+    """The hand-off form of this kernel -- drained `sc1` stores, `sc1` flag, `sc1` poll, `global_load_lds_dwordx4 ... sc1` --
+    under the guide's stress recipe (MI355X_MICROARCH.md: "test every hand-off under UNEVEN load, consumer L1-warm, checking
+    every word"; its table of measured forms lists register loads only): tools/ptile_sc1_stress.hip, 256 workgroups each
+    producer and consumer of 4 KB payloads, consumers re-reading the slots with plain loads between hand-offs, a bandwidth
+    hog on a second stream, pairs inside an XCD and across the fabric.  No wrong word; the control (plain LDS-DMA) must
+    show stale words, or the stress would prove nothing.  (profiles/r06_ptile_sc1_stress.txt: the 4096-epoch run.)"""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ptile_sc1_stress")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", os.path.join(root, "tools", "ptile_sc1_stress.hip"),
+                    "-o", exe], check=True, timeout=300)
+    run = subprocess.run([exe, "2048"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "PASSED" in run.stdout, run.stdout[-3000:] + run.stderr[-1000:]
+    rows = [ln for ln in run.stdout.splitlines() if "hand-offs" in ln]
+    assert len(rows) == 8
+    for ln in rows:
+        wrong, gave_up = int(re.search(r"(\d+) wrong", ln).group(1)), int(re.search(r"(\d+) give-ups", ln).group(1))
+        assert gave_up == 0, ln
+        if ln.startswith("CONTROL"):
+            assert wrong > 0, ln          # plain LDS-DMA reads this CU's stale L1 lines
+        else:
+            assert wrong == 0 and "524288 hand-offs" in ln, ln
+    assert sum("256 pairs inside an XCD" in ln for ln in rows) == 4 and sum("256 across" in ln for ln in rows) == 4

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
 #endif
     ClusterArgs a; memset(&a, 0, sizeof(a));
     a.Q = Q; a.V = V; a.qsum = V; a.x0 = c; a.x1 = c2; a.xb0 = xb0; a.xb1 = xb1; a.table = table; a.seed = 7; a.nsteps = steps;
-    a.status = sync; a.spin_limit = 200000000u;
+    a.status = sync; a.spin_limit = getenv("CL_SPIN") ? (unsigned)atoi(getenv("CL_SPIN")) : 200000000u;  // ticks of 100 MHz
     a.B = B; a.N = N; a.ld = ld; a.in_scale = 1.0f; a.in_shift = 0.5f;
     a.k_first = 4.47f; a.S = 20.0f;  // MF only: sqrt(1 / (4 j)) / sqrt(dt), the measured amplitude's clamp
     const int crows = ld > 512 ? 48 : 32;  // three row sets above K = 512
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned st; hipMemcpy(&st, sync, 4, hipMemcpyDeviceToHost);
+        if (rep == 2 && getenv("CL_DROP")) printf("   (launch with 8 workgroups missing: %.1f ms end to end)\n", ms);
         if (rep == 2) printf("%s ABL=%2d N=%d B=%d grid %d: %.3f us/step%s\n", MODE == MODE_DL ? "DL" : MODE == MODE_MF ? "MF" : "LV", CCVM_CLUSTER_ABL, N, B, grid, ms * 1e3 / steps, st ? "  (SPIN LIMIT HIT)" : "");
     }
     if (CCVM_CLUSTER_ABL & 64) {

@@ -1,22 +1,39 @@
 #!/bin/bash
-# Copy the summaries of tools/profile_round.sh (+ the bench lines in gpurun_out/) into profiles/ (developer tool).
-#   usage: tools/collect_profiles.sh r03
-TAG=${1:-r05}; P=gpurun_out/prof
-for w in pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32; do cp $P/${w}_stats/s_kernel_stats.csv profiles/${TAG}_${w}_kernel_stats.csv; done
+# Copy the summaries of tools/profile_round.sh (+ the bench lines of tools/bench_round.sh in gpurun_out/) into profiles/
+# (developer tool).    usage: tools/collect_profiles.sh r06
+TAG=${1:-r06}; P=gpurun_out/prof
+STATS="pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000"
+for w in $STATS; do [ -f $P/${w}_stats/s_kernel_stats.csv ] && cp $P/${w}_stats/s_kernel_stats.csv profiles/${TAG}_${w}_kernel_stats.csv; done
 cp $P/dl_n1000_b1000_stats/s_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
-CMD='rocprofv3 --pmc <counter set> --kernel-trace --output-format csv -- python3 bench.py --workload W --steps 40 --warmup 5 [persistent kernels: --steps 1000 --warmup 200] --spinup-ms 0 --no-cpu-baseline (one pass per counter set: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*; tools/profile_round.sh)'
-python tools/pmc_summary.py --kernel 'ptile_kernel<0' --steps-per-dispatch 600 --name 'ccvm::ptile_kernel<0> = DL, N=1000, B=1000 (headline; one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n1000_b1000}" --out profiles/${TAG}_bench_pmc.json $P/dl_n1000_b1000_pmc_fetch $P/dl_n1000_b1000_pmc_write $P/dl_n1000_b1000_pmc_sq1 $P/dl_n1000_b1000_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'ptile_kernel<2' --steps-per-dispatch 600 --name 'ccvm::ptile_kernel<2> = pumped Langevin, N=2000, B=512 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/pl_n2000_b512}" --out profiles/${TAG}_pl_n2000_b512_pmc.json $P/pl_n2000_b512_pmc_fetch $P/pl_n2000_b512_pmc_write $P/pl_n2000_b512_pmc_sq1 $P/pl_n2000_b512_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'cluster_kernel<2' --steps-per-dispatch 600 --name 'ccvm::cluster_kernel<2, false, 4, false> = Langevin, N=500, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/langevin_n500_b1000}" --out profiles/${TAG}_langevin_n500_b1000_pmc.json $P/langevin_n500_b1000_pmc_fetch $P/langevin_n500_b1000_pmc_write $P/langevin_n500_b1000_pmc_sq1 $P/langevin_n500_b1000_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'cluster_kernel<1' --steps-per-dispatch 600 --name 'ccvm::cluster_kernel<1, false, 4, false> = MF, N=500, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/mf_n500_b1000}" --out profiles/${TAG}_mf_n500_b1000_pmc.json $P/mf_n500_b1000_pmc_fetch $P/mf_n500_b1000_pmc_write $P/mf_n500_b1000_pmc_sq1 $P/mf_n500_b1000_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'persist_kernel<0, false, 64, 2, 7, 4, 2>' --steps-per-dispatch 600 --name 'ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2> = DL, N=100, B=1000 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n100_b1000}" --out profiles/${TAG}_dl_n100_b1000_pmc.json $P/dl_n100_b1000_pmc_fetch $P/dl_n100_b1000_pmc_write $P/dl_n100_b1000_pmc_sq1 $P/dl_n100_b1000_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'slab_kernel<0, 8, 128' --steps-per-dispatch 600 --name 'ccvm::slab_kernel<0, 8, 128> = DL, N=1000, B=32 (one launch per chunk of steps: 200 and 1000 steps here)' --command "${CMD/W/dl_n1000_b32}" --out profiles/${TAG}_dl_n1000_b32_pmc.json $P/dl_n1000_b32_pmc_fetch $P/dl_n1000_b32_pmc_write $P/dl_n1000_b32_pmc_sq1 $P/dl_n1000_b32_pmc_tcc > /dev/null
-python tools/pmc_summary.py --kernel 'step_kernel<0, false, 0, 4' --name 'ccvm::step_kernel<0, false, 0, 4, false, 0> = DL step, N=1000, B=256 (32 x 32 split-K tiles)' --command "${CMD/W/dl_n1000_b256}" --out profiles/${TAG}_dl_n1000_b256_pmc.json $P/dl_n1000_b256_pmc_fetch $P/dl_n1000_b256_pmc_write $P/dl_n1000_b256_pmc_sq1 $P/dl_n1000_b256_pmc_tcc > /dev/null
+CMD='rocprofv3 --pmc <counter set> --kernel-trace --output-format csv -- python3 bench.py --workload W --steps 40 --warmup 5 [persistent kernels: --steps 1000 --warmup 200] --repeats 1 --spinup-ms 0 --no-cpu-baseline (one pass per counter set: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*; tools/profile_round.sh)'
+pmc() {  # workload, output stem, kernel substring, steps per dispatch, description
+  local w=$1 stem=$2 k=$3 spd=$4 name=$5
+  [ -d $P/${w}_pmc_sq1 ] || return 0
+  python tools/pmc_summary.py --kernel "$k" --steps-per-dispatch $spd --name "$name" --command "${CMD/W/$w}" --out profiles/${TAG}_${stem}_pmc.json $P/${w}_pmc_fetch $P/${w}_pmc_write $P/${w}_pmc_sq1 $P/${w}_pmc_tcc > /dev/null
+}
+PERS='(one launch per chunk of steps: 200 and 1000 steps here)'
+pmc dl_n1000_b1000 bench 'ptile_kernel<0' 600 "ccvm::ptile_kernel<0> = DL, N=1000, B=1000 (headline; $PERS)"
+pmc pl_n2000_b512 pl_n2000_b512 'ptile_kernel<2' 600 "ccvm::ptile_kernel<2> = pumped Langevin, N=2000, B=512 $PERS"
+pmc langevin_n500_b1000 langevin_n500_b1000 'cluster_kernel<2' 600 "ccvm::cluster_kernel<2, false, 4, false> = Langevin, N=500, B=1000 $PERS"
+pmc mf_n500_b1000 mf_n500_b1000 'cluster_kernel<1' 600 "ccvm::cluster_kernel<1, false, 4, false> = MF, N=500, B=1000 $PERS"
+pmc dl_n100_b1000 dl_n100_b1000 'persist_kernel<0, false, 64, 2, 7, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2, 1> = DL, N=100, B=1000: K split + noise producer waves $PERS"
+pmc dl_n70_b1000 dl_n70_b1000 'persist_kernel<0, false, 64, 2, 5, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 5, 4, 2, 1> = DL, N=70, B=1000: K split + noise producer waves $PERS"
+pmc dl_n20_b1000 dl_n20_b1000 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (tuningH020-100-0), B=1000: one wave per row set + noise producer waves $PERS"
+pmc dl_n20_b100 dl_n20_b100 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (test020-100-10), B=100: BASELINE config 1 $PERS"
+pmc mf_n20_b1000 mf_n20_b1000 'persist_kernel<1, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<1, false, 32, 1, 2, 2, 1, 1> = MF, N=20, B=1000 $PERS"
+pmc langevin_n20_b1000 langevin_n20_b1000 'persist_kernel<2, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<2, false, 32, 1, 2, 2, 1, 1> = Langevin, N=20, B=1000 $PERS"
+pmc dl_n1000_b32 dl_n1000_b32 'slab_kernel<0, 8, 128' 600 "ccvm::slab_kernel<0, 8, 128> = DL, N=1000, B=32 $PERS"
+pmc dl_n1000_b256 dl_n1000_b256 'step_kernel<0, false, 0, 4' 1 'ccvm::step_kernel<0, false, 0, 4, false, 0> = DL step, N=1000, B=256 (32 x 32 split-K tiles)'
 cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 cp gpurun_out/${TAG}_bench_driver_like.json profiles/${TAG}_bench_steps20.json
 tail -n 1 gpurun_out/${TAG}_bench_gpus2_share.json > profiles/${TAG}_bench_gpus2_share_rehearsal.json
 tail -n 1 gpurun_out/${TAG}_bench_gpus2_share_strong.json > profiles/${TAG}_bench_gpus2_share_strong_rehearsal.json
 cp gpurun_out/${TAG}_bench_pl_adam.json profiles/${TAG}_bench_pl_n2000_b512_adam.json
-for w in dl_n100_b1000 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n1000_b256 langevin_n1000_b256 langevin_n1000_b1000 mf_n1000_b1000 dl_n1000_b2000 dl_n1000_b4000 pl_n2000_b1024 dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32; do cp gpurun_out/${TAG}_bench_$w.json profiles/${TAG}_bench_$w.json; done
-# (the regime map of round 5 comes from the regret audit's data: tools/policy_regret.py --regime-md; the size sweep from
-#  tools/size_sweep.sh + tools/make_size_sweep_md.py)
+for f in gpurun_out/${TAG}_bench_*_*.json; do
+  w=${f#gpurun_out/${TAG}_bench_}; w=${w%.json}
+  case $w in driver_like|pl_adam|gpus2_share|gpus2_share_strong) continue;; esac
+  cp $f profiles/${TAG}_bench_$w.json
+done
+for how in launcher torch_distributed_run; do
+  [ -f gpurun_out/bench_gpus6_share_rehearsal_$how.json ] && cp gpurun_out/bench_gpus6_share_rehearsal_$how.json profiles/${TAG}_bench_gpus6_share_rehearsal_$how.json
+done
