@@ -35,5 +35,5 @@ for f in gpurun_out/${TAG}_bench_*_*.json; do
   cp $f profiles/${TAG}_bench_$w.json
 done
 for how in launcher torch_distributed_run; do
-  [ -f gpurun_out/bench_gpus6_share_rehearsal_$how.json ] && cp gpurun_out/bench_gpus6_share_rehearsal_$how.json profiles/${TAG}_bench_gpus6_share_rehearsal_$how.json
+  [ -f gpurun_out/bench_gpus5_share_rehearsal_$how.json ] && cp gpurun_out/bench_gpus5_share_rehearsal_$how.json profiles/${TAG}_bench_gpus5_share_rehearsal_$how.json
 done

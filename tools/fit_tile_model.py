@@ -1,14 +1,16 @@
 """Fits behind the launch policy's time estimates of the per-step tile kernel (developer tool, round 5).
 
-    python tools/fit_tile_model.py        (anywhere: reads profiles/r05_policy_regret*.jsonl)
+    python tools/fit_tile_model.py [--write]      (anywhere: reads profiles/r05_policy_regret*.jsonl)
 
 Data: every timing of a per-step plan (families T1 / T2 / T4 = 32 x 128 / 64 / 32 tiles) in the regret audits -- the
 first pass under round 4's policy and the final one: a forced plan's time does not depend on what the default was.
 Model per (solver, tile shape), N >= 300:
     one round  (tiles <= CUs):  t = l0 + l1 N + tiles / CUs * (m0 + m1 N)
     several rounds:             t = ceil(tiles / CUs) * (a N + b + q 1e-6 N^2) + e
-weighted least squares on the relative error.  Prints the coefficient table in the form of ccvm_abi.hip's TILE_FIT,
-the fit errors, and the errors of the coefficients the LIBRARY carries (parsed from ccvm_abi.hip) on the same data."""
+weighted least squares on the relative error.  Prints the coefficient table in the form of the generated header's
+TILE_FIT (ccvm_amd/csrc/ccvm_plan_model.h), the fit errors, and the errors of the coefficients the LIBRARY carries (parsed
+from that header) on the same data.  `--write` puts the refit INTO the header (a re-fit on another box: tools/policy_regret.py
+there for the data, then this)."""
 import collections
 import json
 import math
@@ -70,8 +72,11 @@ def errors(c, rows):
     return float(np.sqrt((err ** 2).mean())), float(np.abs(err).max())
 
 
+MODEL = os.path.join(ROOT, "ccvm_amd", "csrc", "ccvm_plan_model.h")
+
+
 def library_table():
-    src = open(os.path.join(ROOT, "ccvm_amd", "csrc", "ccvm_abi.hip")).read()
+    src = open(MODEL).read()
     block = src[src.index("constexpr TileFit TILE_FIT[3][3]"):]
     block = block[:block.index("};") + 2]
     nums = [float(x) for x in re.findall(r"-?\d+\.\d+", block)]
@@ -80,12 +85,26 @@ def library_table():
             for i, kind in enumerate(("dl", "mf", "langevin")) for j, ks in enumerate((1, 2, 4))}
 
 
+def table_text(data):
+    rows = ["    {" + ", ".join("{%.3f, %.5f, %.3f, %.5f, %.5f, %.3f, %.3f, %.3f}" % fit(data[(kind, ks)]) for ks in (1, 2, 4)) + "},"
+            for kind in ("dl", "mf", "langevin")]
+    return ("constexpr TileFit TILE_FIT[3][3] = {  // [DL, MF, Langevin / pumped Langevin][32 x 128, 32 x 64, 32 x 32]\n"
+            + "\n".join(rows) + "\n};")
+
+
 if __name__ == "__main__":
+    import sys
+
     data, lib = load(), library_table()
-    print("constexpr TileFit TILE_FIT[3][3] = {  // refit from the committed audit data")
-    for kind in ("dl", "mf", "langevin"):
-        print("    {" + ", ".join("{%.3f, %.5f, %.3f, %.5f, %.5f, %.3f, %.3f, %.3f}" % fit(data[(kind, ks)]) for ks in (1, 2, 4)) + "},")
-    print("};\n")
+    if "--write" in sys.argv:
+        # the generated header's TILE_FIT block <- this refit (the measured tables beside it are carried as they are)
+        src = open(MODEL).read()
+        start = src.index("constexpr TileFit TILE_FIT[3][3]")
+        end = src.index("};", start) + 2
+        open(MODEL, "w").write(src[:start] + table_text(data) + src[end:])
+        print(f"{os.path.relpath(MODEL, ROOT)}: TILE_FIT rewritten from {', '.join(os.path.basename(f) for f in FILES)}")
+        lib = library_table()
+    print(table_text(data).replace("// [DL", "// refit from the committed audit data  [DL") + "\n")
     print("| solver | tiles | timings | refit: rms / max relative error | the library's coefficients: rms / max |")
     print("|---|---|---|---|---|")
     for kind in ("dl", "mf", "langevin"):
