@@ -545,9 +545,31 @@ int ccvm_column_sums(const float* Q, int N, int ld, float* qsum, void* ws, size_
     return CCVM_OK;
 }
 
+}  // extern "C"
+namespace {
+int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len);
+}
+extern "C" {
 int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0 || solver < 0 || solver > 2 || B <= 0 || N <= 0)
         return fail(CCVM_E_INVALID, "ccvm_describe_launch: bad argument");
+    const int rc = describe_plan(solver, B, N, adam, per_variable_s, buf, buf_len);
+    if (rc != CCVM_OK || !std::strncmp(buf, "batch cut in two", 16)) return rc;  // (a cut batch: its parts carry theirs)
+    // ... and the estimate the plan rests on (ccvm_plan.hip; the row-owner kernel: its fitted variant model, N <= 64 only)
+    Tuning tun = read_tuning();
+    tun.adam = adam && solver != 0;
+    double est = 0.0;
+    if (want_persist(N, tun))
+        est = persist_shape(solver, tun.adam, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus, tun.persist_pw).est_us;
+    else
+        est = plan_us(solver, B, N, tun);
+    const size_t used = std::strlen(buf);
+    if (est > 0.0 && used + 1 < buf_len) std::snprintf(buf + used, buf_len - used, "; estimated %.2f us per step", est);
+    return CCVM_OK;
+}
+}  // extern "C"
+namespace {
+int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* buf, size_t buf_len) {
     Tuning tun = read_tuning();
     const bool ad = adam && solver != 0;
     tun.adam = ad;
@@ -626,6 +648,8 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     return CCVM_OK;
 }
 
+}  // namespace
+extern "C" {
 int ccvm_pack(const float* src, int rows, int cols, int src_ld, float* dst, int dst_rows, int dst_ld,
               void* stream) {
     if (!src || !dst || rows < 0 || cols < 0 || src_ld < cols || dst_rows < rows || dst_ld < cols)
