@@ -182,11 +182,13 @@ def test_bench_falls_back_to_gloo_when_rccl_refuses():
 
 
 @pytest.mark.parametrize("how", ["launcher", "torch.distributed.run"])
-def test_five_rank_rehearsal_of_the_drivers_launch_line(how):
+def test_four_rank_rehearsal_of_the_drivers_launch_line(how):
     """the launcher / port / gloo control plane / N-way gather of the driver's multi-GPU run, rehearsed
-    with as many ranks as this pool lets a test put on the box's GPU -- FIVE: six processes may have the card open and the
-    test runner is one of them (a seventh ends the run: gpurun's process guard, which is what the first version of this
-    test, six ranks, met; the 8-rank control plane runs on the CPU: tests/test_bench_collectives.py).  The ranks share
+    with as many ranks as this pool lets a TEST put on the box's GPU -- FOUR: six processes may have the card open, and the
+    test runner and the launcher (or torch's agent) are two of them (a seventh ends the run: gpurun's process guard, which
+    is what six- and five-rank versions of this test met).  Outside the test runner five ranks fit: tools/bench_round.sh
+    keeps that line as profiles/r06_bench_gpus5_share_rehearsal.json; the 8-rank control plane runs on the CPU
+    (tests/test_bench_collectives.py).  The ranks share
     cuda:0 (CCVM_BENCH_SHARE_GPU=1: collectives over gloo, the bound of a cross-workgroup wait raised for the shared GPU);
     rank 0 prints ONE line that says it is a rehearsal, not a scaling point."""
     import json
@@ -195,20 +197,20 @@ def test_five_rank_rehearsal_of_the_drivers_launch_line(how):
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(var, None)
     bench = os.path.join(os.path.dirname(HERE), "bench.py")
-    tail = [bench, "--gpus", "5", "--steps", "20", "--warmup", "5", "--spinup-ms", "20"]
+    tail = [bench, "--gpus", "4", "--steps", "20", "--warmup", "5", "--spinup-ms", "20"]
     cmd = ([sys.executable] + tail if how == "launcher" else
-           [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
+           [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
             "--master-port", str(_free_port())] + tail)
     run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 5 and line["n_ranks_seen"] == 5 and line["steps"] == 20 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 4 and line["n_ranks_seen"] == 4 and line["steps"] == 20 and line["scaling"] == "weak"
     assert line["collective"].startswith("gloo (rehearsal") and "rehearsal" in line["config"]["parallelism"]
-    assert line["config"]["global_batch"] == 5000 and len(line["ms_per_step_per_rank"]) == 5
+    assert line["config"]["global_batch"] == 4000 and len(line["ms_per_step_per_rank"]) == 4
     assert len(line["ms_per_step_repeats"]) == 9 and line["check"]["objective_values_finite"] is True
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
-    if os.path.isdir(out):  # (kept as profiles/r06_bench_gpus5_share_rehearsal*.json)
-        with open(os.path.join(out, f"bench_gpus5_share_rehearsal_{how.replace('.', '_')}.json"), "w") as fh:
+    if os.path.isdir(out):  # (kept as profiles/r06_bench_gpus4_share_rehearsal*.json)
+        with open(os.path.join(out, f"bench_gpus4_share_rehearsal_{how.replace('.', '_')}.json"), "w") as fh:
             fh.write(lines[0] + "\n")

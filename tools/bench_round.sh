@@ -20,4 +20,6 @@ done
 CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 1000 --warmup 100 --no-cpu-baseline > $O/${TAG}_bench_gpus2_share.json 2>> $O/${TAG}_bench.err || exit 1
 # strong scaling (BASELINE config 5's global batch split over the ranks), rehearsed on one GPU over gloo
 CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --workload pl_n2000_b512 --post adam --global-batch 4096 --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_gpus2_share_strong.json 2>> $O/${TAG}_bench.err || exit 1
+# the driver's launch line with FIVE ranks on the one GPU (launcher + 5 = the six processes the pool allows on a card)
+CCVM_BENCH_SHARE_GPU=1 python3 bench.py --gpus 5 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_gpus5_share.json 2>> $O/${TAG}_bench.err || exit 1
 echo BENCH_DONE

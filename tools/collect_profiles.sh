@@ -31,9 +31,10 @@ tail -n 1 gpurun_out/${TAG}_bench_gpus2_share_strong.json > profiles/${TAG}_benc
 cp gpurun_out/${TAG}_bench_pl_adam.json profiles/${TAG}_bench_pl_n2000_b512_adam.json
 for f in gpurun_out/${TAG}_bench_*_*.json; do
   w=${f#gpurun_out/${TAG}_bench_}; w=${w%.json}
-  case $w in driver_like|pl_adam|gpus2_share|gpus2_share_strong) continue;; esac
+  case $w in driver_like|pl_adam|gpus2_share|gpus2_share_strong|gpus5_share) continue;; esac
   cp $f profiles/${TAG}_bench_$w.json
 done
 for how in launcher torch_distributed_run; do
-  [ -f gpurun_out/bench_gpus5_share_rehearsal_$how.json ] && cp gpurun_out/bench_gpus5_share_rehearsal_$how.json profiles/${TAG}_bench_gpus5_share_rehearsal_$how.json
+  [ -f gpurun_out/bench_gpus4_share_rehearsal_$how.json ] && cp gpurun_out/bench_gpus4_share_rehearsal_$how.json profiles/${TAG}_bench_gpus4_share_rehearsal_$how.json
 done
+[ -f gpurun_out/${TAG}_bench_gpus5_share.json ] && tail -n 1 gpurun_out/${TAG}_bench_gpus5_share.json > profiles/${TAG}_bench_gpus5_share_rehearsal.json
