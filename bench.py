@@ -440,31 +440,65 @@ def tts99_leg():
     """Secondary metric of BASELINE.json: TTS @ 99 % success = per-row solve time x R99
     (ccvmplotlib/utils/sampleTTSmetric.py:144-153).  Only defined where the optimum is known, so it is
     measured on the reference's shipped tuning instance tuningH020-100-0 (arrays: tests/golden fixture)
-    with the shipped example configuration (examples/ccvm_boxqp_dl.py:12-24: B=1000, 1500 iterations),
-    through the public solver API with the fused generator."""
+    with the shipped example configurations (examples/ccvm_boxqp_dl.py:12-24 and its three siblings: B=1000, 1500
+    iterations), through the public solver API with the fused generator -- DL as `value` (the headline solver), all
+    four under `solvers`, each next to the oracle's TTS on this box's host cores (`cpu`: one solve of the same
+    configuration with torch's CPU stream, one thread -- the best at this size, profiles/r06_cpu_thread_sweep.md; the
+    full protocol with repeats and the second instance: tools/tts_report.py, profiles/r06_tts.md)."""
     import numpy as np
 
     from ccvm_amd.problem_classes.boxqp import ProblemInstance
-    from ccvm_amd.solvers import DLSolver
-    from ccvm_amd.workloads import EXAMPLE_PARAMS
+    from ccvm_amd.solvers import DLSolver, LangevinSolver, MFSolver, PumpedLangevinSolver
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, SCALING_MULTIPLIER
+    from oracle import ccvm_oracle as oracle
 
     gdir = os.path.join(ROOT, "tests", "golden")
     arrays = np.load(os.path.join(gdir, "tuningH020.npz"))
     with open(os.path.join(gdir, "tuningH020.json")) as fh:
         meta = json.load(fh)["instance"]
-    inst = ProblemInstance.from_arrays(arrays["q_matrix"], arrays["v_vector"], device="cuda", name=meta["name"],
-                                       optimal_sol=meta["optimal_sol"], best_sol=meta["best_sol"])
-    solver = DLSolver(device="cuda", batch_size=1000)
-    solver.parameter_key = {20: dict(EXAMPLE_PARAMS["dl"], iterations=1500)}
-    inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
-    torch.manual_seed(1234)
-    solver(instance=inst)  # first call: one-time initialisation
-    sol = solver(instance=inst)
-    p = sol.solution_performance["optimal"]
+    batch, iterations, bounds = 1000, 1500, (0.0, 1.0)
+    out = {}
+    for kind, cls in (("dl", DLSolver), ("mf", MFSolver), ("langevin", LangevinSolver), ("pl", PumpedLangevinSolver)):
+        inst = ProblemInstance.from_arrays(arrays["q_matrix"], arrays["v_vector"], device="cuda", name=meta["name"],
+                                           optimal_sol=meta["optimal_sol"], best_sol=meta["best_sol"])
+        solver = cls(device="cuda", batch_size=batch)
+        solver.parameter_key = {20: dict(EXAMPLE_PARAMS[kind], iterations=iterations)}
+        inst.scale_coefs(solver.get_scaling_factor(inst.q_matrix))
+        torch.manual_seed(1234)
+        solver(instance=inst)  # first call: one-time initialisation
+        sol = solver(instance=inst)
+        # the oracle: the reference's loop on the host (time of the loop only, as solve_time is)
+        q = torch.from_numpy(arrays["q_matrix"]).float()
+        v = torch.from_numpy(arrays["v_vector"]).float()
+        f = oracle.scaling_factor(q, SCALING_MULTIPLIER[kind])
+        qs, vs, p = q / f, v / f, EXAMPLE_PARAMS[kind]
+        torch.set_num_threads(1)
+        torch.manual_seed(1234)
+        t0 = time.perf_counter()
+        if kind == "dl":
+            c, _ = oracle.dl_loop(qs, vs, batch, iterations, p["pump"], p["dt"], p["noise_ratio"], p["feedback_scale"], 0.05, bounds)
+            x = oracle.change_variables(torch.clamp(c, -1, 1), 0.0, 1.0, 1)
+        elif kind == "mf":
+            _, mt, _ = oracle.mf_loop(qs, vs, batch, iterations, p["pump"], p["dt"], p["j"], p["feedback_scale"], p["S"], 0.01, bounds)
+            x = oracle.change_variables(mt, 0.0, 1.0, p["S"])
+        else:
+            loop = oracle.pl_loop if kind == "pl" else oracle.langevin_loop
+            args = (p["pump"],) if kind == "pl" else ()
+            c = loop(qs, vs, batch, iterations, *args, p["dt"], p["sigma"], p["feedback_scale"], p["S"], bounds)
+            x = (c + p["S"]) / (2 * p["S"])
+        cpu_row = (time.perf_counter() - t0) / batch
+        _, perf = oracle.solution_stats(oracle.compute_energy(x, qs, vs, float(f)), meta["optimal_sol"])
+        out[kind] = {
+            "tts99_s": sol.tts99(), "p_optimal": sol.solution_performance["optimal"], "solve_time_per_row_s": sol.solve_time,
+            "best_objective_value": sol.best_objective_value,
+            "cpu": {"tts99_s": cpu_row * oracle.r99(perf["optimal"]), "p_optimal": perf["optimal"],
+                    "solve_time_per_row_s": cpu_row, "threads": 1},
+        }
+    dl = out["dl"]
     return {
-        "value": sol.tts99(), "unit": "s", "instance": meta["name"], "batch": 1000, "iterations": 1500,
-        "p_optimal": p, "solve_time_per_row_s": sol.solve_time, "best_objective_value": sol.best_objective_value,
-        "optimal_value": meta["optimal_sol"],
+        "value": dl["tts99_s"], "unit": "s", "instance": meta["name"], "batch": batch, "iterations": iterations,
+        "p_optimal": dl["p_optimal"], "solve_time_per_row_s": dl["solve_time_per_row_s"],
+        "best_objective_value": dl["best_objective_value"], "optimal_value": meta["optimal_sol"], "solvers": out,
     }
 
 
