@@ -202,13 +202,18 @@ def test_producer_waves_policy(hip_lib, clean_env):
         m = shape.search(_describe(hip_lib, solver, b, n, adam))
         return {"ru": int(m.group(4)), "kh": int(m.group(5)), "pw": 1 if m.group(6) else 0, "grid": int(m.group(7)), "threads": int(m.group(8))}
 
-    # the shipped instances at the example scripts' batch sizes: two rows in use + producers, one four-wave workgroup = two row sets
+    # the shipped instances at the example scripts' batch sizes: producers, one four-wave workgroup = two row sets; two rows in
+    # use at N = 20, and wherever consumers + producers of four-row sets would not be fewer rounds of waves
     for solver in (0, 1, 2):
         for n in (20, 50, 64):
             for b in (1, 100, 1000):
                 p = plan(solver, b, n)
-                assert p["pw"] == 1 and p["ru"] == 2 and p["threads"] == 256, (solver, n, b, p)
+                assert p["pw"] == 1 and p["threads"] == 256, (solver, n, b, p)
+                assert p["ru"] == 2 or (solver == 0 and n > 32 and b == 1000), (solver, n, b, p)
     assert plan(0, 100, 20)["grid"] == 25 and plan(0, 1000, 20)["grid"] == 250
+    # DL N = 64, B = 1000: 1000 one-row consumers + 1000 producers are two rounds of waves, 500 + 500 of the two-row kind one
+    # (measured 0.595 against 0.483 us per step: profiles/r06_persist_policy.md)
+    assert plan(0, 1000, 64) == {"ru": 4, "kh": 1, "pw": 1, "grid": 250, "threads": 256}
     # more rounds of waves: four rows in use + producers, then (consumers alone fill the SIMDs twice over) no producers
     assert plan(0, 1500, 64) == {"ru": 4, "kh": 1, "pw": 1, "grid": 375, "threads": 256}
     assert plan(0, 8000, 64)["pw"] == 0 and plan(0, 8000, 64)["ru"] == 4
