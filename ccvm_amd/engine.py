@@ -11,6 +11,7 @@ present.
 CALLER's tensors live: host tensors are staged to the GPU and results are copied
 back.  The GPU used is ``cuda:$LOCAL_RANK`` (or ``$CCVM_AMD_DEVICE``, default 0).
 """
+import collections
 import contextlib
 import ctypes
 import os
@@ -340,6 +341,23 @@ _exchange_blocked_until = {}
 
 _problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device index, DeviceProblem, ready event)
 
+#: (kind, batch, N, adam, per-variable S, tuning environment) -> does the plan wait across workgroups (Trajectories._exchange_kernel)
+_exchange_kernel_cache = {}
+_TUNING_VARS = ("CCVM_AMD_KERNEL", "CCVM_AMD_GEOMETRY", "CCVM_AMD_KS", "CCVM_AMD_SPLIT", "CCVM_AMD_SLAB_CGRP", "CCVM_AMD_SLAB_RG",
+                "CCVM_AMD_CLUSTER_SETS", "CCVM_AMD_CLUSTER_HALF", "CCVM_AMD_XCD", "CCVM_AMD_XCD_XC")
+
+
+def _tuning_env():
+    """The environment variables the launch policy reads (ccvm_plan.hip: read_tuning) that can move a shape between
+    kernel families, as a hashable snapshot."""
+    get = os.environ.get
+    return tuple(get(k) for k in _TUNING_VARS)
+
+
+#: schedule tables of whole runs (ccvm_*_schedule), reused by later runs with the same parameters on the same stream:
+#: (device, stream, kind, T, the C parameter struct's bytes, the Adam struct's schedule fields) -> tensor; read-only
+_schedule_cache = collections.OrderedDict()
+
 
 def device_problem(q_matrix, v_vector):
     """``DeviceProblem(q, v)``, reused while the SAME tensor objects are passed unmodified: a solver
@@ -412,6 +430,7 @@ class Trajectories:
         self.rows = rows_of(self.b)
         self.step = 0
         self.s_cols = None  # per-variable saturation (device array), MF / Langevin only
+        self.s_full = None  # per-trajectory-and-variable saturation (composed path)
         lo, hi = float(bounds[0]), float(bounds[1])
         with torch.cuda.device(self.device):
             zeros = lambda: torch.zeros((self.rows, self.ld), dtype=torch.float32, device=self.device)
@@ -453,13 +472,31 @@ class Trajectories:
             self._schedule = None
             sched_bytes = self.lib.ccvm_schedule_bytes(self._SOLVER_ID[kind], self.t)
             if sched_bytes and os.environ.get("CCVM_AMD_SCHEDULE", "1") != "0":
-                self._schedule = torch.empty((sched_bytes // 4,), dtype=torch.float32, device=self.device)
-                if kind == "dl":
-                    rc = self.lib.ccvm_dl_schedule(ctypes.byref(cp), self.t, _ptr(self._schedule), _stream_ptr())
+                # (a table is a function of the scalars below and T alone -- never of Q, the batch or the noise -- and is
+                # only ever read: runs with the same parameters on the same stream share one; repeated solves of an
+                # instance, the TTS protocol, then skip the allocation and the schedule kernel's launch)
+                skey = (self.device.index, _stream_ptr().value, kind, self.t, lo, hi,
+                        tuple(sorted((k, float(v)) for k, v in params.items() if not torch.is_tensor(v) and v is not None)),
+                        None if adam is None else tuple(sorted((k, float(v)) for k, v in adam.items())))
+                with _cache_lock:
+                    cached = None if (self.s_cols is not None or self.s_full is not None) else _schedule_cache.get(skey)
+                    if cached is not None:
+                        _schedule_cache.move_to_end(skey)
+                if cached is not None:
+                    self._schedule = cached
                 else:
-                    make = self.lib.ccvm_mf_schedule if kind == "mf" else self.lib.ccvm_langevin_schedule
-                    rc = make(ctypes.byref(cp), ctypes.byref(self.adam), self.t, _ptr(self._schedule), _stream_ptr())
-                _lib.check(rc, "ccvm_schedule")
+                    self._schedule = torch.empty((sched_bytes // 4,), dtype=torch.float32, device=self.device)
+                    if kind == "dl":
+                        rc = self.lib.ccvm_dl_schedule(ctypes.byref(cp), self.t, _ptr(self._schedule), _stream_ptr())
+                    else:
+                        make = self.lib.ccvm_mf_schedule if kind == "mf" else self.lib.ccvm_langevin_schedule
+                        rc = make(ctypes.byref(cp), ctypes.byref(self.adam), self.t, _ptr(self._schedule), _stream_ptr())
+                    _lib.check(rc, "ccvm_schedule")
+                    if self.s_cols is None and self.s_full is None and sched_bytes <= (8 << 20):
+                        with _cache_lock:
+                            _schedule_cache[skey] = self._schedule
+                            while len(_schedule_cache) > 16:
+                                _schedule_cache.popitem(last=False)
                 cp.schedule = self._schedule.data_ptr()
             size_of = self.lib.ccvm_workspace_bytes_cols if self.s_cols is not None else self.lib.ccvm_workspace_bytes
             ws_bytes = size_of(self._SOLVER_ID[kind], self.b, self.n)
@@ -483,6 +520,8 @@ class Trajectories:
         # whatever held the GPU -- another process, a CU mask -- would cost each of them its own bounded wait and repeat)
         self.no_exchange = time.monotonic() < _exchange_blocked_until.get(self.device.index, 0.0)
         self.fallbacks = 0         # time-outs recovered so far
+        self._runs = 0             # run calls so far; _clean_at: their count at the last clean read of the status word
+        self._clean_at = -1
         self._waits = None         # does a run call launch a kernel whose workgroups wait for each other? (asked once)
         self._fixed_args = None    # the run entry point and its constant arguments (made by the first run call)
 
@@ -533,6 +572,7 @@ class Trajectories:
             self._restore(self._snap)
 
     def _run(self, step0, k, nz):
+        self._runs += 1
         if self._ws_padded:  # this object zero-filled the workspace and only its own run calls have used it since
             nz.flags |= _lib.RUN_WS_PADDED
         if self.no_exchange:
@@ -607,7 +647,20 @@ class Trajectories:
 
     def _exchange_kernel(self):
         """Would a run call of this shape launch a kernel whose workgroups wait for each other (column-cluster,
-        column-slab, persistent tile: ccvm_describe_launch under the current tuning environment)?"""
+        column-slab, persistent tile: ccvm_describe_launch under the current tuning environment)?  Asked by every
+        advance of a run that has no snapshot yet: memoised per shape and tuning environment (the description is a
+        plan evaluation plus string formatting, ~10 us; a solve at the shipped example's size is 530 us of kernel)."""
+        key = (self.kind, self.b, self.n, bool(self.adam.enabled), self.s_cols is not None, _tuning_env())
+        hit = _exchange_kernel_cache.get(key)
+        if hit is not None:
+            return hit
+        hit = self._exchange_kernel_uncached()
+        if len(_exchange_kernel_cache) > 512:
+            _exchange_kernel_cache.clear()
+        _exchange_kernel_cache[key] = hit
+        return hit
+
+    def _exchange_kernel_uncached(self):
         buf = ctypes.create_string_buffer(1024)  # (the description of a cut batch names both parts' plans)
         rc = self.lib.ccvm_describe_launch(self._SOLVER_ID[self.kind], self.b, self.n, 1 if self.adam.enabled else 0,
                                            1 if self.s_cols is not None else 0, buf, 1024)
@@ -659,7 +712,11 @@ class Trajectories:
             if not hold:
                 self._snap = None
             return False
-        if int(self._status.cpu().view(torch.int32).item()) == 0:
+        # (no run call since the last clean read: the word cannot have changed -- a solver call verifies at the loop's end,
+        # at the timer's stop and in front of the scoring: one 4-byte device-to-host round trip instead of three, ~20 us
+        # each against a 530 us solve at the shipped example's size)
+        if self._clean_at == self._runs or int(self._status.cpu().view(torch.int32).item()) == 0:
+            self._clean_at = self._runs
             if not hold:
                 self._snap = None  # verified: the next run call snapshots anew
             return False

@@ -177,6 +177,7 @@ class _StubEngineTraj:
         self.step = 0
         self._snap = None
         self._status = torch.zeros(1, dtype=torch.int32)
+        self._runs, self._clean_at = 0, -1  # (run calls so far / their count at the last clean read of the status word)
         self.restored = []
 
     def _exchange_kernel(self):
@@ -194,6 +195,7 @@ class _StubEngineTraj:
         from ccvm_amd import engine
 
         engine.Trajectories.arm(self)
+        self._runs += 1
         self.step += n
 
 

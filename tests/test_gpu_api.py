@@ -394,3 +394,49 @@ def test_workspace_padded_flag_skips_the_memset_without_changing_results():
         for name in out[0]:
             assert torch.equal(out[0][name], out[1][name]), (kind, n, name)
     assert _lib.RUN_WS_PADDED == 1
+
+
+def test_schedule_tables_are_shared_between_runs_of_the_same_parameters_only():
+    """Round 6: a run's schedule table is a function of the solver's scalars and T alone, so runs with the same
+    parameters on the same stream share one (engine._schedule_cache: repeated solves of an instance skip the
+    allocation and the schedule kernel).  Same parameters -> the same table object and bit-identical trajectories;
+    another dt, another T, another Adam setting -> a table of their own; the status word is read once per verified
+    state, not once per check."""
+    from ccvm_amd import engine
+    from ccvm_amd.workloads import EXAMPLE_PARAMS, scaled_qv
+
+    q, v, _ = scaled_qv(20, "dl")
+    prob = engine.DeviceProblem(q, v)
+
+    def run(params, t, kind="dl", adam=None):
+        traj = engine.Trajectories(prob, 64, kind, t, params, (0.0, 1.0), engine.NoiseSpec(mode="fused", seed=5), adam=adam)
+        traj.advance(t)
+        return traj
+
+    base = dict(EXAMPLE_PARAMS["dl"], g=0.05)
+    a1, a2 = run(base, 40), run(base, 40)
+    assert a1._schedule.data_ptr() == a2._schedule.data_ptr()
+    assert torch.equal(a1.compact("c"), a2.compact("c")) and torch.equal(a1.compact("s"), a2.compact("s"))
+    b = run(dict(base, dt=0.002), 40)
+    c = run(base, 41)
+    assert len({a1._schedule.data_ptr(), b._schedule.data_ptr(), c._schedule.data_ptr()}) == 3
+    assert not torch.equal(a1.compact("c"), b.compact("c"))
+    lv = dict(EXAMPLE_PARAMS["langevin"], use_pump=False)
+    ad = {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False}
+    l1, l2 = run(lv, 30, "langevin"), run(lv, 30, "langevin", adam=ad)
+    assert l1._schedule.data_ptr() != l2._schedule.data_ptr()  # (the Adam bias corrections are words of the table)
+    l3 = run(lv, 30, "langevin", adam=dict(ad))
+    assert l2._schedule.data_ptr() == l3._schedule.data_ptr() and torch.equal(l2.compact("c"), l3.compact("c"))
+    # one device-to-host read per verified state
+    reads = []
+    real = torch.Tensor.cpu
+    t = run(base, 10)
+    try:
+        torch.Tensor.cpu = lambda self, *a, **k: (reads.append(1), real(self, *a, **k))[1]
+        assert t.check() is False and t.check() is False and t.check(hold=True) is False
+        assert len(reads) == 1
+        t.advance(0)          # (no run call: nothing to verify)
+        t.check()
+        assert len(reads) == 1
+    finally:
+        torch.Tensor.cpu = real
