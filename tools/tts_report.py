@@ -134,5 +134,35 @@ def main():
             json.dump(doc, fh, indent=1)
 
 
+def write_md(src, dst):
+    """The committed table (profiles/rNN_tts.md) from a report's JSON: python tools/tts_report.py --md IN.json OUT.md"""
+    d = json.load(open(src))
+    out = ["# TTS @ 99 % success: engine (MI355X) next to the oracle (the reference's op sequence on this box's host cores)\n",
+           f"Generated by `python tools/tts_report.py --md {os.path.relpath(src, ROOT)} {os.path.relpath(dst, ROOT)}` from the report of "
+           f"`python tools/tts_report.py --out ...` on the GPU box ({d['device']}, {d['cpu']}, {d['cores_visible']} cores visible, torch {d['torch']}).",
+           "TTS99 = per-row solve time x R99, R99 = max(1, ln 0.01 / ln(1 - p)), p = fraction of the batch within 0.1 % of the known optimum",
+           "(`ccvmplotlib/utils/sampleTTSmetric.py:144-153`; solve time per row = loop wall time / batch, `dl_solver.py:851, 933`).  Engine: the public",
+           "solver API, fused noise, 7 solves after one warm-up call (median solve time; p = mean over the 7); oracle: one solve at its best of",
+           "1 / 4 / 16 torch threads (1 at this size), normals from torch's CPU stream -- two samples of the same distribution, not the same trajectories.\n",
+           "| configuration | instance | batch | iterations | engine us/step (through `Solver.__call__`) | engine p(optimal) | engine TTS99 | oracle CPU us/step | oracle p | oracle TTS99 | ratio |",
+           "|---|---|---|---|---|---|---|---|---|---|---|"]
+    fmt = lambda t: "inf (p = 0)" if t == float("inf") else (f"{t * 1e6:.2f} us" if t < 1e-3 else f"{t * 1e3:.2f} ms")
+    for r in d["rows"]:
+        e, c = r["engine"], r["oracle_cpu"]
+        te, tc = e["tts99_s_at_mean_p"], c["tts99_s"]
+        out.append(f"| {r['config']} | `{r['instance']}` | {r['batch']} | {r['iterations']} | {e['us_per_step']:.3f} | {e['p_optimal_mean']:.3f} | "
+                   f"{fmt(te)} | {c['us_per_step']:.0f} ({c['threads']} thread) | {c['p_optimal']:.3f} | {fmt(tc)} | "
+                   + ("--" if te == float("inf") else f"{tc / te:.0f}x") + " |")
+    out += ["\nThe engine's us/step here is `Solution.solve_time` x batch / iterations -- the reference's definition, which includes building the run's",
+            "device state, the run call's launch and the verification's synchronisation on top of the kernel's 0.35-0.41 us per step",
+            "(`profiles/r06_bench_dl_n20_b1000.json`; round 6 took that overhead from ~150 to ~35 us per solve: shared schedule tables, one status read).",
+            "Config 1 (the README snippet's parameters, BASELINE.md) finds no row within 0.1 % of the optimum on either side: its TTS is undefined",
+            "(R99 = inf), its throughput is the `dl_n20_b100` bench line."]
+    open(dst, "w").write("\n".join(out) + "\n")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--md":
+        write_md(sys.argv[2], sys.argv[3])
+    else:
+        main()
