@@ -359,6 +359,29 @@ def _tuning_env():
 _schedule_cache = collections.OrderedDict()
 
 
+def _schedule_key(device_index, stream, kind, iterations, lo, hi, params, adam):
+    """The key of a run's schedule table in ``_schedule_cache``, or None when a parameter is not a plain scalar (such a
+    run makes its own table).  Every scalar of the parameter dictionaries is part of the key, whether the table reads it
+    or not."""
+    def scalars(d):
+        out = []
+        for k, v in sorted(d.items()):
+            if v is None:
+                continue
+            if torch.is_tensor(v) and v.numel() != 1:
+                return None
+            try:
+                out.append((k, float(v)))
+            except (TypeError, ValueError):
+                return None
+        return tuple(out)
+
+    p, a = scalars(params), (() if adam is None else scalars(adam))
+    if p is None or a is None:
+        return None
+    return (device_index, stream, kind, int(iterations), lo, hi, p, adam is not None, a)
+
+
 def device_problem(q_matrix, v_vector):
     """``DeviceProblem(q, v)``, reused while the SAME tensor objects are passed unmodified: a solver
     call stages Q for the loop, again for the energy evaluation and again for a post-processor
@@ -475,11 +498,11 @@ class Trajectories:
                 # (a table is a function of the scalars below and T alone -- never of Q, the batch or the noise -- and is
                 # only ever read: runs with the same parameters on the same stream share one; repeated solves of an
                 # instance, the TTS protocol, then skip the allocation and the schedule kernel's launch)
-                skey = (self.device.index, _stream_ptr().value, kind, self.t, lo, hi,
-                        tuple(sorted((k, float(v)) for k, v in params.items() if not torch.is_tensor(v) and v is not None)),
-                        None if adam is None else tuple(sorted((k, float(v)) for k, v in adam.items())))
+                skey = None
+                if self.s_cols is None and self.s_full is None and sched_bytes <= (8 << 20):
+                    skey = _schedule_key(self.device.index, _stream_ptr().value, kind, self.t, lo, hi, params, adam)
                 with _cache_lock:
-                    cached = None if (self.s_cols is not None or self.s_full is not None) else _schedule_cache.get(skey)
+                    cached = None if skey is None else _schedule_cache.get(skey)
                     if cached is not None:
                         _schedule_cache.move_to_end(skey)
                 if cached is not None:
@@ -492,7 +515,7 @@ class Trajectories:
                         make = self.lib.ccvm_mf_schedule if kind == "mf" else self.lib.ccvm_langevin_schedule
                         rc = make(ctypes.byref(cp), ctypes.byref(self.adam), self.t, _ptr(self._schedule), _stream_ptr())
                     _lib.check(rc, "ccvm_schedule")
-                    if self.s_cols is None and self.s_full is None and sched_bytes <= (8 << 20):
+                    if skey is not None:
                         with _cache_lock:
                             _schedule_cache[skey] = self._schedule
                             while len(_schedule_cache) > 16:

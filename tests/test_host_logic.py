@@ -238,3 +238,29 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "make_design_tables.py"), "--check"])
     assert run.returncode == 0, "run `python tools/make_design_tables.py` and commit DESIGN.md"
+
+
+def test_schedule_tables_are_shared_only_between_runs_with_the_same_scalars():
+    """engine._schedule_key: every scalar of the parameter dictionaries is part of the key (a one-element tensor counts as
+    its value); a run with a per-variable / per-element parameter, or one that is no number at all, gets no key -- it
+    makes its own table."""
+    import numpy as np
+
+    from ccvm_amd.engine import _schedule_key
+
+    base = dict(dt=0.002, sigma=0.5, feedback_scale=1.0, S=1.0, use_pump=False, pump=None)
+    key = _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, base, None)
+    assert key is not None and key == _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, dict(base), None)
+    assert key == _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, dict(base, S=torch.tensor(1.0), dt=np.float32(0.002).astype(np.float64) * 0 + 0.002), None)
+    for other in (dict(base, S=2.0), dict(base, S=torch.tensor([2.0])), dict(base, use_pump=True), dict(base, pump=1.5)):
+        assert _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, other, None) != key
+    assert _schedule_key(0, 8, "langevin", 1500, 0.0, 1.0, base, None) != key      # another stream
+    assert _schedule_key(1, 7, "langevin", 1500, 0.0, 1.0, base, None) != key      # another device
+    assert _schedule_key(0, 7, "langevin", 1501, 0.0, 1.0, base, None) != key      # another run length
+    assert _schedule_key(0, 7, "langevin", 1500, 0.0, 2.0, base, None) != key      # other bounds
+    adam = dict(alpha=0.001, beta1=0.9, beta2=0.999, add_assign=False)
+    with_adam = _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, base, adam)
+    assert with_adam is not None and with_adam != key
+    assert _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, base, dict(adam, beta2=1.0)) != with_adam
+    for odd in (torch.ones(20), torch.ones(4, 20), np.ones(20), "one"):
+        assert _schedule_key(0, 7, "langevin", 1500, 0.0, 1.0, dict(base, S=odd), None) is None

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R; mkdir -p gpurun_out
 CASES=""
-for k in dl langevin mf; do for n in 100 256 257 320 384 448 500 513 576 640 700 768 896 1000 1200 1500 2000 2500; do CASES="$CASES $k:$n:1000"; done; done
+for k in dl langevin mf; do for n in 20 45 64 70 100 128 160 200 256 257 320 384 448 500 513 576 640 700 768 896 1000 1200 1500 2000 2500; do CASES="$CASES $k:$n:1000"; done; done
 # the Adam variants (MF / Langevin: second-moment Adam of the example scripts) at the cluster kernel's sizes
 for k in langevin mf; do for n in 100 320 500 640 768 1000; do CASES="$CASES $k:$n:1000:adam"; done; done
 python3 tools/time_small.py $CASES pl:500:1000 pl:640:1000 pl:768:1000 pl:2000:512 2>&1 | grep "us/step" > gpurun_out/size_sweep_auto.txt || exit 1
