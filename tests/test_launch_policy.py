@@ -375,6 +375,39 @@ def test_default_policy_against_the_regret_audit(hip_lib, clean_env):
     assert not upside_down, upside_down
 
 
+def test_default_policy_against_a_second_boxes_audit(hip_lib, clean_env):
+    """Round 6 ("pins the policy to that data, not to a second box"): the same audit run again on the
+    box of round 6's call 18 -- another machine of the pool, the final code of round 6 (producer waves, one launch per
+    cluster round, time-bounded waits) -- over 162 cells (N = 100 ... 2000, B = 32 ... 2000, the three solvers):
+    profiles/r06_policy_regret.{jsonl,md}.  The policy's constants were NOT refitted to it.  The plan picked for a cell must
+    be within 7 % of the best plan THAT box measured for the cell (the audit's own list beyond 5 %: one cell, Langevin
+    N = 2000, B = 768 at 6 %)."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tools.regime_map import family
+
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    solver_id = {"dl": 0, "mf": 1, "langevin": 2}
+    with open(os.path.join(root, "profiles", "r06_policy_regret.jsonl")) as fh:
+        cells = {(r["kind"], r["n"], r["b"]): r for r in map(json.loads, fh)}
+    assert len(cells) >= 160
+    regrets, unmeasured = [], []
+    for (kind, n, b), r in sorted(cells.items()):
+        plans = [p for p in r["plans"] if p.get("us")]
+        fam = family(_describe(hip_lib, solver_id[kind], b, n))
+        mine = [p for p in plans if p["family"] == fam]
+        if not mine:
+            unmeasured.append((kind, n, b, fam))
+        elif mine[0]["us"] > 1.07 * min(p["us"] for p in plans):
+            regrets.append((kind, n, b, fam, round(mine[0]["us"], 2), round(min(p["us"] for p in plans), 2)))
+    assert not regrets, regrets
+    assert not unmeasured, unmeasured
+
+
 def test_tile_time_model_fits_the_audit_data():
     """The coefficients ccvm_abi.hip carries for the per-step tile kernel's time (TILE_FIT) against every timing of such a
     plan in the committed audits (tools/fit_tile_model.py): rms relative error below 4 % for the 32 x 128 and 32 x 64

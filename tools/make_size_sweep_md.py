@@ -14,7 +14,8 @@ NAMES = {"R": "persistent row-owner", "S": "column-slab persistent", "C": "colum
 def parse(path):
     out = {}
     for line in open(path):
-        m = re.match(r"(\w+):(\d+):(\d+)(:adam)?\s+RU=\w+\s+([\d.]+) us/step.*?(?:\[([^\]]+)\])?$", line.rstrip())
+        # (round 6: "RU=auto PW=auto" and the kernel's name behind the family tag)
+        m = re.match(r"(\w+):(\d+):(\d+)(:adam)?\s+RU=\w+(?:\s+PW=\w+)?\s+([\d.]+) us/step[^\[]*(?:\[([^\]]+)\])?", line.rstrip())
         if m:
             key = (m.group(1) + (" + Adam" if m.group(4) else ""), int(m.group(2)), int(m.group(3)))
             out[key] = float(m.group(5))
