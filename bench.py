@@ -242,6 +242,39 @@ def init_collectives(rank, world, dev, share, probe=None, timeout_s=None):
     return {"group": None, "device": cpu, "collective": f"gloo-fallback: {first}"}
 
 
+def gather_values(values, coll, world, all_gather=None):
+    """THE data collective of a multi-rank line: every rank's vector of objective values (equal lengths) to every rank,
+    over the group the ranks agreed on (init_collectives) -- and, if that group's all-gather fails on ANY rank after
+    all (RCCL's set-up was proven by a one-element all-reduce, not by this call), over gloo on host copies, decided by
+    the same min-reduce on the control plane, so that a transport problem after the timed region costs a label, not
+    the line.  Returns (list of `world` host tensors, the collective's label).  `all_gather` stands in for
+    dist.all_gather in tests."""
+    import torch.distributed as dist
+
+    label = coll["collective"]
+    if coll["group"] is not None:
+        parts, err = None, ""
+        try:
+            mine = values.to(coll["device"])
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            (all_gather or dist.all_gather)(parts, mine, group=coll["group"])
+            parts = [p.cpu() for p in parts]  # (the copy waits for the collective: an asynchronous failure surfaces here)
+        except Exception as exc:  # noqa: BLE001 -- whatever the transport raises
+            err = f"{type(exc).__name__}: {exc}".replace("\n", " ")[:300]
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the default (gloo) group
+        if int(ok.item()) == 1:
+            return parts, label
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        first = next((f"rank {r}: {e}" for r, e in enumerate(errs) if e), "unknown")
+        label = f"gloo-fallback (the all-gather over {label} failed: {first})"
+    host = values.detach().cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)
+    return parts, label
+
+
 def timed_steps(traj, warmup, steps, dev, barrier, any_rank=lambda flag: flag, repeats=1):
     """W untimed warm-up steps, then `repeats` timed regions of EXACTLY K steps of `traj` each, every one under the
     contract's clock -- barrier + device synchronisation on both sides, HIP events on the launch stream around the same
@@ -679,16 +712,14 @@ def main():
     finite = bool(torch.isfinite(obj).all().item())
     ranks_seen = 1
     if world > 1:
-        obj = obj.to(coll["device"])
         if args.global_batch is not None:  # shards differ by a row: gather equal-length, +inf-padded vectors
             per = -(-args.global_batch // world)
             obj = torch.cat([obj, torch.full((per - obj.numel(),), float("inf"), dtype=obj.dtype, device=obj.device)])
-        gathered = [torch.empty_like(obj) for _ in range(world)]
-        dist.all_gather(gathered, obj, group=coll["group"])  # THE data collective: RCCL (or what the ranks agreed on)
+        gathered, coll["collective"] = gather_values(obj, coll, world)  # THE data collective: RCCL (or what the ranks agreed on)
         obj = torch.cat(gathered)
         if args.global_batch is not None:
             obj = obj[torch.isfinite(obj) | torch.isnan(obj)]
-        ranks_seen = dist.get_world_size(coll["group"])
+        ranks_seen = len(gathered)
     best = float((-obj).max().item())
 
     if rank == 0:

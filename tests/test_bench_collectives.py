@@ -52,6 +52,53 @@ def _worker(rank, world, port, which, queue):
             dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, which, queue):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import bench
+
+    def broken_all_gather(parts, mine, group=None):
+        """The agreed group's all-gather fails on ONE rank; the others believe theirs went through (and hold garbage)."""
+        if dist.get_rank() == 1:
+            raise RuntimeError("NCCL error: unhandled system error\n(stub)")
+        for p in parts:
+            p.fill_(-1.0)
+
+    try:
+        coll = bench.init_collectives(rank, world, torch.device("cpu"), share=False, probe=_probe_ok, timeout_s=30)
+        values = torch.full((3,), float(rank))
+        parts, label = bench.gather_values(values, coll, world, all_gather=broken_all_gather if which == "broken" else None)
+        queue.put((rank, label, torch.cat(parts).tolist()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["broken", "fine"])
+def test_a_failing_data_collective_costs_a_label_not_the_line(which):
+    """bench.gather_values: the agreed group's all-gather raising on one rank AFTER the timed region (RCCL's set-up is
+    proven by a one-element all-reduce, not by this call) moves every rank to gloo on host copies; the values are the
+    right ones on every rank and the label says what happened."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, which, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((queue.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    labels = {r[1] for r in results}
+    assert len(labels) == 1
+    label = labels.pop()
+    if which == "broken":
+        assert label == "gloo-fallback (the all-gather over RCCL failed: rank 1: RuntimeError: NCCL error: unhandled system error (stub))"
+    else:
+        assert label == "RCCL"
+    assert all(r[2] == [float(r2) for r2 in range(world) for _ in range(3)] for r in results)
+
+
 @pytest.mark.parametrize("which,world", [("fail", 2), ("ok", 2), ("fail", 8), ("ok", 8)])
 def test_ranks_agree_on_the_collective(which, world):
     """(world 8: the control plane of the driver's 8-GPU run -- rendez-vous, agreement, 8-way gather -- which this pool's
