@@ -560,7 +560,8 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     tun.adam = adam && solver != 0;
     double est = 0.0;
     if (want_persist(N, tun))
-        est = persist_shape(solver, tun.adam, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus, tun.persist_pw).est_us;
+        est = persist_shape(solver, tun.adam, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus, tun.persist_pw,
+                            tun.persist_rsw).est_us;
     else
         est = plan_us(solver, B, N, tun);
     const size_t used = std::strlen(buf);
@@ -611,8 +612,11 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
     }
     if (want_persist(N, tun)) {
         const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus,
-                                              tun.persist_pw);
-        if (sh.pw)
+                                              tun.persist_pw, tun.persist_rsw);
+        if (sh.rsw == 2)
+            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
+        else if (sh.pw)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 1> grid %d x %d threads (noise producer waves), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
         else
@@ -739,6 +743,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
+        pa.rsw_override = tun.persist_rsw;
         pa.simds = 4 * chip_of(tun).cus;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
@@ -1025,6 +1030,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
+        pa.rsw_override = tun.persist_rsw;
         pa.simds = 4 * chip_of(tun).cus;
         pa.s_cols = s_cols;
         AdamSched asc;
@@ -1349,6 +1355,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         pa.ru_override = tun.persist_ru;
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
+        pa.rsw_override = tun.persist_rsw;
         pa.simds = 4 * chip_of(tun).cus;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);

@@ -13,8 +13,8 @@
 // (B=1000 DL rows on the 16-row tile of v_mfma_f32_16x16x4_f32 filled 125 of 256 CUs).
 //
 //   shape (CW, NCG): a wave covers CW columns (16 / 32 / 64) and RG = 64 / CW row groups of 4 MFMA
-//     rows; N > 64 uses NCG = 2 waves side by side (128 columns) which exchange the state through a
-//     double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per workgroup.
+//     rows; N > 64 uses NCG = 2 waves side by side (128 columns; N > 128: 3, N > 192: 4) which exchange the state
+//     through a double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per row set.
 //   RU (2 or 4) = MFMA rows in use per group: 4 when that still gives every SIMD a wave, else 2
 //     (half the per-step VALU chain per wave, twice the waves).
 //   KH (1 or 2; 2 with NCG = 2 or 4, round 3) = split of K over two waves: wave (cg, kh) contracts half of the
@@ -72,6 +72,7 @@ struct PersistArgs {
     int kh_override;     // host only: 1 / 2 forces the K split off / on (tuning), 0 = by batch size
     int simds;           // host only: SIMDs of the chip the shape is planned for (4 per CU; 0 = 1024)
     int pw_override;     // host only: 1 / 2 forces the noise producer waves off / on (tuning), 0 = by shape and batch size
+    int rsw_override;    // host only: 1 / 2 forces the row sets per six-wave workgroup (tuning), 0 = by batch size
     AdamConsts ad;
     unsigned long long* dbg;  // tools/persist_ablate.hip, CCVM_PERSIST_ABL & 16: s_memtime sums, [grid][16]
 };
@@ -127,6 +128,15 @@ __device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf
 #ifndef CCVM_PERSIST_KTAIL1
 #define CCVM_PERSIST_KTAIL1 1
 #endif
+// THREE waves side by side for 128 < N <= 192 (round 6): with four, the fourth wave of N <= 192 owns no real column at all
+// -- it runs its MFMAs on zero fragments and its generator calls for nothing (ccvm_persist_launch.h: persist_shape).
+// Same-box A/B of the library (profiles/r06_ab_persist_ncg3.txt, r06_ab_persist_kh_small.txt; bit-identical results: a
+// column's arithmetic does not depend on how many waves stand next to its own): at B >= 768 nothing changes -- within 2 %
+// either way; the fullest SIMD of a CU holds as many waves as before -- but small batches on whole chains, one workgroup
+// per CU, are 2-9 % faster without it (MF N = 144, B <= 512: 1.15 -> 1.04 us per step; DL 0.90 -> 0.88; Langevin 0.95 -> 0.92).
+#ifndef CCVM_PERSIST_NCG3
+#define CCVM_PERSIST_NCG3 1
+#endif
 
 __device__ __forceinline__ unsigned long long persist_stamp() {
     unsigned long long t;
@@ -141,13 +151,23 @@ __device__ __forceinline__ unsigned long long persist_stamp() {
 // noise set of the NEXT step (the same generator calls: bit-identical results) into a double-buffered LDS slot and
 // meets the consumers at ONE workgroup barrier per step; the consumer's chain loses the generator (and, in replay
 // mode, the global loads of the noise blocks).
-template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0>
-__global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW) : 256) void persist_kernel(const PersistArgs a) {
-    static_assert(KH == 1 || (KH == 2 && (NCG == 2 || NCG == 4) && RU == 4), "K split: waves side by side, all four rows in use");
+// threads of a workgroup: row sets per workgroup (RSWO, or what fills four wave slots) x waves per row set
+constexpr int persist_block_threads(int ncg, int kh, int pw, int rswo) {
+    const int wps = ncg * kh * (1 + pw), rsw = rswo ? rswo : (wps > 4 ? 1 : 4 / wps);
+    return 64 * wps * rsw < 256 ? 256 : 64 * wps * rsw;
+}
+
+// RSWO = 2 (round 6): TWO row sets per workgroup where a row set is six waves (three side by side x two K halves) -- twelve
+// waves are three per SIMD, where two six-wave workgroups on a CU put four on two of its SIMDs and two on the others (a
+// workgroup's waves start at SIMD 0) and a step costs what the fullest SIMD issues.
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0>
+__global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void persist_kernel(const PersistArgs a) {
+    static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 4 && RU == 4), "K split: waves side by side, all four rows in use");
     static_assert(PW == 0 || (PW == 1 && NCG * KH <= 4), "producer waves: at most eight waves per workgroup");
+    static_assert(RSWO == 0 || (PW == 0 && 64 * NCG * KH * RSWO <= 1024), "row sets per workgroup: at most sixteen waves, no producers");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
-    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || ((NCG == 2 || NCG == 4) && CW == 64)), "shape");
+    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG >= 2 && NCG <= 4 && CW == 64)), "shape");
     static_assert(RU == 2 || RU == 4, "rows in use per group");
     constexpr int RG = 64 / CW;                                // row groups per wave
     static_assert(NCH >= 1 && 16 * NCH <= CW * NCG, "K chunks vs shape");
@@ -161,14 +181,14 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
                                                                // of a half-wave read hit 32 distinct banks
     constexpr int KC = CW / 4;                                 // k-steps fed by one A register (blocks per row group)
     constexpr int CBSZ = (CW == 64) ? 4 : (CW == 32) ? 3 : 2;  // log2(KC)
-    // Row sets per workgroup: a workgroup is always four waves = one per SIMD, i.e. two two-wave sets
-    // (N > 64) or four one-wave sets.  Smaller workgroups landed unevenly on the SIMDs (DL N=100:
-    // 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with two of these waves takes twice as
-    // long.  The sets of a workgroup share nothing (N > 64: but the barrier).
+    // Row sets per workgroup: a workgroup is four waves = one per SIMD where the row sets divide four, i.e. two two-wave
+    // sets (N > 64) or four one-wave sets (three side by side: one row set of three waves; more than four: one row set).
+    // Smaller workgroups landed unevenly on the SIMDs (DL N=100: 1.46 vs 0.92 us/step; N=64: 0.89 vs 0.63) and a SIMD with
+    // two of these waves takes twice as long.  The sets of a workgroup share nothing (N > 64: but the barrier).
     constexpr int WPS = NCG * KH * (1 + PW);                   // waves per row set, producers included
-    constexpr int RSW = (WPS > 4) ? 1 : 4 / WPS;               // (four waves side by side x two K halves: eight waves)
+    constexpr int RSW = RSWO ? RSWO : (WPS > 4) ? 1 : 4 / WPS; // (four waves side by side x two K halves: eight waves)
     constexpr int NWC = RSW * NCG * KH;                        // consumer waves per workgroup
-    constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums
+    constexpr int PXF = (KH == 2) ? 2 * NCG * 2 * 64 : 0;      // K split: [kh][cg][2 rows][lane] partial sums, per row set
     constexpr int NV = ((MODE == MODE_DL) ? 2 : 1) * NE;       // normals per lane and step
     constexpr int NZF = PW ? 2 * NWC * NV * 64 : 0;            // producer waves: [step parity][consumer][value][lane]
     // producer waves also relay the schedule rows: ring[step & 3][TABLE_WORDS], the words a solver reads (in fours)
@@ -182,9 +202,9 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     // words of a row that are the same in every step of a run (ccvm_schedule.h) -- DL: dt, 2 g; MF: g^2, f_q, f_v, 1 / sqrt(dt),
     // dt, S, has_next (unused here), + the unused words 14, 15; Langevin: all but the pump term
     constexpr unsigned ROW_SAME = (MODE == MODE_DL) ? 0x030u : (MODE == MODE_MF) ? 0xCD8Eu : 0xC0FBu;
-    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXF + NZF + RING];
-    float* const px = xs_all + RSW * 2 * ROWS * LDX;
-    float* const nzl = px + PXF;
+    constexpr int PXA = (RSWO ? RSW : 1) * PXF;                // (without RSWO a K-split workgroup is one row set)
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXA + NZF + RING];
+    float* const nzl = xs_all + RSW * 2 * ROWS * LDX + PXA;
     float* const ring = nzl + NZF;
 
     const int lane = threadIdx.x & 63;
@@ -196,9 +216,11 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     const bool swap_roles = PW && WPS <= 4 && ((blockIdx.x / (a.simds > 0 ? a.simds / 4 : 256)) & 1);
     const bool producer = PW && ((wave_all >= NWC) != swap_roles);  // (wave-uniform)
     const int wave = (PW && wave_all >= NWC) ? wave_all - NWC : wave_all;  // a producer has its consumer's index and element map
-    const int cg = wave % NCG;
-    const int kh = (KH == 2) ? wave / NCG : 0;  // K half (wave-uniform)
-    float* const xs = xs_all + (wave / (NCG * KH)) * (2 * ROWS * LDX);
+    const int set = wave / (NCG * KH), wis = wave % (NCG * KH);  // row set of the workgroup, wave inside the row set
+    const int cg = wis % NCG;
+    const int kh = (KH == 2) ? wis / NCG : 0;  // K half (wave-uniform)
+    float* const xs = xs_all + set * (2 * ROWS * LDX);
+    float* const px = xs_all + RSW * 2 * ROWS * LDX + (RSWO ? set : 0) * PXF;
     const int rs = lane / CW;            // row group
     const int col = cg * CW + (lane % CW);
     const int i4 = lane & 3;             // the A-operand row this lane supplies to its block
@@ -224,7 +246,7 @@ __global__ __launch_bounds__((NCG * KH * (1 + PW) > 4) ? 64 * NCG * KH * (1 + PW
     const float inv_sat_j = a.s_cols ? 1.0f / sat_j : 1.0f;
 
     // ---- this lane's elements: batch rows brow[e] at column col -------------------------------
-    const int row0 = (blockIdx.x * RSW + wave / (NCG * KH)) * BR;
+    const int row0 = (blockIdx.x * RSW + set) * BR;
     int brow[NE];
     bool ok[NE];
     size_t gidx[NE];

@@ -21,20 +21,22 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 // by ccvm_describe_launch (so that the name a benchmark line reports is the instantiation that runs).
 struct PersistShape {
     int cw, ncg, nch, ru, grid, kh, pw, threads;
+    int rsw;        // 2: two six-wave row sets per workgroup (three side by side x two K halves), else 0
     double est_us;  // the variant model's estimate (one wave per row set, N <= 64: ccvm_persist_model.h), else 0
 };
 constexpr int PERSIST_PW_MAX_NCG = 2;  // noise producer waves are instantiated for one and two waves side by side
 // kh_override: 1 / 2 forces the K split off / on (where the shape has one), 0 = by batch size
 // solver: 0 DL, 1 MF, 2 Langevin / pumped Langevin (the C ABI's numbering)
 // pw_override: 1 / 2 forces the noise producer waves off / on (where the shape has them), 0 = by shape and batch size
+// rsw_override: 1 / 2 forces the row sets per workgroup of six-wave row sets, 0 = by batch size
 inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_override, int kh_override = 0, int simds = 1024,
-                                  int pw_override = 0) {
+                                  int pw_override = 0, int rsw_override = 0) {
     const bool dl = solver == 0;
     if (simds <= 0) simds = 1024;
     PersistShape s;
     s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
     s.cw = s.nch == 1 ? 16 : s.nch == 2 ? 32 : 64;                   // columns a wave covers
-    s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : 4;                     // waves side by side
+    s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : (CCVM_PERSIST_NCG3 && s.nch <= 12) ? 3 : 4;  // waves side by side
     const int br4 = (dl ? 2 : 4) * (64 / s.cw);                      // batch rows per row set at RU = 4
     s.ru = ((B + br4 - 1) / br4) * s.ncg >= 768 ? 4 : 2;
     if (ru_override == 2 || ru_override == 4) s.ru = ru_override;
@@ -57,12 +59,28 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         // vs 2.61 split).  Register counts from the code objects of this build (hipcc 7.2): DL 258 at NCH = 13, MF 272
         // at 11, MF + Adam 270 at 10, Langevin 272 at 14, Langevin + Adam 266 at 12.
         const int lone_from = dl ? 13 : solver == 1 ? (adam ? 10 : 11) : (adam ? 12 : 14);
-        const bool lone = s.ncg == 4 && s.nch >= lone_from;
-        if ((halves < 2 * whole || waves4 <= simds || lone) && !(ru_override == 2 || ru_override == 4)) s.kh = 2;
+        const bool lone = s.ncg >= 3 && s.nch >= lone_from;
+        // (three waves side by side: the "three halves < two wholes" case does not pay -- DL N = 176 / 192, B = 1000: 2.26 / 2.37
+        // us per step split, 1.96 / 2.08 whole; Langevin N = 176, B = 2000: 2.39 / 2.02 -- profiles/r06_ab_persist_ncg3.txt)
+        const bool fewer_rounds = s.ncg != 3 && halves < 2 * whole;
+        if ((fewer_rounds || waves4 <= simds || lone) && !(ru_override == 2 || ru_override == 4)) s.kh = 2;
+        // Small batches, three / four waves side by side (round 6): while every row set at TWO rows in use still has a CU of
+        // its own, whole chains over two rows beat both the K split and four rows -- one wave per SIMD either way, and the
+        // wave's VALU part (generator, update, publish) is half as long (us per step, split / two rows: DL N = 144 1.05 /
+        // 0.88 up to B = 256, N = 224 1.32 / 1.20; Langevin N = 144 1.07 / 0.92 up to B = 512, N = 200 1.30 / 1.17; MF N = 144 1.25 /
+        // 1.04, + Adam 1.54 / 1.25; one row set more than CUs: 1.49 -- and from N = 241 the unsplit kernel's registers
+        // turn it around, N = 256: 1.42 / 1.59: profiles/r06_ab_persist_kh_small.txt).
+        const int sets2 = (B + br4 / 2 - 1) / (br4 / 2);
+        const bool two_rows_alone = s.ncg >= 3 && s.nch <= 14 && sets2 <= simds / 4 && ru_override != 4;
+        if (two_rows_alone) { s.kh = 1; s.ru = 2; }
         if (kh_override == 1) s.kh = 1;
         if (kh_override == 2) s.kh = 2;
         if (s.kh == 2) s.ru = 4;
     }
+    // Three waves side by side x two K halves: six waves per row set.  (EXPERIMENT, round 6: rsw_override only)
+    s.rsw = 0;
+    const bool rsw_fits = !(solver == 1 && adam && s.nch >= 11);  // twelve waves = three per SIMD: at most 168 VGPRs
+    if (s.ncg == 3 && s.kh == 2 && rsw_override == 2 && rsw_fits) s.rsw = 2;
     // Noise producer waves (ccvm_persist.h, PW).
     // One wave per row set (N <= 64): four variants -- two or four rows in use, with or without producers -- and which
     // one is fastest depends on how many ROUNDS of waves the fullest SIMD holds (a consumer next to its producer costs
@@ -104,10 +122,10 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     // B = 1000 1.06 us per step against 0.93 without, role swap or not)
     if (pw_override == 2 && (s.ncg == 1 || (s.ncg == 2 && s.kh == 2))) s.pw = 1;
     const int wps = s.ncg * s.kh * (1 + s.pw);                       // waves per row set
-    const int sets = wps > 4 ? 1 : 4 / wps;                          // row sets per workgroup
+    const int sets = s.rsw ? s.rsw : wps > 4 ? 1 : 4 / wps;          // row sets per workgroup
     const int per = br4 * s.ru / 4 * sets;                           // batch rows per workgroup
     s.grid = (B + per - 1) / per;
-    s.threads = wps > 4 ? 64 * wps : 256;
+    s.threads = 64 * wps * sets;                                     // (256 up to four waves per row set, but 192 for three)
     return s;
 }
 
@@ -117,8 +135,8 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
     const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, ADAM, a.B, a.N, a.ru_override,
-                                          a.kh_override, a.simds, a.pw_override);  // sh.cw == CW etc. by construction
-    const dim3 block(sh.threads);  // 4 / NCG row sets of NCG waves per workgroup (ccvm_persist.h)
+                                          a.kh_override, a.simds, a.pw_override, a.rsw_override);  // sh.cw == CW etc. by construction
+    const dim3 block(sh.threads);  // row sets of NCG x KH (x 2 with producers) waves per workgroup (ccvm_persist.h: RSW)
     if constexpr (NCG <= PERSIST_PW_MAX_NCG) {
         if (sh.pw) {  // as many producer waves as consumer waves
             if constexpr (NCG >= 2) {  // (next to the K split only: persist_shape)
@@ -129,6 +147,12 @@ void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
                 else
                     hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 2, 1, 1>), dim3(sh.grid), block, 0, st, a);
             }
+            return;
+        }
+    }
+    if constexpr (NCG == 3 && !(MODE == MODE_MF && ADAM && NCH >= 11)) {  // (MF + Adam from 11 K chunks: > 168 VGPRs, persist_shape)
+        if (sh.kh == 2 && sh.rsw == 2) {  // two row sets of six waves
+            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 0, 2>), dim3(sh.grid), block, 0, st, a);
             return;
         }
     }
@@ -155,10 +179,10 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
         case 6: launch_persist_shape<MODE, ADAM, 64, 2, 6>(a, st); break;
         case 7: launch_persist_shape<MODE, ADAM, 64, 2, 7>(a, st); break;
         case 8: launch_persist_shape<MODE, ADAM, 64, 2, 8>(a, st); break;
-        case 9: launch_persist_shape<MODE, ADAM, 64, 4, 9>(a, st); break;
-        case 10: launch_persist_shape<MODE, ADAM, 64, 4, 10>(a, st); break;
-        case 11: launch_persist_shape<MODE, ADAM, 64, 4, 11>(a, st); break;
-        case 12: launch_persist_shape<MODE, ADAM, 64, 4, 12>(a, st); break;
+        case 9: launch_persist_shape<MODE, ADAM, 64, CCVM_PERSIST_NCG3 ? 3 : 4, 9>(a, st); break;
+        case 10: launch_persist_shape<MODE, ADAM, 64, CCVM_PERSIST_NCG3 ? 3 : 4, 10>(a, st); break;
+        case 11: launch_persist_shape<MODE, ADAM, 64, CCVM_PERSIST_NCG3 ? 3 : 4, 11>(a, st); break;
+        case 12: launch_persist_shape<MODE, ADAM, 64, CCVM_PERSIST_NCG3 ? 3 : 4, 12>(a, st); break;
         case 13: launch_persist_shape<MODE, ADAM, 64, 4, 13>(a, st); break;
         case 14: launch_persist_shape<MODE, ADAM, 64, 4, 14>(a, st); break;
         case 15: launch_persist_shape<MODE, ADAM, 64, 4, 15>(a, st); break;

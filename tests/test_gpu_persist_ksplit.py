@@ -29,6 +29,9 @@ def _kh(kind, b, n, adam=False):
     ("dl", 129, 33, 20, None), ("dl", 200, 500, 12, None), ("dl", 256, 64, 12, None), ("dl", 177, 3, 20, None),
     ("mf", 144, 50, 20, "second_moment"), ("mf", 250, 700, 10, None), ("langevin", 256, 1000, 8, "add_assign"),
     ("pl", 193, 129, 16, None), ("langevin", 225, 7, 20, "first_moment_only"), ("dl", 240, 1000, 6, None),
+    # three waves side by side (128 < N <= 192, round 6): workgroups of three (whole chains) or six waves, two and four rows in use
+    ("dl", 160, 600, 10, None), ("dl", 130, 255, 12, None), ("langevin", 176, 1100, 8, "second_moment"), ("mf", 192, 300, 12, None),
+    ("mf", 145, 777, 8, "add_assign"), ("pl", 161, 512, 10, None),
 ])
 def test_k_split_matches_oracle(monkeypatch, kh, kind, n, b, t, adam):
     monkeypatch.setenv("CCVM_AMD_PERSIST_KH", str(kh))
@@ -45,12 +48,17 @@ def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves
     assert _kh("dl", 1000, 64) == 1                                           # one wave per row set: nothing to split
     assert _kh("dl", 1000, 192) == 1 and _kh("dl", 500, 192) == 2 and _kh("langevin", 1000, 256) == 2  # 128 < N <= 256: same rule ...
     assert _kh("dl", 4000, 256) == 2 and _kh("mf", 4000, 176) == 2 and _kh("langevin", 2000, 208) == 1  # ... unless a SIMD holds one unsplit wave
+    # small batches, N > 128 (round 6): whole chains over TWO rows while every such row set has a CU of its own
+    assert _kh("dl", 256, 144) == 1 and _kh("dl", 257, 144) == 2 and _kh("langevin", 512, 200) == 1 and _kh("langevin", 513, 200) == 2
+    assert _kh("mf", 512, 224, adam=True) == 1 and _kh("mf", 512, 256) == 2 and _kh("dl", 100, 240) == 2  # (N <= 224: the unsplit kernel's registers)
+    assert "persist_kernel<0, false, 64, 3, 9, 2, 1> grid 256 x 192 threads" in _describe("dl", 256, 144)
 
 
+@pytest.mark.parametrize("kh", ["2", "1"])
 @pytest.mark.parametrize("kind,n,b", [("dl", 100, 200), ("mf", 120, 77), ("langevin", 90, 300), ("dl", 200, 150),
-                                      ("langevin", 256, 90)])
-def test_chunking_and_sharding_are_exact_with_the_split(monkeypatch, kind, n, b):
-    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "2")
+                                      ("langevin", 256, 90), ("dl", 150, 120), ("mf", 190, 333)])
+def test_chunking_and_sharding_are_exact_with_the_split(monkeypatch, kind, n, b, kh):
+    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", kh)
     t = 24
     adam = None if kind == "dl" else _ADAMS["add_assign"]
     whole = _run_engine(kind, n, b, t, adam, 777, 0)

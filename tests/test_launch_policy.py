@@ -162,7 +162,8 @@ def test_no_plan_means_the_tile_kernel(hip_lib, clean_env):
 def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_counts(hip_lib, clean_env):
     """Code-object metadata of the built library (tools/kernel_resources.py, no GPU): no kernel uses scratch, and the
     row-owner kernel's "one unsplit wave per SIMD" thresholds (ccvm_persist_launch.h: lone_from) are the K chunk counts
-    from which the unsplit four-wave kernels need more than 256 VGPRs -- a compiler change that moves them fails here."""
+    from which the unsplit kernels of three (N <= 192) / four waves side by side need more than 256 VGPRs -- a compiler
+    change that moves them fails here."""
     import os
     import sys
 
@@ -175,7 +176,7 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
     assert not bad, bad
     regs = {}
     for k in ks:
-        m = re.search(r"persist_kernel<(\d), (true|false), 64, 4, (\d+), 4, 1, 0>", k["name"])
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, [34], (\d+), 4, 1, 0, 0>", k["name"])
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
@@ -183,8 +184,42 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
         for nch in range(9, 17):
             # B = 4096 rows per ... : whole rounds either way, so the split is taken only for the register reason
             d = _describe(hip_lib, solver, 8192 if solver else 4096, 16 * nch, 1 if adam else 0)
-            split = int(re.search(r"persist_kernel<\d, \w+, 64, 4, \d+, 4, (\d)>", d).group(1)) == 2
+            split = int(re.search(r"persist_kernel<\d, \w+, 64, %d, \d+, 4, (\d)>" % (3 if nch <= 12 else 4), d).group(1)) == 2
             assert split == (regs[(solver, adam, nch)] > 256), (solver, adam, nch, regs[(solver, adam, nch)], d)
+
+
+def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
+    """Round 6: 128 < N <= 192 runs THREE waves side by side (with four, the fourth owned no real column), and a batch small
+    enough for every two-row set to have a CU of its own runs whole chains over two rows in use instead of the K split
+    (profiles/r06_ab_persist_ncg3.txt, r06_ab_persist_kh_small.txt) -- up to N = 224: from 15 K chunks on the unsplit kernel's
+    registers turn the comparison around."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    shape = re.compile(r"persist_kernel<\d, \w+, 64, (\d), (\d+), (\d), (\d)(?:, 1)?> grid (\d+) x (\d+) threads")
+
+    def plan(solver, b, n, adam=0):
+        m = shape.search(_describe(hip_lib, solver, b, n, adam))
+        return tuple(int(g) for g in m.groups())  # (ncg, nch, ru, kh, grid, threads)
+
+    for n, ncg in ((129, 3), (160, 3), (192, 3), (193, 4), (256, 4)):
+        assert plan(0, 1000, n)[0] == ncg and plan(2, 4000, n)[0] == ncg
+    # workgroups: three waves (whole chains), six (K split); four / eight above N = 192
+    assert plan(0, 256, 144) == (3, 9, 2, 1, 256, 192) and plan(0, 257, 144) == (3, 9, 4, 2, 129, 384)
+    assert plan(2, 512, 200) == (4, 13, 2, 1, 256, 256) and plan(2, 513, 200) == (4, 13, 4, 2, 129, 512)
+    assert plan(1, 512, 224, 1)[2:4] == (2, 1) and plan(1, 512, 240)[2:4] == (4, 2) and plan(0, 64, 256)[2:4] == (4, 2)
+    # half the chip: half the batch
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
+    assert plan(0, 128, 144)[2:4] == (2, 1) and plan(0, 129, 144)[2:4] == (4, 2)
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    # the overrides still pin their dimension
+    clean_env.setenv("CCVM_AMD_PERSIST_KH", "2")
+    assert plan(0, 100, 144)[2:4] == (4, 2)
+    clean_env.delenv("CCVM_AMD_PERSIST_KH")
+    clean_env.setenv("CCVM_AMD_PERSIST_RU", "4")
+    assert plan(0, 100, 144)[2] == 4
+    clean_env.delenv("CCVM_AMD_PERSIST_RU")
+    # three waves side by side: the split where every wave has a SIMD of its own or the unsplit kernel holds one wave per
+    # SIMD, NOT for "three halves instead of two wholes" (DL N = 176, B = 1000: 2.26 us per step split, 1.96 whole)
+    assert plan(0, 1000, 176)[3] == 1 and plan(0, 1000, 100)[3] == 2 and plan(2, 1000, 176)[3] == 2 and plan(1, 2000, 176)[3] == 2
 
 
 def test_producer_waves_policy(hip_lib, clean_env):
@@ -236,7 +271,7 @@ def test_producer_waves_policy(hip_lib, clean_env):
 
     regs = {}
     for k in kernel_resources.kernels():
-        m = re.search(r"persist_kernel<(\d), (true|false), 64, 2, (\d+), 4, 2, 1>", k["name"])
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, 2, (\d+), 4, 2, 1, 0>", k["name"])
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     assert len(regs) == 20
