@@ -158,8 +158,8 @@ constexpr int persist_block_threads(int ncg, int kh, int pw, int rswo) {
 }
 
 // RSWO = 2 (round 6): TWO row sets per workgroup where a row set is six waves (three side by side x two K halves) -- twelve
-// waves are three per SIMD, where two six-wave workgroups on a CU put four on two of its SIMDs and two on the others (a
-// workgroup's waves start at SIMD 0) and a step costs what the fullest SIMD issues.
+// waves are three per SIMD, where two six-wave workgroups on a CU put four on two of its SIMDs and two on the others
+// (HW_ID of every wave: tools/simd_probe.hip, profiles/r06_simd_probe.txt) and a step costs what the fullest SIMD issues.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0>
 __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void persist_kernel(const PersistArgs a) {
     static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 4 && RU == 4), "K split: waves side by side, all four rows in use");

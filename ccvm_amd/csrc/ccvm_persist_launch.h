@@ -77,10 +77,23 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         if (kh_override == 2) s.kh = 2;
         if (s.kh == 2) s.ru = 4;
     }
-    // Three waves side by side x two K halves: six waves per row set.  (EXPERIMENT, round 6: rsw_override only)
+    // Three waves side by side (128 < N <= 192), batches of more row sets than CUs (round 6): six whole-chain waves of two
+    // workgroups cannot put fewer than two on some SIMD of their CU, and two six-wave K-split workgroups land four / four /
+    // two / two (the second starts on the SIMDs the first doubled up on: HW_ID of every wave, tools/simd_probe.hip,
+    // profiles/r06_simd_probe.txt) -- and a step costs what the fullest SIMD issues.  TWO six-wave row sets in ONE workgroup
+    // are twelve waves, three half chains on every SIMD: a round of such workgroups takes 1.6 x a round of whole chains
+    // and holds twice the rows (us per step, before / after: DL N = 144, B = 1000 1.72 -> 1.39, B = 2000
+    // 3.36 -> 2.77, B = 4000 6.57 -> 5.55; Langevin N = 160, B = 2000 1.90 -> 1.54; MF N = 176, B = 2000 2.64 -> 1.83; MF + Adam
+    // N = 160, B = 2000 3.19 -> 2.07 -- but B = 1500 DL, three rounds of whole chains against two of these: 2.58 / 2.82:
+    // profiles/r06_ab_persist_rsw.txt).  Twelve waves need <= 168 VGPRs: not MF + Adam from 11 K chunks (tests/test_launch_policy.py).
     s.rsw = 0;
-    const bool rsw_fits = !(solver == 1 && adam && s.nch >= 11);  // twelve waves = three per SIMD: at most 168 VGPRs
-    if (s.ncg == 3 && s.kh == 2 && rsw_override == 2 && rsw_fits) s.rsw = 2;
+    const bool rsw_fits = !(solver == 1 && adam && s.nch >= 11);
+    if (s.ncg == 3 && rsw_fits) {
+        const int cus = simds / 4, sets4 = (B + br4 - 1) / br4;
+        const int r1 = (sets4 + cus - 1) / cus, r2 = (sets4 + 2 * cus - 1) / (2 * cus);  // rounds of one / two row sets per CU
+        const bool pays = 8 * r2 < 5 * r1 && kh_override != 1 && !(ru_override == 2 || ru_override == 4);
+        if (rsw_override == 2 ? (s.kh == 2 || pays) : (rsw_override == 0 && pays)) { s.kh = 2; s.ru = 4; s.rsw = 2; }
+    }
     // Noise producer waves (ccvm_persist.h, PW).
     // One wave per row set (N <= 64): four variants -- two or four rows in use, with or without producers -- and which
     // one is fastest depends on how many ROUNDS of waves the fullest SIMD holds (a consumer next to its producer costs

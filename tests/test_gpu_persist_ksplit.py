@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _kh(kind, b, n, adam=False):
-    return int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, \d+, \d+, (\d)(?:, 1)?>", _describe(kind, b, n, adam)).group(1))
+    return int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, \d+, \d+, (\d)(?:, \d)?(?:, \d)?>", _describe(kind, b, n, adam)).group(1))
 
 
 @pytest.mark.parametrize("kh", [1, 2])
@@ -39,6 +39,34 @@ def test_k_split_matches_oracle(monkeypatch, kh, kind, n, b, t, adam):
     _check_against_oracle(kind, n, b, t, adam)
 
 
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("dl", 129, 33, 20, None), ("dl", 144, 1000, 8, None), ("dl", 177, 515, 10, None), ("dl", 192, 2001, 6, None),
+    ("mf", 144, 50, 20, "second_moment"), ("mf", 160, 1100, 8, None), ("mf", 176, 2000, 6, None), ("mf", 150, 1030, 8, "add_assign"),
+    ("langevin", 176, 1100, 8, "second_moment"), ("langevin", 130, 2500, 6, None), ("pl", 161, 512, 10, None),
+    ("langevin", 192, 1030, 8, "first_moment_only"), ("pl", 145, 7, 16, None),
+])
+def test_two_row_sets_per_workgroup_match_oracle(monkeypatch, kind, n, b, t, adam):
+    """Round 6: 128 < N <= 192, K split, TWO six-wave row sets per twelve-wave workgroup (ccvm_persist.h: RSWO = 2) -- forced
+    here at every batch, ragged ones and a single row included; the default takes it where it costs fewer rounds."""
+    monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "2")
+    monkeypatch.setenv("CCVM_AMD_PERSIST_RSW", "2")
+    assert ", 4, 2, 0, 2> grid" in _describe(kind, b, n, adam is not None) and "x 768 threads" in _describe(kind, b, n, adam is not None)
+    _check_against_oracle(kind, n, b, t, adam)
+
+
+def test_two_row_sets_per_workgroup_are_bit_identical_to_one(monkeypatch):
+    """The same K split, one or two row sets per workgroup: the same arithmetic per element, chunked or not."""
+    for kind, n, b in (("dl", 160, 700), ("mf", 190, 333), ("langevin", 131, 1027)):
+        adam = None if kind == "dl" else _ADAMS["add_assign"]
+        monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "2")
+        monkeypatch.setenv("CCVM_AMD_PERSIST_RSW", "1")
+        one = _run_engine(kind, n, b, 24, adam, 777, 0)
+        monkeypatch.setenv("CCVM_AMD_PERSIST_RSW", "2")
+        two = _run_engine(kind, n, b, 24, adam, 777, 0, chunks=[1, 9, 3, 11])
+        for name in one.state:
+            assert torch.equal(one.compact(name), two.compact(name)), (kind, name)
+
+
 def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_PERSIST_KH", raising=False)
     monkeypatch.delenv("CCVM_AMD_PERSIST_RU", raising=False)
@@ -46,12 +74,16 @@ def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves
     assert _kh("dl", 2000, 100) == 1 and _kh("langevin", 4000, 100) == 1      # two whole chains = four halves
     assert _kh("dl", 1500, 100) == 2 and _kh("langevin", 3000, 100) == 2      # 1.46 waves per SIMD: three halves < two wholes
     assert _kh("dl", 1000, 64) == 1                                           # one wave per row set: nothing to split
-    assert _kh("dl", 1000, 192) == 1 and _kh("dl", 500, 192) == 2 and _kh("langevin", 1000, 256) == 2  # 128 < N <= 256: same rule ...
+    assert _kh("dl", 1500, 192) == 1 and _kh("dl", 500, 192) == 2 and _kh("langevin", 1000, 256) == 2  # 128 < N <= 256: same rule ...
     assert _kh("dl", 4000, 256) == 2 and _kh("mf", 4000, 176) == 2 and _kh("langevin", 2000, 208) == 1  # ... unless a SIMD holds one unsplit wave
     # small batches, N > 128 (round 6): whole chains over TWO rows while every such row set has a CU of its own
     assert _kh("dl", 256, 144) == 1 and _kh("dl", 257, 144) == 2 and _kh("langevin", 512, 200) == 1 and _kh("langevin", 513, 200) == 2
     assert _kh("mf", 512, 224, adam=True) == 1 and _kh("mf", 512, 256) == 2 and _kh("dl", 100, 240) == 2  # (N <= 224: the unsplit kernel's registers)
     assert "persist_kernel<0, false, 64, 3, 9, 2, 1> grid 256 x 192 threads" in _describe("dl", 256, 144)
+    # more row sets than CUs, three waves side by side: two six-wave row sets per workgroup where that is fewer rounds x 1.6
+    assert "64, 3, 9, 4, 2, 0, 2> grid 250 x 768 threads" in _describe("dl", 1000, 144) and _kh("dl", 1500, 144) == 1
+    assert "0, 2> grid 150 x 768" in _describe("dl", 600, 160) and "0, 2> grid 250 x 768" in _describe("langevin", 2000, 176)
+    assert "0, 2>" not in _describe("langevin", 1000, 176) and "0, 2>" not in _describe("mf", 2000, 176, adam=True)
 
 
 @pytest.mark.parametrize("kh", ["2", "1"])

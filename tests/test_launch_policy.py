@@ -180,6 +180,7 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    clean_env.setenv("CCVM_AMD_PERSIST_RSW", "1")  # (not the twelve-wave workgroups of N <= 192: their own rule, tested below)
     for solver, adam in ((0, False), (1, False), (1, True), (2, False), (2, True)):
         for nch in range(9, 17):
             # B = 4096 rows per ... : whole rounds either way, so the split is taken only for the register reason
@@ -194,7 +195,7 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     (profiles/r06_ab_persist_ncg3.txt, r06_ab_persist_kh_small.txt) -- up to N = 224: from 15 K chunks on the unsplit kernel's
     registers turn the comparison around."""
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
-    shape = re.compile(r"persist_kernel<\d, \w+, 64, (\d), (\d+), (\d), (\d)(?:, 1)?> grid (\d+) x (\d+) threads")
+    shape = re.compile(r"persist_kernel<\d, \w+, 64, (\d), (\d+), (\d), (\d)(?:, \d)?(?:, \d)?> grid (\d+) x (\d+) threads")
 
     def plan(solver, b, n, adam=0):
         m = shape.search(_describe(hip_lib, solver, b, n, adam))
@@ -218,8 +219,32 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     assert plan(0, 100, 144)[2] == 4
     clean_env.delenv("CCVM_AMD_PERSIST_RU")
     # three waves side by side: the split where every wave has a SIMD of its own or the unsplit kernel holds one wave per
-    # SIMD, NOT for "three halves instead of two wholes" (DL N = 176, B = 1000: 2.26 us per step split, 1.96 whole)
-    assert plan(0, 1000, 176)[3] == 1 and plan(0, 1000, 100)[3] == 2 and plan(2, 1000, 176)[3] == 2 and plan(1, 2000, 176)[3] == 2
+    # SIMD, NOT for "three halves instead of two wholes" in six-wave workgroups (DL N = 176, B = 1000: 2.26 us per step, 1.96 whole)
+    assert plan(0, 1500, 176)[3] == 1 and plan(0, 1000, 100)[3] == 2 and plan(2, 1000, 176)[3] == 2 and plan(1, 3000, 176)[3] == 2
+    # ... but TWO six-wave row sets in a twelve-wave workgroup (three half chains on every SIMD) wherever rounds of those
+    # x 1.6 are fewer than rounds of single row sets (profiles/r06_ab_persist_rsw.txt)
+    two = lambda solver, b, n, adam=0: "0, 2> grid" in _describe(hip_lib, solver, b, n, adam)
+    assert plan(0, 1000, 176) == (3, 11, 4, 2, 250, 768) and two(0, 1000, 176) and two(0, 513, 144) and not two(0, 512, 144)
+    assert two(0, 2000, 160) and two(0, 4000, 192) and not two(0, 1500, 160)          # 4 / 8 rounds against 2 / 4; 3 against 2
+    assert two(2, 2000, 130) and not two(2, 1000, 130) and not two(2, 3000, 130) and two(1, 1500, 192)
+    assert two(1, 2000, 160, 1) and not two(1, 2000, 176, 1)                          # MF + Adam from 11 K chunks: > 168 VGPRs
+    assert not two(0, 1000, 200) and not two(0, 1000, 128)                            # three side by side only
+    clean_env.setenv("CCVM_AMD_PERSIST_RSW", "1")
+    assert not two(0, 1000, 176)
+    clean_env.setenv("CCVM_AMD_PERSIST_RSW", "2")
+    clean_env.setenv("CCVM_AMD_PERSIST_KH", "2")
+    assert two(0, 64, 176) and plan(0, 64, 176)[4:] == (16, 768)
+    clean_env.delenv("CCVM_AMD_PERSIST_RSW")
+    clean_env.delenv("CCVM_AMD_PERSIST_KH")
+    # the twelve-wave kernels fit three waves per SIMD
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    twelve = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<\d, \w+, 64, 3, \d+, 4, 2, 0, 2>", k["name"])]
+    assert len(twelve) == 18 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] for k in twelve), twelve
 
 
 def test_producer_waves_policy(hip_lib, clean_env):
