@@ -561,7 +561,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     double est = 0.0;
     if (want_persist(N, tun))
         est = persist_shape(solver, tun.adam, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus, tun.persist_pw,
-                            tun.persist_rsw).est_us;
+                            tun.persist_rsw, tun.persist_cw).est_us;
     else
         est = plan_us(solver, B, N, tun);
     const size_t used = std::strlen(buf);
@@ -612,7 +612,7 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
     }
     if (want_persist(N, tun)) {
         const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus,
-                                              tun.persist_pw, tun.persist_rsw);
+                                              tun.persist_pw, tun.persist_rsw, tun.persist_cw);
         if (sh.rsw == 2)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
@@ -744,6 +744,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
+        pa.cw_override = tun.persist_cw;
         pa.simds = 4 * chip_of(tun).cus;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
@@ -1031,6 +1032,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
+        pa.cw_override = tun.persist_cw;
         pa.simds = 4 * chip_of(tun).cus;
         pa.s_cols = s_cols;
         AdamSched asc;
@@ -1356,6 +1358,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         pa.kh_override = tun.persist_kh;
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
+        pa.cw_override = tun.persist_cw;
         pa.simds = 4 * chip_of(tun).cus;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);

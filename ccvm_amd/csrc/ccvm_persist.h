@@ -12,7 +12,7 @@
 // big tiles, but with M = 4, so a wave owns FEW rows and the batch spreads over all 1024 SIMDs
 // (B=1000 DL rows on the 16-row tile of v_mfma_f32_16x16x4_f32 filled 125 of 256 CUs).
 //
-//   shape (CW, NCG): a wave covers CW columns (16 / 32 / 64) and RG = 64 / CW row groups of 4 MFMA
+//   shape (CW, NCG): a wave covers CW columns (16 / 32 / 64; 64 < N <= 96 also three 32-column waves) and RG = 64 / CW row groups of 4 MFMA
 //     rows; N > 64 uses NCG = 2 waves side by side (128 columns; N > 128: 3, N > 192: 4) which exchange the state
 //     through a double-buffered LDS tile and one barrier per step; N <= 64 is ONE wave per row set.
 //   RU (2 or 4) = MFMA rows in use per group: 4 when that still gives every SIMD a wave, else 2
@@ -73,6 +73,7 @@ struct PersistArgs {
     int simds;           // host only: SIMDs of the chip the shape is planned for (4 per CU; 0 = 1024)
     int pw_override;     // host only: 1 / 2 forces the noise producer waves off / on (tuning), 0 = by shape and batch size
     int rsw_override;    // host only: 1 / 2 forces the row sets per six-wave workgroup (tuning), 0 = by batch size
+    int cw_override;     // host only: 32 / 64 forces three 32-column / two 64-column waves side by side at 64 < N <= 96 (tuning)
     AdamConsts ad;
     unsigned long long* dbg;  // tools/persist_ablate.hip, CCVM_PERSIST_ABL & 16: s_memtime sums, [grid][16]
 };
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     static_assert(RSWO == 0 || (PW == 0 && 64 * NCG * KH * RSWO <= 1024), "row sets per workgroup: at most sixteen waves, no producers");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
-    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG >= 2 && NCG <= 4 && CW == 64)), "shape");
+    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG >= 2 && NCG <= 4 && CW == 64) || (NCG == 3 && CW == 32)), "shape");
+    static_assert(KH == 1 || CW == 64, "K split: 64-column waves");
     static_assert(RU == 2 || RU == 4, "rows in use per group");
     constexpr int RG = 64 / CW;                                // row groups per wave
     static_assert(NCH >= 1 && 16 * NCH <= CW * NCG, "K chunks vs shape");

@@ -29,17 +29,40 @@ constexpr int PERSIST_PW_MAX_NCG = 2;  // noise producer waves are instantiated 
 // solver: 0 DL, 1 MF, 2 Langevin / pumped Langevin (the C ABI's numbering)
 // pw_override: 1 / 2 forces the noise producer waves off / on (where the shape has them), 0 = by shape and batch size
 // rsw_override: 1 / 2 forces the row sets per workgroup of six-wave row sets, 0 = by batch size
+// cw_override: 32 / 64 forces the wave shape at 64 < N <= 96 (three 32-column waves of eight rows / two 64-column waves of four)
 inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_override, int kh_override = 0, int simds = 1024,
-                                  int pw_override = 0, int rsw_override = 0) {
+                                  int pw_override = 0, int rsw_override = 0, int cw_override = 0) {
     const bool dl = solver == 0;
     if (simds <= 0) simds = 1024;
     PersistShape s;
     s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
     s.cw = s.nch == 1 ? 16 : s.nch == 2 ? 32 : 64;                   // columns a wave covers
     s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : (CCVM_PERSIST_NCG3 && s.nch <= 12) ? 3 : 4;  // waves side by side
+    // 64 < N <= 96 (round 6): THREE 32-column waves side by side, two row groups (eight MFMA rows) each -- 96 columns instead
+    // of 128 for the same rows, three waves where two pairs stood; whole chains, producers next to them.  Bit-identical to
+    // the 64-column waves' whole chains.  Same-box sweep (profiles/r06_ab_persist_cw32.txt, tools/ab_persist_cw32.sh): mostly a
+    // wash -- every wave's chain is as long as before -- but two kinds of cells gain: (1) a batch that needs TWO eight-wave
+    // workgroups of the wide shape on a CU and ONE six-wave workgroup of this one (DL N = 70, B = 1000: 0.765 -> 0.72 us per
+    // step; Langevin B = 1500 / 2000: 0.78 -> 0.70, + Adam 1.07 -> 0.96; MF: +-1 %, + Adam worse: left alone); (2) the Adam
+    // variants while every two-row set has a CU (Langevin + Adam N = 70, B <= 1000: 0.82 -> 0.69; MF + Adam 0.94 -> 0.85).
+    // Elsewhere the wide shape stays.
+    bool narrow = false;
+    int narrow_ru = 0;  // the rows in use and producers that come with the rule (0: as forced / by the generic rules)
+    if (s.nch == 5 || s.nch == 6) {
+        if (cw_override == 32) {
+            narrow = true;
+        } else if (cw_override == 0 && !ru_override && !kh_override && !pw_override) {
+            const int rows64 = dl ? 2 : 4, cus = simds / 4;
+            const int sets64 = (B + rows64 - 1) / rows64, sets32 = (B + 2 * rows64 - 1) / (2 * rows64);
+            if (solver != 1 && sets64 > cus && sets32 <= cus) { narrow = true; narrow_ru = 4; }
+            else if (adam && sets64 <= cus) { narrow = true; narrow_ru = 2; }
+        }
+    }
+    if (narrow) { s.cw = 32; s.ncg = 3; }
     const int br4 = (dl ? 2 : 4) * (64 / s.cw);                      // batch rows per row set at RU = 4
     s.ru = ((B + br4 - 1) / br4) * s.ncg >= 768 ? 4 : 2;
     if (ru_override == 2 || ru_override == 4) s.ru = ru_override;
+    if (narrow_ru) s.ru = narrow_ru;
     // Two waves side by side (64 < N <= 128): K can be split over two waves instead of idling two MFMA rows -- twice the
     // waves at half the chain each.  A step costs what the fullest SIMD issues: with w = waves per SIMD at four rows in
     // use, ceil(w) whole chains against ceil(2 w) half chains (DL N = 100, us per step, whole / split: B = 1500, w = 1.46:
@@ -48,7 +71,7 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     // second, independent half-chain wave fills: w <= 1 takes the split too (Langevin B = 1000 0.82 -> 0.68, MF 0.94 ->
     // 0.84, DL B <= 512 0.79 -> 0.66, DL B = 1000 0.95 -> 0.94).
     s.kh = 1;
-    if (s.ncg >= 2) {
+    if (s.ncg >= 2 && !narrow) {
         const int waves4 = ((B + br4 - 1) / br4) * s.ncg;
         const int whole = (waves4 + simds - 1) / simds, halves = (2 * waves4 + simds - 1) / simds;
         // Four waves side by side (128 < N <= 256): from this many K chunks on the unsplit kernel needs more than 256
@@ -88,7 +111,7 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     // profiles/r06_ab_persist_rsw.txt).  Twelve waves need <= 168 VGPRs: not MF + Adam from 11 K chunks (tests/test_launch_policy.py).
     s.rsw = 0;
     const bool rsw_fits = !(solver == 1 && adam && s.nch >= 11);
-    if (s.ncg == 3 && rsw_fits) {
+    if (s.ncg == 3 && !narrow && rsw_fits) {
         const int cus = simds / 4, sets4 = (B + br4 - 1) / br4;
         const int r1 = (sets4 + cus - 1) / cus, r2 = (sets4 + 2 * cus - 1) / (2 * cus);  // rounds of one / two row sets per CU
         const bool pays = 8 * r2 < 5 * r1 && kh_override != 1 && !(ru_override == 2 || ru_override == 4);
@@ -118,6 +141,8 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
             }
         }
         s.est_us = best < 1e30 ? best : 0.0;
+    } else if (narrow) {
+        if (pw_override == 2 || narrow_ru) s.pw = 1;
     } else if (s.ncg == 2 && s.kh == 2) {
         // Two waves side by side: producers next to the K split while a SIMD holds at most two half-chain consumers (DL
         // N = 100: B = 1000 0.95 -> 0.87 us per step, B = 1500 1.26 -> 1.35; Langevin B = 2000 0.98 -> 0.92, B = 3000 1.30 ->
@@ -133,7 +158,7 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     // (two waves side by side: producers only next to the K split -- with whole chains the consumers and producers of a
     // four-wave workgroup sit on different SIMDs and two such workgroups per CU cost more than they save: DL N = 100,
     // B = 1000 1.06 us per step against 0.93 without, role swap or not)
-    if (pw_override == 2 && (s.ncg == 1 || (s.ncg == 2 && s.kh == 2))) s.pw = 1;
+    if (pw_override == 2 && (s.ncg == 1 || narrow || (s.ncg == 2 && s.kh == 2))) s.pw = 1;
     const int wps = s.ncg * s.kh * (1 + s.pw);                       // waves per row set
     const int sets = s.rsw ? s.rsw : wps > 4 ? 1 : 4 / wps;          // row sets per workgroup
     const int per = br4 * s.ru / 4 * sets;                           // batch rows per workgroup
@@ -148,11 +173,12 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
 template <int MODE, bool ADAM, int CW, int NCG, int NCH>
 void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
     const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, ADAM, a.B, a.N, a.ru_override,
-                                          a.kh_override, a.simds, a.pw_override, a.rsw_override);  // sh.cw == CW etc. by construction
+                                          a.kh_override, a.simds, a.pw_override, a.rsw_override, a.cw_override);  // sh.cw == CW etc. by construction
+    constexpr bool NARROW = CW == 32 && NCG == 3;  // (whole chains only)
     const dim3 block(sh.threads);  // row sets of NCG x KH (x 2 with producers) waves per workgroup (ccvm_persist.h: RSW)
-    if constexpr (NCG <= PERSIST_PW_MAX_NCG) {
+    if constexpr (NCG <= PERSIST_PW_MAX_NCG || NARROW) {
         if (sh.pw) {  // as many producer waves as consumer waves
-            if constexpr (NCG >= 2) {  // (next to the K split only: persist_shape)
+            if constexpr (NCG >= 2 && !NARROW) {  // (next to the K split only: persist_shape)
                 hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 1>), dim3(sh.grid), block, 0, st, a);
             } else {
                 if (sh.ru == 4)
@@ -163,13 +189,13 @@ void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
             return;
         }
     }
-    if constexpr (NCG == 3 && !(MODE == MODE_MF && ADAM && NCH >= 11)) {  // (MF + Adam from 11 K chunks: > 168 VGPRs, persist_shape)
+    if constexpr (NCG == 3 && !NARROW && !(MODE == MODE_MF && ADAM && NCH >= 11)) {  // (MF + Adam from 11 K chunks: > 168 VGPRs, persist_shape)
         if (sh.kh == 2 && sh.rsw == 2) {  // two row sets of six waves
             hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 0, 2>), dim3(sh.grid), block, 0, st, a);
             return;
         }
     }
-    if constexpr (NCG >= 2) {
+    if constexpr (NCG >= 2 && !NARROW) {
         if (sh.kh == 2) {  // one row set of NCG x 2 waves
             hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2>), dim3(sh.grid), block, 0, st, a);
             return;
@@ -188,8 +214,19 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
         case 2: launch_persist_shape<MODE, ADAM, 32, 1, 2>(a, st); break;
         case 3: launch_persist_shape<MODE, ADAM, 64, 1, 3>(a, st); break;
         case 4: launch_persist_shape<MODE, ADAM, 64, 1, 4>(a, st); break;
-        case 5: launch_persist_shape<MODE, ADAM, 64, 2, 5>(a, st); break;
-        case 6: launch_persist_shape<MODE, ADAM, 64, 2, 6>(a, st); break;
+        case 5:
+        case 6: {
+            const bool narrow = persist_shape(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, ADAM, a.B, a.N, a.ru_override, a.kh_override,
+                                              a.simds, a.pw_override, a.rsw_override, a.cw_override).cw == 32;
+            if ((a.N + 15) / 16 == 5) {
+                if (narrow) launch_persist_shape<MODE, ADAM, 32, 3, 5>(a, st);
+                else launch_persist_shape<MODE, ADAM, 64, 2, 5>(a, st);
+            } else {
+                if (narrow) launch_persist_shape<MODE, ADAM, 32, 3, 6>(a, st);
+                else launch_persist_shape<MODE, ADAM, 64, 2, 6>(a, st);
+            }
+            break;
+        }
         case 7: launch_persist_shape<MODE, ADAM, 64, 2, 7>(a, st); break;
         case 8: launch_persist_shape<MODE, ADAM, 64, 2, 8>(a, st); break;
         case 9: launch_persist_shape<MODE, ADAM, 64, CCVM_PERSIST_NCG3 ? 3 : 4, 9>(a, st); break;

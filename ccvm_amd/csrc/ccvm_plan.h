@@ -35,6 +35,7 @@ namespace ccvm {
 //   CCVM_AMD_PERSIST_RU=2|4   rows in use per 4-row group of the persistent kernel
 //   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
 //   CCVM_AMD_PERSIST_RSW=1|2  row sets per workgroup of its six-wave row sets (128 < N <= 192 with the K split; default: by batch size)
+//   CCVM_AMD_PERSIST_CW=32|64 64 < N <= 96: three 32-column waves side by side (eight rows each) / two 64-column waves
 //   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 20 ms or 50
 //                             estimated steps; rehearsals that put several processes on ONE GPU raise it)
 constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
@@ -49,6 +50,7 @@ struct Tuning {
     int persist_kh = 0;  // K split of the two-wave shapes (64 < N <= 128): 1 off, 2 on, 0: by batch size
     int persist_pw = 0;  // noise producer waves of the row-owner kernel: 1 off, 2 on, 0: by shape and batch size
     int persist_rsw = 0; // row sets per workgroup where a row set is six waves (128 < N <= 192, K split): 1 / 2, 0: by batch size
+    int persist_cw = 0;  // 64 < N <= 96: 32 = three 32-column waves side by side (eight rows each), 64 = two 64-column waves, 0: by policy
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     double spin_ms = 0.0;  // CCVM_AMD_SPIN_MS: > 0 replaces the bound of the cross-workgroup waits
     int cluster_sets = 0;  // CCVM_AMD_CLUSTER_SETS=2|3 (tuning): that many row sets per cluster above K = 512; 0: cluster_sets()

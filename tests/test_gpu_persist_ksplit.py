@@ -67,6 +67,39 @@ def test_two_row_sets_per_workgroup_are_bit_identical_to_one(monkeypatch):
             assert torch.equal(one.compact(name), two.compact(name)), (kind, name)
 
 
+@pytest.mark.parametrize("pw", ["0", "1"])
+@pytest.mark.parametrize("ru", ["2", "4"])
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("dl", 65, 7, 30, None), ("dl", 70, 1000, 12, None), ("dl", 80, 33, 30, None), ("dl", 96, 130, 20, None), ("dl", 81, 1, 30, None),
+    ("mf", 72, 9, 30, "second_moment"), ("mf", 96, 1000, 10, None), ("mf", 70, 515, 12, "add_assign"),
+    ("langevin", 81, 5, 30, "first_moment_only"), ("langevin", 70, 1027, 10, None), ("pl", 90, 300, 16, "second_moment"),
+])
+def test_three_narrow_waves_side_by_side_match_oracle(monkeypatch, kind, n, b, t, adam, ru, pw):
+    """Round 6: 64 < N <= 96 as THREE 32-column waves side by side, two row groups (eight MFMA rows) each, whole chains, with
+    and without noise producer waves, two and four rows in use."""
+    monkeypatch.setenv("CCVM_AMD_PERSIST_CW", "32")
+    monkeypatch.setenv("CCVM_AMD_PERSIST_RU", ru)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_PW", pw)
+    d = _describe(kind, b, n, adam is not None)
+    assert re.search(r"persist_kernel<\d, \w+, 32, 3, [56], %s, 1%s> grid \d+ x %d threads" % (ru, ", 1" if pw == "1" else "", 384 if pw == "1" else 192), d), d
+    _check_against_oracle(kind, n, b, t, adam)
+
+
+def test_narrow_waves_are_bit_identical_to_wide_ones(monkeypatch):
+    """Whole chains either way: a column's arithmetic does not depend on the wave shape (64 columns x 4 rows or 32 x 8)."""
+    for kind, n, b in (("dl", 70, 333), ("mf", 96, 200), ("langevin", 65, 1027)):
+        adam = None if kind == "dl" else _ADAMS["add_assign"]
+        monkeypatch.setenv("CCVM_AMD_PERSIST_KH", "1")
+        monkeypatch.setenv("CCVM_AMD_PERSIST_PW", "0")
+        monkeypatch.setenv("CCVM_AMD_PERSIST_CW", "64")
+        wide = _run_engine(kind, n, b, 24, adam, 777, 0)
+        monkeypatch.setenv("CCVM_AMD_PERSIST_CW", "32")
+        monkeypatch.setenv("CCVM_AMD_PERSIST_PW", "1")
+        narrow = _run_engine(kind, n, b, 24, adam, 777, 0, chunks=[1, 9, 3, 11])
+        for name in wide.state:
+            assert torch.equal(wide.compact(name), narrow.compact(name)), (kind, name)
+
+
 def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_PERSIST_KH", raising=False)
     monkeypatch.delenv("CCVM_AMD_PERSIST_RU", raising=False)

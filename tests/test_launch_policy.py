@@ -247,6 +247,36 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     assert len(twelve) == 18 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] for k in twelve), twelve
 
 
+def test_narrow_waves_between_64_and_96_columns(hip_lib, clean_env):
+    """Round 6: 64 < N <= 96 can run THREE 32-column waves of eight rows side by side instead of two 64-column waves of four
+    (ccvm_persist_launch.h: narrow).  Mostly a wash (profiles/r06_ab_persist_cw32.txt); taken where (1) the wide shape needs two
+    eight-wave workgroups on a CU and this one six-wave workgroup (DL, Langevin without Adam), (2) the Adam variants while
+    every two-row set has a CU of its own."""
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    narrow = lambda solver, b, n, adam=0: re.search(r"persist_kernel<\d, \w+, 32, 3, [56], (\d), 1, 1> grid (\d+) x 384 threads", _describe(hip_lib, solver, b, n, adam))
+    for n in (65, 70, 80, 96):
+        assert narrow(0, 1000, n).groups() == ("4", "250") and narrow(0, 513, n) and narrow(0, 1024, n)
+        assert not narrow(0, 512, n) and not narrow(0, 1025, n) and not narrow(0, 100, n)
+        assert narrow(2, 2000, n).groups() == ("4", "250") and narrow(2, 1025, n) and not narrow(2, 1000, n) and not narrow(2, 2049, n)
+        assert not narrow(1, 1500, n)                                        # MF without Adam: +-1 %, left alone
+        for solver in (1, 2):                                                # the Adam variants: two rows in use, B <= 4 x CUs
+            assert narrow(solver, 1000, n, 1).groups() == ("2", "250") and narrow(solver, 1, n, 1) and narrow(solver, 1024, n, 1)
+            assert (narrow(solver, 1025, n, 1) is not None) == (solver == 2) and not narrow(solver, 4000, n, 1)
+        assert narrow(2, 2048, n, 1).groups() == ("4", "256")               # Langevin + Adam: rule (1) as without Adam
+    assert not narrow(0, 1000, 64) and not narrow(0, 1000, 97) and not narrow(0, 1000, 100)
+    # any override of the wide shape's dimensions keeps the wide shape; CCVM_AMD_PERSIST_CW pins the choice
+    clean_env.setenv("CCVM_AMD_PERSIST_KH", "2")
+    assert not narrow(0, 1000, 70)
+    clean_env.delenv("CCVM_AMD_PERSIST_KH")
+    clean_env.setenv("CCVM_AMD_PERSIST_CW", "64")
+    assert not narrow(0, 1000, 70) and not narrow(2, 1000, 70, 1)
+    clean_env.setenv("CCVM_AMD_PERSIST_CW", "32")
+    assert "persist_kernel<0, false, 32, 3, 5, 2, 1> grid 50 x 192 threads" in _describe(hip_lib, 0, 100, 70)  # (two rows in use x two row groups: two DL rows per wave set)
+    clean_env.delenv("CCVM_AMD_PERSIST_CW")
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")                          # half the chip: half the batch
+    assert narrow(0, 500, 70) and not narrow(0, 1000, 70)
+
+
 def test_producer_waves_policy(hip_lib, clean_env):
     """Round 6: the row-owner kernel's noise producer waves (ccvm_persist.h, PW).  N <= 64: the variant (rows in use x
     producers) with the smallest estimate of the fitted model (ccvm_persist_model.h, generated); 64 < N <= 128: next to
@@ -300,6 +330,7 @@ def test_producer_waves_policy(hip_lib, clean_env):
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     assert len(regs) == 20
+    clean_env.setenv("CCVM_AMD_PERSIST_CW", "64")  # (the 64-column shape's own rule; where 64 < N <= 96 goes narrow: the test above)
     for (solver, adam, nch), vgpr in regs.items():
         # B = 1500 one-stream rows (375 row sets: two workgroups on some CUs) / 700 DL rows (350 row sets)
         p = plan(solver, 1500 if solver else 700, 16 * nch, 1 if adam else 0)

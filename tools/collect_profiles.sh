@@ -17,7 +17,7 @@ pmc pl_n2000_b512 pl_n2000_b512 'ptile_kernel<2' 600 "ccvm::ptile_kernel<2> = pu
 pmc langevin_n500_b1000 langevin_n500_b1000 'cluster_kernel<2' 600 "ccvm::cluster_kernel<2, false, 4, false> = Langevin, N=500, B=1000 $PERS"
 pmc mf_n500_b1000 mf_n500_b1000 'cluster_kernel<1' 600 "ccvm::cluster_kernel<1, false, 4, false> = MF, N=500, B=1000 $PERS"
 pmc dl_n100_b1000 dl_n100_b1000 'persist_kernel<0, false, 64, 2, 7, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2, 1> = DL, N=100, B=1000: K split + noise producer waves $PERS"
-pmc dl_n70_b1000 dl_n70_b1000 'persist_kernel<0, false, 64, 2, 5, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 5, 4, 2, 1> = DL, N=70, B=1000: K split + noise producer waves $PERS"
+pmc dl_n70_b1000 dl_n70_b1000 'persist_kernel<0, false, 32, 3, 5, 4, 1, 1' 600 "ccvm::persist_kernel<0, false, 32, 3, 5, 4, 1, 1> = DL, N=70, B=1000: three 32-column waves of eight rows + noise producer waves $PERS"
 pmc dl_n20_b1000 dl_n20_b1000 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (tuningH020-100-0), B=1000: one wave per row set + noise producer waves $PERS"
 pmc dl_n20_b100 dl_n20_b100 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (test020-100-10), B=100: BASELINE config 1 $PERS"
 pmc mf_n20_b1000 mf_n20_b1000 'persist_kernel<1, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<1, false, 32, 1, 2, 2, 1, 1> = MF, N=20, B=1000 $PERS"
