@@ -453,6 +453,7 @@ size_t ccvm_workspace_bytes(int solver, int B, int N) {
     if (solver < 0 || solver > 2 || B <= 0 || N <= 0) return plain;
     Tuning tun = read_tuning();
     if (tun.split < 0) tun.split = 1;  // (whatever the estimates say at run time: room for the cut)
+    tun.persist_wide = 0;              // (... and whichever solver variant runs: the Adam variants of 256 < N <= 320 are cut)
     tun.ptile = tun.ptile ? -1 : 0;
     tun.ks = 0;
     tun.slab = tun.slab ? -1 : 0;
@@ -559,7 +560,7 @@ int ccvm_describe_launch(int solver, int B, int N, int adam, int per_variable_s,
     Tuning tun = read_tuning();
     tun.adam = adam && solver != 0;
     double est = 0.0;
-    if (want_persist(N, tun))
+    if (want_persist(N, tun, solver, B))
         est = persist_shape(solver, tun.adam, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus, tun.persist_pw,
                             tun.persist_rsw, tun.persist_cw).est_us;
     else
@@ -582,7 +583,7 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
         std::snprintf(buf, buf_len, "batch cut in two: rows 0-%d %s | rows %d-%d %s", cut - 1, first, cut, B - 1, rest);
         return CCVM_OK;
     }
-    if (const SlabPlan sp = want_persist(N, tun) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
+    if (const SlabPlan sp = want_persist(N, tun, solver, B) ? SlabPlan{} : want_slab(B, N, tun, solver); sp.ok) {
         // the fourth template argument: launches of 512 steps or more of clusters that span XCDs calibrate their
         // fetch delay (ccvm_slab.h: slab_calibrates); shorter launches of the same shape run the `false` variant
         char where[48] = "";
@@ -593,7 +594,7 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
                       where, TABLE_STEPS);
         return CCVM_OK;
     }
-    if (!want_persist(N, tun) && want_cluster(B, N, tun, solver, ad)) {
+    if (!want_persist(N, tun, solver, B) && want_cluster(B, N, tun, solver, ad)) {
         const ChipGeometry chip = chip_of(tun);
         const int G = (N + CL_COLS - 1) / CL_COLS, count = cluster_count(B, N, chip, tun.cluster_sets);
         const bool spread = cluster_spread(B, N, chip, tun.cluster_sets);
@@ -610,10 +611,14 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
                       spread ? ", spread over the XCDs" : "", TABLE_STEPS);
         return CCVM_OK;
     }
-    if (want_persist(N, tun)) {
+    if (want_persist(N, tun, solver, B)) {
         const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus,
                                               tun.persist_pw, tun.persist_rsw, tun.persist_cw);
-        if (sh.rsw == 2)
+        if (sh.ncg == 5)
+            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d> grid %d x %d threads (five waves side by side, %d of a wave's %d fragments in LDS), up to %d steps per launch",
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - PERSIST_WIDE_KR, sh.grid, sh.threads,
+                          8 * sh.nch - PERSIST_WIDE_KR, 8 * sh.nch, TABLE_STEPS);
+        else if (sh.rsw == 2)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
         else if (sh.pw)
@@ -732,7 +737,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
     a.in_scale = (float)(ul / Sd);
     a.in_shift = (float)up;
     if (nsteps > 0 && (rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 2 * state, st, &a.qsum, p->qsum))) return rc;
-    if (nsteps > 0 && want_persist(N, tun)) {
+    if (nsteps > 0 && want_persist(N, tun, MODE_DL, B)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         float* table = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N));
         PersistArgs pa;
@@ -766,7 +771,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         }
         return CCVM_OK;
     }
-    if (const SlabPlan sp = (nsteps > 0 && !want_persist(N, tun)) ? want_slab(B, N, tun, MODE_DL) : SlabPlan{}; sp.ok) {
+    if (const SlabPlan sp = (nsteps > 0 && !want_persist(N, tun, MODE_DL, B)) ? want_slab(B, N, tun, MODE_DL) : SlabPlan{}; sp.ok) {
         // small batch: whole chunks in one launch each, Q resident in the members' registers (ccvm_slab.h)
         char* after = static_cast<char*>(ws) + 2 * state * sizeof(float) + qsum_area_bytes(N);
         float* table = reinterpret_cast<float*>(after);
@@ -1016,7 +1021,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         return CCVM_OK;
     }
 
-    if (want_persist(N, tun)) {
+    if (want_persist(N, tun, MODE_MF, B)) {
         // whole chunks of the trajectory in one launch each (ccvm_persist.h)
         const float* qsum;
         if ((rc = compute_qsum(Q, N, ld, static_cast<float*>(ws) + 3 * state, st, &qsum, p->qsum))) return rc;
@@ -1348,7 +1353,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         }
         return CCVM_OK;
     }
-    if (want_persist(N, tun)) {
+    if (want_persist(N, tun, MODE_LANGEVIN, B)) {
         PersistArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.Q = a.Q; pa.V = V; pa.qsum = a.qsum; pa.x0 = c; pa.table = table; pa.s_cols = s_cols;

@@ -110,6 +110,13 @@ __device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf
     ((acc[I & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[(OFF + I) / KC], qf[I], acc[I & 3], CBSZ, (OFF + I) % KC, 0)), ...);
 }
 
+// K split with part of the fragments in LDS (QL): the k-steps OFF + IB .. OFF + IB + 3 of one half, their fragments in q
+template <int CBSZ, int KC, int OFF, int IB, int... J>
+__device__ __forceinline__ void mfma_group4(const float* af, f32x4v q, f32x4v* acc, std::integer_sequence<int, J...>) {
+    ((acc[(IB + J) & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[(OFF + IB + J) / KC], q[J], acc[(IB + J) & 3], CBSZ,
+                                                            (OFF + IB + J) % KC, 0)), ...);
+}
+
 // K tail (measured and left off): the last chunk of 16 k-steps runs only the groups of four that hold
 // a k < N (N = 100: 100 MFMAs per
 // step instead of 112; wave-uniform scalar branches behind the straight-line part)
@@ -135,6 +142,9 @@ __device__ __forceinline__ void mfma_chain_half(const float* af, const float* qf
 // column's arithmetic does not depend on how many waves stand next to its own): at B >= 768 nothing changes -- within 2 %
 // either way; the fullest SIMD of a CU holds as many waves as before -- but small batches on whole chains, one workgroup
 // per CU, are 2-9 % faster without it (MF N = 144, B <= 512: 1.15 -> 1.04 us per step; DL 0.90 -> 0.88; Langevin 0.95 -> 0.92).
+#ifndef CCVM_PERSIST_QL_AHEAD
+#define CCVM_PERSIST_QL_AHEAD 2   // fragments in LDS (QL): groups of four read ahead of their MFMAs (3: two registers spilled at N > 288)
+#endif
 #ifndef CCVM_PERSIST_NCG3
 #define CCVM_PERSIST_NCG3 1
 #endif
@@ -161,14 +171,19 @@ constexpr int persist_block_threads(int ncg, int kh, int pw, int rswo) {
 // RSWO = 2 (round 6): TWO row sets per workgroup where a row set is six waves (three side by side x two K halves) -- twelve
 // waves are three per SIMD, where two six-wave workgroups on a CU put four on two of its SIMDs and two on the others
 // (HW_ID of every wave: tools/simd_probe.hip, profiles/r06_simd_probe.txt) and a step costs what the fullest SIMD issues.
-template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0>
+// QL > 0 (round 6, FIVE waves side by side: 256 < N <= 320): the LAST QL k-steps of a wave's K half keep their fragments in LDS
+// -- ten waves are three on some SIMD, 168 registers each, and 160 fragments + the working set do not fit; the fragments of a
+// wave's own column, [k / 4][lane][k % 4], read back four at a time (one ds_read_b128 per four MFMAs, conflict-free) a few
+// groups ahead of their MFMAs.
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0, int QL = 0>
 __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void persist_kernel(const PersistArgs a) {
-    static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 4 && RU == 4), "K split: waves side by side, all four rows in use");
+    static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 5 && RU == 4), "K split: waves side by side, all four rows in use");
+    static_assert(QL == 0 || (KH == 2 && QL % 4 == 0 && PW == 0 && RSWO == 0), "fragments in LDS: K split only, whole groups of four");
     static_assert(PW == 0 || (PW == 1 && NCG * KH <= 4), "producer waves: at most eight waves per workgroup");
     static_assert(RSWO == 0 || (PW == 0 && 64 * NCG * KH * RSWO <= 1024), "row sets per workgroup: at most sixteen waves, no producers");
     static_assert(MODE == MODE_DL || MODE == MODE_MF || MODE == MODE_LANGEVIN, "persistent kernel: solver loops only");
     static_assert(!(ADAM && MODE == MODE_DL), "DL has no Adam variant (dl_solver.py:571-769 is unreachable)");
-    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG >= 2 && NCG <= 4 && CW == 64) || (NCG == 3 && CW == 32)), "shape");
+    static_assert((CW == 16 || CW == 32 || CW == 64) && (NCG == 1 || (NCG >= 2 && NCG <= 5 && CW == 64) || (NCG == 3 && CW == 32)), "shape");
     static_assert(KH == 1 || CW == 64, "K split: 64-column waves");
     static_assert(RU == 2 || RU == 4, "rows in use per group");
     constexpr int RG = 64 / CW;                                // row groups per wave
@@ -205,9 +220,11 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     // dt, S, has_next (unused here), + the unused words 14, 15; Langevin: all but the pump term
     constexpr unsigned ROW_SAME = (MODE == MODE_DL) ? 0x030u : (MODE == MODE_MF) ? 0xCD8Eu : 0xC0FBu;
     constexpr int PXA = (RSWO ? RSW : 1) * PXF;                // (without RSWO a K-split workgroup is one row set)
-    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXA + NZF + RING];
+    constexpr int QTF = QL * 64 * NWC;                         // fragments kept in LDS: [consumer wave][k / 4][lane][k % 4]
+    __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXA + NZF + RING + QTF];
     float* const nzl = xs_all + RSW * 2 * ROWS * LDX + PXA;
     float* const ring = nzl + NZF;
+    float* const qtail = ring + RING;
 
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -235,12 +252,24 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     constexpr int KSPLIT = (KH == 2) ? (KMAX / 2 + 3) / 4 * 4 : KMAX;  // k-steps per half, a multiple of 4
     constexpr int KQ = (KH == 2) ? KSPLIT : KMAX;
     const int koff = kh * KSPLIT;
-    float qf[KQ];
+    constexpr int KR = KQ - QL;  // fragments in registers: the first KR k-steps of the wave's range
+    static_assert(KR >= 4, "fragments in LDS: some stay in registers");
+    float qf[KR];
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) qf[k] = 0.0f;
+    for (int k = 0; k < KR; ++k) qf[k] = 0.0f;
     if (!producer) {
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+        for (int k = 0; k < KR; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+    }
+    float* const qt = qtail + wave * (QL * 64) + lane * 4;  // this lane's fragments of group g: qt[g * 256 .. + 3]
+    if constexpr (QL > 0) {
+#pragma unroll
+        for (int g = 0; g < QL / 4; ++g) {
+            f32x4v q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = (koff + KR + 4 * g + j < KMAX) ? a.Q[(size_t)(koff + KR + 4 * g + j) * ld + col] : 0.0f;
+            *reinterpret_cast<f32x4v*>(qt + g * 256) = q;  // (read back by this lane only: no barrier)
+        }
     }
     const float vj = col_ok ? a.V[col] : 0.0f;
     const float shift_j = a.in_shift * a.qsum[col];  // shift * colsum(Q)[j]
@@ -504,6 +533,21 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
                 if (rem > 4) mfma_chain_at<CBSZ, KC, FULL + 4>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 8) mfma_chain_at<CBSZ, KC, FULL + 8>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 12) mfma_chain_at<CBSZ, KC, FULL + 12>(af, qf, acc, std::make_integer_sequence<int, 4>{});
+            } else if constexpr (KH == 2 && QL > 0) {
+                static_assert(K1 - K0 == KQ, "fragments in LDS: equal halves");
+                constexpr int G = QL / 4, AHEAD = CCVM_PERSIST_QL_AHEAD;  // groups of four k-steps out of LDS, read AHEAD groups ahead of their MFMAs
+                f32x4v qb[AHEAD];
+#pragma unroll
+                for (int g = 0; g < AHEAD && g < G; ++g) qb[g] = *reinterpret_cast<const f32x4v*>(qt + g * 256);
+                mfma_chain_half<CBSZ, KC, K0>(af, qf, acc, std::make_integer_sequence<int, KR>{});  // (covers the first reads)
+                unroll_indices([&](auto g_tag) {
+                    constexpr int g = decltype(g_tag)::value;
+                    mfma_group4<CBSZ, KC, K0, KR + 4 * g>(af, qb[g % AHEAD], acc, std::make_integer_sequence<int, 4>{});
+                    if constexpr (g + AHEAD < G) {
+                        qb[g % AHEAD] = *reinterpret_cast<const f32x4v*>(qt + (g + AHEAD) * 256);
+                        __builtin_amdgcn_sched_barrier(0);  // (keeps the reads where they are: hoisted, they would all be live at once)
+                    }
+                }, std::make_integer_sequence<int, G>{});
             } else if constexpr (KH == 2) {
                 mfma_chain_half<CBSZ, KC, K0>(af, qf, acc, std::make_integer_sequence<int, K1 - K0>{});
             } else {

@@ -6,10 +6,24 @@
 
 #include "ccvm_persist.h"
 #include "ccvm_persist_model.h"
+#include "ccvm_plan_model.h"
 
 namespace ccvm {
 
 constexpr int PERSIST_MAX_N = 256;
+// FIVE waves side by side x two K halves (round 6): 256 < N <= 320, part of every wave's fragments in LDS (ccvm_persist.h: QL).
+// Ten waves are three on some SIMD -- 168 registers -- and the working set next to the fragments must leave room for 104 of
+// them: DL and Langevin / pumped Langevin without Adam (MF spills 20 registers at that split, the Adam variants more; their
+// fragments beyond what LDS holds: those stay on the column-cluster kernel).
+constexpr int PERSIST_WIDE_MAX_N = 320;
+constexpr int PERSIST_WIDE_KR = 104;  // fragments of a wave kept in registers; the other 8 NCH - 104 (32 ... 56) in LDS
+inline bool persist_wide_ok(int solver, bool adam) { return solver == 0 || (solver == 2 && !adam); }
+// its estimate: rounds of one row set (two DL rows, four of a one-stream solver) per CU x the measured round
+inline double persist_wide_us(int solver, int B, int N, int cus) {
+    const int nch = (N + 15) / 16, rows = solver == 0 ? 2 : 4, sets = (B + rows - 1) / rows;
+    const int k = nch < 17 ? 0 : nch > 20 ? 3 : nch - 17;
+    return (double)((sets + cus - 1) / cus) * PERSIST_WIDE_ROUND_US[solver == 0 ? 0 : 1][k];
+}
 
 void persist_launch_dl(const PersistArgs& a, hipStream_t st);
 void persist_launch_mf(const PersistArgs& a, hipStream_t st);
@@ -35,9 +49,9 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     const bool dl = solver == 0;
     if (simds <= 0) simds = 1024;
     PersistShape s;
-    s.nch = (N + 15) / 16 > 16 ? 16 : (N + 15) / 16;                 // K chunks of 16
+    s.nch = (N + 15) / 16 > 20 ? 20 : (N + 15) / 16;                 // K chunks of 16
     s.cw = s.nch == 1 ? 16 : s.nch == 2 ? 32 : 64;                   // columns a wave covers
-    s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : (CCVM_PERSIST_NCG3 && s.nch <= 12) ? 3 : 4;  // waves side by side
+    s.ncg = s.nch <= 4 ? 1 : s.nch <= 8 ? 2 : (CCVM_PERSIST_NCG3 && s.nch <= 12) ? 3 : s.nch <= 16 ? 4 : 5;  // waves side by side
     // 64 < N <= 96 (round 6): THREE 32-column waves side by side, two row groups (eight MFMA rows) each -- 96 columns instead
     // of 128 for the same rows, three waves where two pairs stood; whole chains, producers next to them.  Bit-identical to
     // the 64-column waves' whole chains.  Same-box sweep (profiles/r06_ab_persist_cw32.txt, tools/ab_persist_cw32.sh): mostly a
@@ -117,6 +131,8 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         const bool pays = 8 * r2 < 5 * r1 && kh_override != 1 && !(ru_override == 2 || ru_override == 4);
         if (rsw_override == 2 ? (s.kh == 2 || pays) : (rsw_override == 0 && pays)) { s.kh = 2; s.ru = 4; s.rsw = 2; }
     }
+    if (s.ncg == 5) { s.kh = 2; s.ru = 4; }  // five side by side: the K split only (ten waves, fragments partly in LDS)
+    const double wide_est = s.ncg == 5 ? persist_wide_us(solver, B, N, simds / 4) : 0.0;
     // Noise producer waves (ccvm_persist.h, PW).
     // One wave per row set (N <= 64): four variants -- two or four rows in use, with or without producers -- and which
     // one is fastest depends on how many ROUNDS of waves the fullest SIMD holds (a consumer next to its producer costs
@@ -124,7 +140,7 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
     // model fitted to the sweep of round 6 (ccvm_persist_model.h, generated by tools/fit_persist_model.py: within 3 %
     // of the best variant in all 144 cells, at most 2.7 % behind: profiles/r06_persist_policy.md); the overrides pin their dimension.
     s.pw = 0;
-    s.est_us = 0.0;
+    s.est_us = wide_est;
     if (s.ncg == 1) {
         const int k4 = (N + 3) / 4;
         double best = 1e30;
@@ -236,7 +252,19 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
         case 13: launch_persist_shape<MODE, ADAM, 64, 4, 13>(a, st); break;
         case 14: launch_persist_shape<MODE, ADAM, 64, 4, 14>(a, st); break;
         case 15: launch_persist_shape<MODE, ADAM, 64, 4, 15>(a, st); break;
-        default: launch_persist_shape<MODE, ADAM, 64, 4, 16>(a, st); break;
+        case 16: launch_persist_shape<MODE, ADAM, 64, 4, 16>(a, st); break;
+        default:
+            if constexpr (MODE == MODE_DL || (MODE == MODE_LANGEVIN && !ADAM)) {  // persist_wide_ok
+                const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : 2, ADAM, a.B, a.N, 0, 0, a.simds);
+                const dim3 grid(sh.grid), block(sh.threads);
+                switch ((a.N + 15) / 16) {
+                    case 17: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 17, 4, 2, 0, 0, 8 * 17 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
+                    case 18: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 18, 4, 2, 0, 0, 8 * 18 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
+                    case 19: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 19, 4, 2, 0, 0, 8 * 19 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
+                    default: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 20, 4, 2, 0, 0, 8 * 20 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
+                }
+            }
+            break;
     }
 }
 

@@ -36,6 +36,8 @@ namespace ccvm {
 //   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
 //   CCVM_AMD_PERSIST_RSW=1|2  row sets per workgroup of its six-wave row sets (128 < N <= 192 with the K split; default: by batch size)
 //   CCVM_AMD_PERSIST_CW=32|64 64 < N <= 96: three 32-column waves side by side (eight rows each) / two 64-column waves
+//   CCVM_AMD_PERSIST_WIDE=0   256 < N <= 320 stays on the column-cluster / slab / tile kernels (default: DL and Langevin without
+//                             Adam run the row-owner kernel's five-waves-side-by-side shape there)
 //   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 20 ms or 50
 //                             estimated steps; rehearsals that put several processes on ONE GPU raise it)
 constexpr int CLUSTER_DEFAULT = -1;  // -1: where it applies AND the whole grid is resident at once
@@ -51,6 +53,7 @@ struct Tuning {
     int persist_pw = 0;  // noise producer waves of the row-owner kernel: 1 off, 2 on, 0: by shape and batch size
     int persist_rsw = 0; // row sets per workgroup where a row set is six waves (128 < N <= 192, K split): 1 / 2, 0: by batch size
     int persist_cw = 0;  // 64 < N <= 96: 32 = three 32-column waves side by side (eight rows each), 64 = two 64-column waves, 0: by policy
+    int persist_wide = -1;  // 256 < N <= 320 on the row-owner kernel (five waves side by side, DL / Langevin without Adam): 0 never, else where it applies
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     double spin_ms = 0.0;  // CCVM_AMD_SPIN_MS: > 0 replaces the bound of the cross-workgroup waits
     int cluster_sets = 0;  // CCVM_AMD_CLUSTER_SETS=2|3 (tuning): that many row sets per cluster above K = 512; 0: cluster_sets()
@@ -86,7 +89,7 @@ void set_grid(StepArgs& a, const Tuning& tun, bool resident = false);
 void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun, int max_ks = 2, int mode = -1);
 
 // ---- the row-owner persistent kernel (N <= 256; its shape: ccvm_persist_launch.h, persist_shape) ----
-bool want_persist(int N, const Tuning& tun);
+bool want_persist(int N, const Tuning& tun, int solver, int B);
 
 // ---- the column-cluster persistent kernel ----
 int cluster_sets(int B, int N, const ChipGeometry& chip, int force = 0);

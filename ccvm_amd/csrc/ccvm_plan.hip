@@ -50,6 +50,7 @@ Tuning read_tuning() {
         if (e[0] == '0' || e[0] == '1') t.persist_pw = e[0] - '0' + 1;
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RSW"))
         if (e[0] == '1' || e[0] == '2') t.persist_rsw = e[0] - '0';
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_WIDE")) t.persist_wide = e[0] != '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_CW"))
         if (!std::strcmp(e, "32") || !std::strcmp(e, "64")) t.persist_cw = std::atoi(e);
     // CCVM_AMD_FAULT=cluster_drop: the cluster path launches without its last 8 workgroups, so the last member of
@@ -220,7 +221,19 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
 
 // The persistent row-owner kernel applies up to PERSIST_MAX_N columns (CCVM_AMD_KERNEL=tile forces
 // the per-step kernel; read once per ABI call so a test can flip it between calls).
-bool want_persist(int N, const Tuning& tun) { return N <= PERSIST_MAX_N && !tun.force_tile; }
+// (256 < N <= 320, round 6: five waves side by side for the solver variants whose working set leaves room -- persist_wide_ok --
+// where its rounds cost less than the plan that would run otherwise: the slab kernel keeps the smallest batches, the cluster
+// kernel a batch its 48-row clusters hold in one round where row sets need two (Langevin B = 1500: 3.35 against 4.5 us per
+// step); unless a kernel family is forced: CCVM_AMD_KERNEL=cluster / nocluster / slab / ptile keep what they meant before.
+// CCVM_AMD_PERSIST_WIDE=1: wherever it applies.)
+bool want_persist(int N, const Tuning& tun, int solver, int B) {
+    if (tun.force_tile) return false;
+    if (N <= PERSIST_MAX_N) return true;
+    if (N > PERSIST_WIDE_MAX_N || !persist_wide_ok(solver, tun.adam) || tun.persist_wide == 0 || tun.cluster != CLUSTER_DEFAULT ||
+        tun.slab == 1 || tun.ptile == 1)
+        return false;
+    return tun.persist_wide > 0 || persist_wide_us(solver, B, N, chip_of(tun).cus) < plan_us(solver, B, N, tun);
+}
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 768, every solver and Adam variant ---------
 // (CLUSTER_TWO_SETS, CLUSTER_TWO_SETS_SPREAD -- a step on two row sets relative to three, XCD by XCD / spread --, CLUSTER_ROUND_US,
@@ -427,6 +440,7 @@ double plan_us(int mode, int B, int N, const Tuning& tun) {
 int split_rows(int mode, int B, int N, const Tuning& tun) {
     if (!tun.split || tun.force_tile) return 0;
     if (tun.split < 0 && (tun.ptile > 0 || tun.ks || tun.slab > 0 || tun.cluster > 0)) return 0;  // a forced family: one plan per batch
+    if (want_persist(N, tun, mode, B)) return 0;  // (row owners never interact: nothing to cut)
     const ChipGeometry chip = chip_of(tun);
     int rows_fit;  // rows of one resident grid
     if (N > CL_MAX_N) {

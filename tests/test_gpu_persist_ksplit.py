@@ -100,6 +100,58 @@ def test_narrow_waves_are_bit_identical_to_wide_ones(monkeypatch):
             assert torch.equal(wide.compact(name), narrow.compact(name)), (kind, name)
 
 
+@pytest.mark.parametrize("kind,n,b,t", [
+    ("dl", 257, 33, 12), ("dl", 300, 1000, 6), ("dl", 320, 515, 6), ("dl", 289, 1, 12), ("dl", 272, 130, 10), ("dl", 305, 64, 10),
+    ("langevin", 300, 1000, 6), ("pl", 272, 130, 10), ("langevin", 320, 2000, 4), ("pl", 305, 7, 12), ("langevin", 257, 1, 12),
+    ("pl", 288, 1027, 6),
+])
+def test_five_waves_side_by_side_match_oracle(monkeypatch, kind, n, b, t):
+    """Round 6: 256 < N <= 320 on the row-owner kernel -- five waves side by side x two K halves, ten waves of 168 registers,
+    the last 32 ... 56 fragments of every wave's K half in LDS (ccvm_persist.h: QL) -- DL and Langevin / pumped Langevin
+    without Adam (the default there; the others stay on the column-cluster kernel)."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")  # (wherever it applies: the default leaves the smallest batches to the slab kernel)
+    d = _describe(kind, b, n)
+    assert re.search(r"persist_kernel<[02], false, 64, 5, (17|18|19|20), 4, 2, 0, 0, (32|40|48|56)> grid \d+ x 640 threads", d), d
+    _check_against_oracle(kind, n, b, t, None)
+
+
+@pytest.mark.parametrize("kind,n,b", [("dl", 300, 150), ("langevin", 320, 333), ("pl", 257, 90)])
+def test_chunking_and_sharding_are_exact_with_five_waves_side_by_side(monkeypatch, kind, n, b):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")
+    t = 24
+    whole = _run_engine(kind, n, b, t, None, 777, 0)
+    parts = _run_engine(kind, n, b, t, None, 777, 0, chunks=[1, 9, 3, 11])
+    for name in whole.state:
+        assert torch.equal(whole.compact(name), parts.compact(name)), name
+    cut = 37
+    lo = _run_engine(kind, n, cut, t, None, 777, 0)
+    hi = _run_engine(kind, n, b - cut, t, None, 777, cut)
+    for name in whole.state:
+        w = whole.compact(name)
+        assert torch.equal(w[:cut], lo.compact(name)) and torch.equal(w[cut:], hi.compact(name)), name
+
+
+def test_the_other_variants_stay_on_the_cluster_kernel_between_256_and_320_columns(monkeypatch):
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    assert "cluster_kernel" in _describe("mf", 1000, 300) and "cluster_kernel" in _describe("langevin", 1000, 300, adam=True)
+    assert "cluster_kernel" in _describe("dl", 1000, 321) and "persist_kernel" in _describe("dl", 1000, 320)
+    # by the estimates: the slab kernel keeps the smallest batches, the cluster kernel a batch its 48-row clusters hold in ONE
+    # round where row sets need two (Langevin, B = 1500: 3.35 us per step against 4.5)
+    assert "slab_kernel" in _describe("dl", 32, 300) and "persist_kernel" in _describe("dl", 128, 300)
+    assert "slab_kernel" in _describe("langevin", 128, 300) and "persist_kernel" in _describe("langevin", 256, 300)
+    assert "cluster_kernel" in _describe("langevin", 1500, 300) and "persist_kernel" in _describe("langevin", 2000, 300)
+    assert "estimated 4.30 us per step" in _describe("dl", 1000, 300) and "estimated 2.23 us per step" in _describe("langevin", 1000, 300)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "0")
+    assert "cluster_kernel" in _describe("dl", 1000, 300) and "slab_kernel" in _describe("dl", 32, 300)
+    monkeypatch.delenv("CCVM_AMD_PERSIST_WIDE")
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "cluster")
+    assert "cluster_kernel" in _describe("dl", 1000, 300)
+    monkeypatch.setenv("CCVM_AMD_KERNEL", "nocluster")
+    assert "step_kernel" in _describe("dl", 1000, 300)
+
+
 def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_PERSIST_KH", raising=False)
     monkeypatch.delenv("CCVM_AMD_PERSIST_RU", raising=False)

@@ -117,7 +117,7 @@ def test_batches_cut_in_two(hip_lib, clean_env):
 def test_other_geometries_never_take_the_cluster_kernel_unless_it_is_8_xcds(hip_lib, clean_env, geometry):
     clean_env.setenv("CCVM_AMD_GEOMETRY", geometry)
     cus, xcds = map(int, geometry.split(","))
-    for solver, b, n in ((1, 1000, 500), (2, 1000, 300), (0, 1000, 640), (2, 1000, 768)):
+    for solver, b, n in ((1, 1000, 500), (1, 1000, 300), (0, 1000, 640), (2, 1000, 768)):  # (DL / Langevin at N <= 320: row owners, on any chip)
         d = _describe(hip_lib, solver, b, n)
         if xcds != 8:
             assert "step_kernel" in d, (geometry, d)
@@ -176,7 +176,7 @@ def test_kernels_do_not_spill_and_the_k_split_thresholds_match_the_register_coun
     assert not bad, bad
     regs = {}
     for k in ks:
-        m = re.search(r"persist_kernel<(\d), (true|false), 64, [34], (\d+), 4, 1, 0, 0>", k["name"])
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, [34], (\d+), 4, 1, 0, 0, 0>", k["name"])
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
@@ -243,7 +243,7 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import kernel_resources
 
-    twelve = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<\d, \w+, 64, 3, \d+, 4, 2, 0, 2>", k["name"])]
+    twelve = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<\d, \w+, 64, 3, \d+, 4, 2, 0, 2, 0>", k["name"])]
     assert len(twelve) == 18 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] for k in twelve), twelve
 
 
@@ -326,7 +326,7 @@ def test_producer_waves_policy(hip_lib, clean_env):
 
     regs = {}
     for k in kernel_resources.kernels():
-        m = re.search(r"persist_kernel<(\d), (true|false), 64, 2, (\d+), 4, 2, 1, 0>", k["name"])
+        m = re.search(r"persist_kernel<(\d), (true|false), 64, 2, (\d+), 4, 2, 1, 0, 0>", k["name"])
         if m:
             regs[(int(m.group(1)), m.group(2) == "true", int(m.group(3)))] = k["vgpr"]
     assert len(regs) == 20
@@ -432,6 +432,9 @@ def test_default_policy_against_the_regret_audit(hip_lib, clean_env):
     for (kind, n, b), r in sorted(cells.items()):
         plans = [p for p in r["plans"] if p.get("us")]
         fam = family(_describe(hip_lib, solver_id[kind], b, n))
+        if fam == "R" and n > 256:
+            continue  # (round 6: DL / Langevin at 256 < N <= 320 run the row-owner kernel's five waves side by side, which this
+                      # audit predates -- measured against every other plan in profiles/r06_policy_regret.jsonl, the test below)
         mine = [p for p in plans if p["family"] == fam]
         if not mine:
             unmeasured.append((kind, n, b, fam))
@@ -469,8 +472,9 @@ def test_default_policy_against_the_regret_audit(hip_lib, clean_env):
 def test_default_policy_against_a_second_boxes_audit(hip_lib, clean_env):
     """Round 6 ("pins the policy to that data, not to a second box"): the same audit run again on the
     box of round 6's call 18 -- another machine of the pool, the final code of round 6 (producer waves, one launch per
-    cluster round, time-bounded waits) -- over 162 cells (N = 100 ... 2000, B = 32 ... 2000, the three solvers):
-    profiles/r06_policy_regret.{jsonl,md}.  The policy's constants were NOT refitted to it.  The plan picked for a cell must
+    cluster round, time-bounded waits) -- over 162 cells (N = 100 ... 2000, B = 32 ... 2000, the three solvers), and the
+    cells of N = 257 / 300 / 320 again on the box of call 33, when DL / Langevin there moved to the row-owner kernel's five
+    waves side by side (216 cells in all): profiles/r06_policy_regret.{jsonl,md}.  The policy's constants were NOT refitted to it.  The plan picked for a cell must
     be within 7 % of the best plan THAT box measured for the cell (the audit's own list beyond 5 %: one cell, Langevin
     N = 2000, B = 768 at 6 %)."""
     import json
@@ -485,7 +489,7 @@ def test_default_policy_against_a_second_boxes_audit(hip_lib, clean_env):
     solver_id = {"dl": 0, "mf": 1, "langevin": 2}
     with open(os.path.join(root, "profiles", "r06_policy_regret.jsonl")) as fh:
         cells = {(r["kind"], r["n"], r["b"]): r for r in map(json.loads, fh)}
-    assert len(cells) >= 160
+    assert len(cells) >= 216
     regrets, unmeasured = [], []
     for (kind, n, b), r in sorted(cells.items()):
         plans = [p for p in r["plans"] if p.get("us")]
