@@ -36,7 +36,7 @@ ROWS = [
     ("langevin_n1000_b1000", "one-stream solver at the headline's size", "8 N + 4 N²/B"),
     ("mf_n1000_b1000", "one-stream solver at the headline's size", "16 N + 4 N²/B"),
     ("dl_n500_b1000", "DL at config 3's size (not a BASELINE configuration)", "16 N + 4 N²/B"),
-    ("langevin_n300_b1000", "the low end of the cluster kernel's range (its half-chunk variant, K = 320)", "8 N + 4 N²/B"),
+    ("langevin_n300_b1000", "256 < N ≤ 320: the row-owner kernel's five waves side by side since round 6 (the cluster kernel's half-chunk variant before: 3.36 µs)", "8 N + 4 N²/B"),
     ("dl_n300_b1000", "the same, DL", "16 N + 4 N²/B"),
     ("langevin_n640_b512", "K = 640 at half the batch: clusters of 32 rows (two row sets)", "8 N + 4 N²/B"),
     ("dl_n640_b512", "the same, DL", "16 N + 4 N²/B"),

@@ -10,15 +10,20 @@ import torch
 import bench
 
 ADAM = {"alpha": 0.001, "beta1": 0.9, "beta2": 0.999, "add_assign": False}
-VARS = ("CCVM_AMD_PERSIST_CW", "CCVM_AMD_PERSIST_KH", "CCVM_AMD_PERSIST_RU", "CCVM_AMD_PERSIST_PW", "CCVM_AMD_PERSIST_RSW")
+VARS = ("CCVM_AMD_PERSIST_CW", "CCVM_AMD_PERSIST_KH", "CCVM_AMD_PERSIST_RU", "CCVM_AMD_PERSIST_PW", "CCVM_AMD_PERSIST_RSW",
+        "CCVM_AMD_PERSIST_WIDE", "SOAK_CHUNK")
 NARROW = ({"CCVM_AMD_PERSIST_CW": "64", "CCVM_AMD_PERSIST_KH": "1", "CCVM_AMD_PERSIST_PW": "0"}, {})   # old (whole chains), default
 NARROW_ADAM = NARROW
 TWO_SETS = ({"CCVM_AMD_PERSIST_KH": "2", "CCVM_AMD_PERSIST_RSW": "1"}, {})
 TWO_ROWS = ({"CCVM_AMD_PERSIST_KH": "1", "CCVM_AMD_PERSIST_RU": "4"}, {})
+# 256 < N <= 320: five waves side by side with part of Q in LDS -- nothing to be bit-identical with (the cluster kernel sums in
+# another order): the long run twice, whole and in odd chunks ("before" = one call per 7777 steps, "default" = per 1234)
+WIDE = ({"CCVM_AMD_PERSIST_WIDE": "1"}, {"CCVM_AMD_PERSIST_WIDE": "1", "SOAK_CHUNK": "1234"})
 CASES = (("dl", 70, 1000, 100000, None, NARROW), ("langevin", 96, 2000, 50000, None, NARROW), ("pl", 80, 1000, 100000, ADAM, NARROW_ADAM),
          ("mf", 65, 777, 100000, ADAM, NARROW_ADAM), ("dl", 144, 1000, 60000, None, TWO_SETS), ("dl", 192, 4000, 20000, None, TWO_SETS),
          ("mf", 176, 2000, 40000, None, TWO_SETS), ("langevin", 160, 2000, 40000, ADAM, TWO_SETS), ("dl", 144, 256, 100000, None, TWO_ROWS),
-         ("mf", 224, 512, 50000, ADAM, TWO_ROWS), ("langevin", 130, 500, 100000, None, TWO_ROWS))
+         ("mf", 224, 512, 50000, ADAM, TWO_ROWS), ("langevin", 130, 500, 100000, None, TWO_ROWS),
+         ("dl", 300, 1000, 40000, None, WIDE), ("langevin", 320, 2000, 30000, None, WIDE), ("pl", 257, 333, 60000, None, WIDE))
 for kind, n, b, t, adam, (old, new) in CASES:
     finals, shapes = [], []
     for env in (old, new):
@@ -31,7 +36,7 @@ for kind, n, b, t, adam, (old, new) in CASES:
         t0 = time.time()
         done = 0
         while done < t:
-            k = min(7777, t - done)   # odd chunking on purpose
+            k = min(int(os.environ.get("SOAK_CHUNK", "7777")), t - done)   # odd chunking on purpose
             traj.advance(k); done += k
         torch.cuda.synchronize()
         dt = time.time() - t0
