@@ -88,7 +88,7 @@ double best_tile_us(int mode, int B, int N, const Tuning& tun);
 void set_grid(StepArgs& a, const Tuning& tun, bool resident = false);
 void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld, const Tuning& tun, int max_ks = 2, int mode = -1);
 
-// ---- the row-owner persistent kernel (N <= 256; its shape: ccvm_persist_launch.h, persist_shape) ----
+// ---- the row-owner persistent kernel (N <= 256, DL / Langevin without Adam N <= 320; its shape: ccvm_persist_launch.h, persist_shape) ----
 bool want_persist(int N, const Tuning& tun, int solver, int B);
 
 // ---- the column-cluster persistent kernel ----
