@@ -64,7 +64,7 @@ typedef enum ccvm_noise_mode {
  * 2 % of a 20-step call).  Without the flag every call zeroes them itself. */
 #define CCVM_RUN_WS_PADDED 1
 /* CCVM_RUN_NO_EXCHANGE: run this call on kernels whose workgroups do not wait for each other (the per-step tile kernel,
- * or the row-owner persistent kernel for N <= 256 -- DL and Langevin without Adam: N <= 320 --), never on the column-cluster / column-slab / persistent-tile kernels.  What
+ * or the row-owner persistent kernel for N <= 256), never on the column-cluster / column-slab / persistent-tile kernels.  What
  * a caller sets to repeat a chunk whose status word reported a time-out (ccvm_status_offset): same noise, same
  * result up to the summation order of the contraction. */
 #define CCVM_RUN_NO_EXCHANGE 2
