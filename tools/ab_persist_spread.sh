@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B (developer tool, round 6): CCVM_AMD_PERSIST_SPREAD=1 -- LDS padding so that a CU takes no more row-owner
 # workgroups than the grid needs -- against the default placement, by shape and batch.
+# A RECORD, not a runnable tool: the padding (dynamic LDS of 160 KB / (workgroups per CU + 1) + 1 KB in the row-owner launch)
+# changed no cell by 3 % (profiles/r06_ab_persist_spread.txt) and was taken out of the library again; the variable no longer exists.
 #   usage: bash tools/ab_persist_spread.sh > gpurun_out/r06/ab_persist_spread.txt
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 CASES=""
