@@ -344,7 +344,7 @@ _problem_cache = []  # (weakref(q), weakref(v), q._version, v._version, device i
 #: (kind, batch, N, adam, per-variable S, tuning environment) -> does the plan wait across workgroups (Trajectories._exchange_kernel)
 _exchange_kernel_cache = {}
 _TUNING_VARS = ("CCVM_AMD_KERNEL", "CCVM_AMD_GEOMETRY", "CCVM_AMD_KS", "CCVM_AMD_SPLIT", "CCVM_AMD_SLAB_CGRP", "CCVM_AMD_SLAB_RG",
-                "CCVM_AMD_CLUSTER_SETS", "CCVM_AMD_CLUSTER_HALF", "CCVM_AMD_XCD", "CCVM_AMD_XCD_XC")
+                "CCVM_AMD_CLUSTER_SETS", "CCVM_AMD_CLUSTER_HALF", "CCVM_AMD_XCD", "CCVM_AMD_XCD_XC", "CCVM_AMD_PERSIST_WIDE")
 
 
 def _tuning_env():
