@@ -3,7 +3,7 @@
 # default policy picks at N = 65 / 96 / 129 / 144 / 200 and B = 257 / 1000)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=gpurun_out/r06; mkdir -p $O
 : > $O/fuzz_final.txt
-for seed in 606 1717 424242; do
+for seed in ${SEEDS:-606 1717 424242}; do
   CCVM_FUZZ_SEED=$seed CCVM_FUZZ_COUNT=500 timeout -k 10 330 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | sed "s/^/seed $seed: /" >> $O/fuzz_final.txt || { echo FUZZ_FAILED $seed; tail -3 $O/fuzz_final.txt; exit 1; }
 done
 cat $O/fuzz_final.txt
