@@ -247,6 +247,52 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     assert len(twelve) == 18 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] for k in twelve), twelve
 
 
+def test_row_owners_between_256_and_320_columns(hip_lib, clean_env):
+    """Round 6: DL and Langevin / pumped Langevin without Adam run the row-owner kernel up to N = 320 -- five waves side by
+    side x two K halves, ten waves of at most 168 registers, the last 8 NCH - 104 fragments of a wave's K half in LDS -- where
+    rounds x the measured round (ccvm_plan_model.h: PERSIST_WIDE_ROUND_US) is less than the plan that would run otherwise
+    (profiles/r06_ab_persist_wide.txt).  MF and the Adam variants do not fit (registers, then LDS) and keep the cluster kernel."""
+    import os
+    import sys
+
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    wide = lambda solver, b, n, adam=0: re.search(
+        r"persist_kernel<[02], false, 64, 5, (\d+), 4, 2, 0, 0, (\d+)> grid (\d+) x 640 threads .*estimated ([\d.]+) us per step",
+        _describe(hip_lib, solver, b, n, adam))
+    for n, nch, ql in ((257, 17, 32), (272, 17, 32), (288, 18, 40), (300, 19, 48), (304, 19, 48), (320, 20, 56)):
+        m = wide(0, 1000, n)
+        assert m and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (nch, ql, 500), (n, m and m.groups())
+        m = wide(2, 1000, n)
+        assert m and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (nch, ql, 250), (n, m and m.groups())
+        assert not wide(1, 1000, n) and not wide(2, 1000, n, 1) and not wide(1, 1000, n, 1)
+    assert not wide(0, 1000, 256) and not wide(0, 1000, 321)
+    # by estimate: rounds of one row set (two DL rows / four rows) per CU x the round -- against slab, cluster, tiles
+    assert float(wide(0, 512, 300).group(4)) == 2.15 and float(wide(0, 513, 300).group(4)) == 4.30 and float(wide(2, 1024, 320).group(4)) == 2.31
+    assert "slab_kernel" in _describe(hip_lib, 0, 32, 300) and wide(0, 128, 300)            # DL: the slab kernel up to a few dozen rows
+    assert "slab_kernel" in _describe(hip_lib, 2, 128, 300) and wide(2, 256, 300)          # Langevin: up to ~200
+    assert "cluster_kernel" in _describe(hip_lib, 2, 1500, 300) and wide(2, 2000, 300)     # 48-row clusters: 1536 rows in ONE round
+    # forced families keep what they meant; CCVM_AMD_PERSIST_WIDE pins the choice
+    for forced, family in (("cluster", "cluster_kernel"), ("nocluster", "step_kernel"), ("tile", "step_kernel"), ("slab", "slab_kernel")):
+        clean_env.setenv("CCVM_AMD_KERNEL", forced)
+        assert family in _describe(hip_lib, 0, 256 if forced == "slab" else 1000, 300), forced
+    clean_env.delenv("CCVM_AMD_KERNEL")
+    clean_env.setenv("CCVM_AMD_PERSIST_WIDE", "0")
+    assert "cluster_kernel" in _describe(hip_lib, 0, 1000, 300)
+    clean_env.setenv("CCVM_AMD_PERSIST_WIDE", "1")
+    assert wide(0, 1, 300) and wide(2, 1500, 300) and not wide(1, 1000, 300)
+    clean_env.delenv("CCVM_AMD_PERSIST_WIDE")
+    # a smaller chip: more rounds
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
+    assert float(wide(0, 512, 300).group(4)) == 4.30
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    # the ten-wave kernels: at most 168 registers, no spill, within the 160 KB of LDS
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    ten = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<[02], false, 64, 5, ", k["name"])]
+    assert len(ten) == 8 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] and k["lds"] <= 160 * 1024 for k in ten), ten
+
+
 def test_narrow_waves_between_64_and_96_columns(hip_lib, clean_env):
     """Round 6: 64 < N <= 96 can run THREE 32-column waves of eight rows side by side instead of two 64-column waves of four
     (ccvm_persist_launch.h: narrow).  Mostly a wash (profiles/r06_ab_persist_cw32.txt); taken where (1) the wide shape needs two
