@@ -616,8 +616,8 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
                                               tun.persist_pw, tun.persist_rsw, tun.persist_cw);
         if (sh.ncg == 5)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d> grid %d x %d threads (five waves side by side, %d of a wave's %d fragments in LDS), up to %d steps per launch",
-                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - PERSIST_WIDE_KR, sh.grid, sh.threads,
-                          8 * sh.nch - PERSIST_WIDE_KR, 8 * sh.nch, TABLE_STEPS);
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr(solver, ad), sh.grid, sh.threads,
+                          8 * sh.nch - persist_wide_kr(solver, ad), 8 * sh.nch, TABLE_STEPS);
         else if (sh.rsw == 2)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);

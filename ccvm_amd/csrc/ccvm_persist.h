@@ -1,4 +1,4 @@
-// Row-owner persistent kernel for small problems (N <= 256; DL and Langevin without Adam: N <= 320): a whole chunk of time steps in ONE
+// Row-owner persistent kernel for small problems (N <= 256; DL and Langevin without Adam: N <= 320, Langevin + Adam 288, MF 272): a whole chunk of time steps in ONE
 // launch, for every solver of the family (DL, MF, Langevin / pumped Langevin, Adam variants).
 //
 // At these sizes a per-step launch is latency-bound (N=100, B=1000: ~0.3 us of arithmetic per step

@@ -2,6 +2,7 @@
 // (8 + 8 shapes x 2 row fillings per solver variant) are spread over five translation units
 // (ccvm_persist_*.hip) so that they compile in parallel; each defines one persist_launch_* entry.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 
 #include "ccvm_persist.h"
@@ -12,17 +13,20 @@ namespace ccvm {
 
 constexpr int PERSIST_MAX_N = 256;
 // FIVE waves side by side x two K halves (round 6): 256 < N <= 320, part of every wave's fragments in LDS (ccvm_persist.h: QL).
-// Ten waves are three on some SIMD -- 168 registers -- and the working set next to the fragments must leave room for 104 of
-// them: DL and Langevin / pumped Langevin without Adam (MF spills 20 registers at that split, the Adam variants more; their
-// fragments beyond what LDS holds: those stay on the column-cluster kernel).
+// Ten waves are three on some SIMD -- 168 registers -- and what the working set leaves of them holds a wave's first KR
+// fragments, the other 8 NCH - KR live in LDS, 160 KB for all ten waves + the state: DL and Langevin / pumped Langevin
+// without Adam keep 104 in registers and reach N = 320 (56 in LDS); Langevin + Adam keeps 92 and reaches N = 288; MF 84 and
+// N = 272; MF + Adam (72) nothing.  Beyond that the column-cluster kernel stays (code objects' counts: tests/test_launch_policy.py).
 constexpr int PERSIST_WIDE_MAX_N = 320;
-constexpr int PERSIST_WIDE_KR = 104;  // fragments of a wave kept in registers; the other 8 NCH - 104 (32 ... 56) in LDS
-inline bool persist_wide_ok(int solver, bool adam) { return solver == 0 || (solver == 2 && !adam); }
+constexpr int persist_wide_kr(int solver, bool adam) { return solver == 1 ? (adam ? 0 : 84) : (solver == 2 && adam) ? 92 : 104; }
+constexpr int persist_wide_max_nch(int solver, bool adam) { return solver == 1 ? (adam ? 0 : 17) : (solver == 2 && adam) ? 18 : 20; }
+inline bool persist_wide_ok(int solver, bool adam, int N) { return N > PERSIST_MAX_N && (N + 15) / 16 <= persist_wide_max_nch(solver, adam); }
 // its estimate: rounds of one row set (two DL rows, four of a one-stream solver) per CU x the measured round
-inline double persist_wide_us(int solver, int B, int N, int cus) {
+inline double persist_wide_us(int solver, bool adam, int B, int N, int cus) {
     const int nch = (N + 15) / 16, rows = solver == 0 ? 2 : 4, sets = (B + rows - 1) / rows;
     const int k = nch < 17 ? 0 : nch > 20 ? 3 : nch - 17;
-    return (double)((sets + cus - 1) / cus) * PERSIST_WIDE_ROUND_US[solver == 0 ? 0 : 1][k];
+    const double round = solver == 1 ? PERSIST_WIDE_ROUND_MF_US : PERSIST_WIDE_ROUND_US[solver == 0 ? 0 : 1][k] * (adam ? PERSIST_WIDE_ADAM : 1.0);
+    return (double)((sets + cus - 1) / cus) * round;
 }
 
 void persist_launch_dl(const PersistArgs& a, hipStream_t st);
@@ -132,7 +136,7 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         if (rsw_override == 2 ? (s.kh == 2 || pays) : (rsw_override == 0 && pays)) { s.kh = 2; s.ru = 4; s.rsw = 2; }
     }
     if (s.ncg == 5) { s.kh = 2; s.ru = 4; }  // five side by side: the K split only (ten waves, fragments partly in LDS)
-    const double wide_est = s.ncg == 5 ? persist_wide_us(solver, B, N, simds / 4) : 0.0;
+    const double wide_est = s.ncg == 5 ? persist_wide_us(solver, adam, B, N, simds / 4) : 0.0;
     // Noise producer waves (ccvm_persist.h, PW).
     // One wave per row set (N <= 64): four variants -- two or four rows in use, with or without producers -- and which
     // one is fastest depends on how many ROUNDS of waves the fullest SIMD holds (a consumer next to its producer costs
@@ -254,15 +258,20 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
         case 15: launch_persist_shape<MODE, ADAM, 64, 4, 15>(a, st); break;
         case 16: launch_persist_shape<MODE, ADAM, 64, 4, 16>(a, st); break;
         default:
-            if constexpr (MODE == MODE_DL || (MODE == MODE_LANGEVIN && !ADAM)) {  // persist_wide_ok
-                const PersistShape sh = persist_shape(MODE == MODE_DL ? 0 : 2, ADAM, a.B, a.N, 0, 0, a.simds);
+            {  // five waves side by side (persist_wide_ok: the planner asks only for what is instantiated here)
+                constexpr int SOLVER = MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2;
+                constexpr int KR = persist_wide_kr(SOLVER, ADAM), MAXCH = persist_wide_max_nch(SOLVER, ADAM);
+                const PersistShape sh = persist_shape(SOLVER, ADAM, a.B, a.N, 0, 0, a.simds);
                 const dim3 grid(sh.grid), block(sh.threads);
-                switch ((a.N + 15) / 16) {
-                    case 17: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 17, 4, 2, 0, 0, 8 * 17 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
-                    case 18: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 18, 4, 2, 0, 0, 8 * 18 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
-                    case 19: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 19, 4, 2, 0, 0, 8 * 19 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
-                    default: hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 20, 4, 2, 0, 0, 8 * 20 - PERSIST_WIDE_KR>), grid, block, 0, st, a); break;
+                const int nch = (a.N + 15) / 16;
+                if (nch > MAXCH) {  // (want_persist never asks: a launch that would silently do nothing must not pass)
+                    std::fprintf(stderr, "ccvm: no row-owner kernel for N = %d of this solver variant\n", a.N);
+                    std::abort();
                 }
+                if constexpr (MAXCH >= 17) { if (nch == 17) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 17, 4, 2, 0, 0, 8 * 17 - KR>), grid, block, 0, st, a); }
+                if constexpr (MAXCH >= 18) { if (nch == 18) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 18, 4, 2, 0, 0, 8 * 18 - KR>), grid, block, 0, st, a); }
+                if constexpr (MAXCH >= 19) { if (nch == 19) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 19, 4, 2, 0, 0, 8 * 19 - KR>), grid, block, 0, st, a); }
+                if constexpr (MAXCH >= 20) { if (nch >= 20) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 20, 4, 2, 0, 0, 8 * 20 - KR>), grid, block, 0, st, a); }
             }
             break;
     }

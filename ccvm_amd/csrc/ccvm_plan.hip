@@ -229,10 +229,10 @@ void base_args(StepArgs& a, const float* Q, const float* V, int B, int N, int ld
 bool want_persist(int N, const Tuning& tun, int solver, int B) {
     if (tun.force_tile) return false;
     if (N <= PERSIST_MAX_N) return true;
-    if (N > PERSIST_WIDE_MAX_N || !persist_wide_ok(solver, tun.adam) || tun.persist_wide == 0 || tun.cluster != CLUSTER_DEFAULT ||
+    if (N > PERSIST_WIDE_MAX_N || !persist_wide_ok(solver, tun.adam, N) || tun.persist_wide == 0 || tun.cluster != CLUSTER_DEFAULT ||
         tun.slab == 1 || tun.ptile == 1)
         return false;
-    return tun.persist_wide > 0 || persist_wide_us(solver, B, N, chip_of(tun).cus) < plan_us(solver, B, N, tun);
+    return tun.persist_wide > 0 || persist_wide_us(solver, tun.adam, B, N, chip_of(tun).cus) < plan_us(solver, B, N, tun);
 }
 
 // ---- column-cluster persistent path (ccvm_cluster.h): 256 < N <= 768, every solver and Adam variant ---------

@@ -26,6 +26,8 @@ constexpr double CLUSTER_MARGIN = 0.98;  // (the audit: 0.95 kept six cells on t
 // the row-owner kernel's five waves side by side (256 < N <= 320): us per step of a round of one row set per CU, by K chunks
 // 17 ... 20 [DL, Langevin / pumped Langevin] (profiles/r06_ab_persist_wide.txt: flat in the batch up to a row set per CU)
 constexpr double PERSIST_WIDE_ROUND_US[2][4] = {{2.03, 2.05, 2.15, 2.24}, {2.10, 2.11, 2.23, 2.31}};
+// ... MF (17 chunks only: 2.28-2.30), and Langevin + Adam relative to Langevin (17 / 18 chunks: 2.50 / 2.55) -- profiles/r06_ab_persist_wide2.txt
+constexpr double PERSIST_WIDE_ROUND_MF_US = 2.30, PERSIST_WIDE_ADAM = 1.2;
 // a resident round of 32 x 128 tiles, us per step (fits of the regime map: DL 30.9 at N = 1000, 59 at N = 2000)
 constexpr double PTILE_DL_PER_N = 0.0281, PTILE_DL_0 = 2.8, PTILE_ONE_PER_N = 0.0145, PTILE_ONE_0 = 1.4, PTILE_MF_EXTRA = 0.4;
 }  // namespace ccvm

@@ -116,7 +116,22 @@ def test_five_waves_side_by_side_match_oracle(monkeypatch, kind, n, b, t):
     _check_against_oracle(kind, n, b, t, None)
 
 
-@pytest.mark.parametrize("kind,n,b", [("dl", 300, 150), ("langevin", 320, 333), ("pl", 257, 90)])
+@pytest.mark.parametrize("kind,n,b,t,adam", [
+    ("mf", 257, 33, 12, None), ("mf", 272, 1000, 6, None), ("mf", 265, 515, 8, None), ("mf", 260, 1, 12, None),
+    ("langevin", 257, 1000, 6, "second_moment"), ("pl", 288, 130, 10, "add_assign"), ("langevin", 280, 2000, 4, "first_moment_only"),
+    ("pl", 273, 7, 12, "second_moment"),
+])
+def test_five_waves_side_by_side_of_mf_and_langevin_with_adam_match_oracle(monkeypatch, kind, n, b, t, adam):
+    """... and where their larger working sets leave room: MF up to N = 272 (84 fragments of a wave in registers, 52 in LDS),
+    Langevin + Adam up to N = 288 (92 / 44 ... 52)."""
+    monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
+    monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")
+    d = _describe(kind, b, n, adam is not None)
+    assert re.search(r"persist_kernel<[12], \w+, 64, 5, (17|18), 4, 2, 0, 0, (44|52)> grid \d+ x 640 threads", d), d
+    _check_against_oracle(kind, n, b, t, adam)
+
+
+@pytest.mark.parametrize("kind,n,b", [("dl", 300, 150), ("langevin", 320, 333), ("pl", 257, 90), ("mf", 270, 120)])
 def test_chunking_and_sharding_are_exact_with_five_waves_side_by_side(monkeypatch, kind, n, b):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")
@@ -136,6 +151,8 @@ def test_chunking_and_sharding_are_exact_with_five_waves_side_by_side(monkeypatc
 def test_the_other_variants_stay_on_the_cluster_kernel_between_256_and_320_columns(monkeypatch):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     assert "cluster_kernel" in _describe("mf", 1000, 300) and "cluster_kernel" in _describe("langevin", 1000, 300, adam=True)
+    assert "cluster_kernel" in _describe("mf", 1000, 273) and "cluster_kernel" in _describe("langevin", 1000, 289, adam=True)
+    assert "cluster_kernel" in _describe("mf", 1000, 260, adam=True)
     assert "cluster_kernel" in _describe("dl", 1000, 321) and "persist_kernel" in _describe("dl", 1000, 320)
     # by the estimates: the slab kernel keeps the smallest batches, the cluster kernel a batch its 48-row clusters hold in ONE
     # round where row sets need two (Langevin, B = 1500: 3.35 us per step against 4.5)
