@@ -296,6 +296,35 @@ def test_row_owners_between_256_and_320_columns(hip_lib, clean_env):
     assert len(ten) == 11 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] and k["lds"] <= 160 * 1024 for k in ten), ten
 
 
+def test_every_row_owner_shape_the_policy_picks_is_in_the_library(hip_lib, clean_env):
+    """The description names the instantiation that runs (one persist_shape for launcher and description); every name the
+    policy can produce over N = 1 ... 320, the batches around its thresholds and all five solver variants must be a kernel of
+    the built library -- a shape picked but not instantiated would be a launch of something else."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    in_library = set()
+    for k in kernel_resources.kernels():
+        m = re.search(r"persist_kernel<([^>]*)>", k["name"])
+        if m:
+            in_library.add(tuple(x.strip() for x in m.group(1).split(",")))
+    assert len(in_library) > 300
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    picked = set()
+    for solver, adam in ((0, 0), (1, 0), (1, 1), (2, 0), (2, 1)):
+        for n in list(range(1, 130, 3)) + list(range(129, 321, 5)) + [64, 65, 96, 97, 128, 192, 193, 224, 225, 256, 257, 272, 273, 288, 289, 320]:
+            for b in (1, 33, 256, 257, 512, 513, 1000, 1024, 1025, 1500, 2048, 2049, 4000):
+                m = re.search(r"persist_kernel<([^>]*)>", _describe(hip_lib, solver, b, n, adam))
+                if m:
+                    args = [x.strip() for x in m.group(1).split(",")]
+                    args += ["1", "0", "0", "0"][len(args) - 6:]  # the defaults: KH = 1, PW = 0, RSWO = 0, QL = 0
+                    picked.add(tuple(args))
+    assert len(picked) > 150 and picked <= in_library, sorted(picked - in_library)[:5]
+
+
 def test_narrow_waves_between_64_and_96_columns(hip_lib, clean_env):
     """Round 6: 64 < N <= 96 can run THREE 32-column waves of eight rows side by side instead of two 64-column waves of four
     (ccvm_persist_launch.h: narrow).  Mostly a wash (profiles/r06_ab_persist_cw32.txt); taken where (1) the wide shape needs two
