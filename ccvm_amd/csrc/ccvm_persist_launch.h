@@ -40,7 +40,8 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 struct PersistShape {
     int cw, ncg, nch, ru, grid, kh, pw, threads;
     int rsw;        // 2: two six-wave row sets per workgroup (three side by side x two K halves), else 0
-    double est_us;  // the variant model's estimate (one wave per row set, N <= 64: ccvm_persist_model.h), else 0
+    double est_us;  // the variant model's estimate (one wave per row set, N <= 64: ccvm_persist_model.h); five side by side: rounds x
+                    // the measured round (ccvm_plan_model.h); else 0
 };
 constexpr int PERSIST_PW_MAX_NCG = 2;  // noise producer waves are instantiated for one and two waves side by side
 // kh_override: 1 / 2 forces the K split off / on (where the shape has one), 0 = by batch size
