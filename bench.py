@@ -80,6 +80,10 @@ WORKLOADS = {
     "langevin_n20_b1000": ("langevin", 20, 1000),
     "pl_n20_b1000": ("pl", 20, 1000),
     "dl_n70_b1000": ("dl", 70, 1000),
+    # between the shipped sizes and the cluster kernel's range (round 6): the row-owner kernel's twelve-wave workgroups
+    # (three waves side by side x two K halves x two row sets) and, with the N = 300 workloads above, its five waves side by side
+    "dl_n160_b1000": ("dl", 160, 1000),
+    "mf_n257_b1000": ("mf", 257, 1000),
 }
 #: workloads on a shipped instance (arrays: tests/golden/<instance>.npz, made from the reference's .in files) and / or
 #: inside the schedule of a longer run than the timed steps (`total`: the iterations of the run the steps belong to)

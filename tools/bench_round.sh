@@ -10,7 +10,7 @@ cd $R
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_like.json 2>> $O/${TAG}_bench.err || exit 1
 python3 bench.py --workload pl_n2000_b512 --post adam > $O/${TAG}_bench_pl_adam.json 2>> $O/${TAG}_bench.err || exit 1
-for w in dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 pl_n20_b1000 dl_n70_b1000 dl_n100_b1000 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 langevin_n300_b1000 dl_n300_b1000 langevin_n640_b512 dl_n640_b512 dl_n1000_b256 langevin_n1000_b256 langevin_n1000_b1000 mf_n1000_b1000 dl_n1000_b2000 dl_n1000_b4000 pl_n2000_b1024; do
+for w in dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 pl_n20_b1000 dl_n70_b1000 dl_n160_b1000 mf_n257_b1000 dl_n100_b1000 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 langevin_n300_b1000 dl_n300_b1000 langevin_n640_b512 dl_n640_b512 dl_n1000_b256 langevin_n1000_b256 langevin_n1000_b1000 mf_n1000_b1000 dl_n1000_b2000 dl_n1000_b4000 pl_n2000_b1024; do
   python3 bench.py --workload $w > $O/${TAG}_bench_$w.json 2>> $O/${TAG}_bench.err || exit 1
 done
 # small batches (column-slab kernel): 8192 steps = two launches

@@ -2,7 +2,7 @@
 # Copy the summaries of tools/profile_round.sh (+ the bench lines of tools/bench_round.sh in gpurun_out/) into profiles/
 # (developer tool).    usage: tools/collect_profiles.sh r06
 TAG=${1:-r06}; P=gpurun_out/prof
-STATS="dl_n300_b1000 langevin_n300_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000"
+STATS="dl_n160_b1000 mf_n257_b1000 dl_n300_b1000 langevin_n300_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n1000_b1 dl_n1000_b8 dl_n1000_b32 langevin_n1000_b32 mf_n500_b32 pl_n2000_b32 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000"
 for w in $STATS; do [ -f $P/${w}_stats/s_kernel_stats.csv ] && cp $P/${w}_stats/s_kernel_stats.csv profiles/${TAG}_${w}_kernel_stats.csv; done
 cp $P/dl_n1000_b1000_stats/s_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 CMD='rocprofv3 --pmc <counter set> --kernel-trace --output-format csv -- python3 bench.py --workload W --steps 40 --warmup 5 [persistent kernels: --steps 1000 --warmup 200] --repeats 1 --spinup-ms 0 --no-cpu-baseline (one pass per counter set: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*; tools/profile_round.sh)'
@@ -18,6 +18,8 @@ pmc langevin_n500_b1000 langevin_n500_b1000 'cluster_kernel<2' 600 "ccvm::cluste
 pmc mf_n500_b1000 mf_n500_b1000 'cluster_kernel<1' 600 "ccvm::cluster_kernel<1, false, 4, false> = MF, N=500, B=1000 $PERS"
 pmc dl_n100_b1000 dl_n100_b1000 'persist_kernel<0, false, 64, 2, 7, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2, 1> = DL, N=100, B=1000: K split + noise producer waves $PERS"
 pmc dl_n70_b1000 dl_n70_b1000 'persist_kernel<0, false, 32, 3, 5, 4, 1, 1' 600 "ccvm::persist_kernel<0, false, 32, 3, 5, 4, 1, 1> = DL, N=70, B=1000: three 32-column waves of eight rows + noise producer waves $PERS"
+pmc dl_n160_b1000 dl_n160_b1000 'persist_kernel<0, false, 64, 3, 10, 4, 2, 0, 2' 600 "ccvm::persist_kernel<0, false, 64, 3, 10, 4, 2, 0, 2, 0> = DL, N=160, B=1000: three waves side by side x two K halves, two row sets per twelve-wave workgroup $PERS"
+pmc mf_n257_b1000 mf_n257_b1000 'persist_kernel<1, false, 64, 5, 17' 600 "ccvm::persist_kernel<1, false, 64, 5, 17, 4, 2, 0, 0, 52> = MF, N=257, B=1000: five waves side by side, 52 of a wave's 136 Q fragments in LDS $PERS"
 pmc dl_n300_b1000 dl_n300_b1000 'persist_kernel<0, false, 64, 5, 19' 600 "ccvm::persist_kernel<0, false, 64, 5, 19, 4, 2, 0, 0, 48> = DL, N=300, B=1000: five waves side by side x two K halves, 48 of a wave's 152 Q fragments in LDS $PERS"
 pmc langevin_n300_b1000 langevin_n300_b1000 'persist_kernel<2, false, 64, 5, 19' 600 "ccvm::persist_kernel<2, false, 64, 5, 19, 4, 2, 0, 0, 48> = Langevin, N=300, B=1000: the same $PERS"
 pmc dl_n20_b1000 dl_n20_b1000 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (tuningH020-100-0), B=1000: one wave per row set + noise producer waves $PERS"

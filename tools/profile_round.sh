@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
 if [ "${PART:-stats}" = stats ]; then
-for w in dl_n1000_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000 dl_n300_b1000 langevin_n300_b1000; do
+for w in dl_n1000_b1000 pl_n2000_b512 mf_n500_b1000 langevin_n500_b1000 dl_n500_b1000 dl_n100_b1000 dl_n1000_b256 langevin_n1000_b256 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000 dl_n300_b1000 langevin_n300_b1000 dl_n160_b1000 mf_n257_b1000; do
   rocprofv3 --kernel-trace --stats -d $OUT/${w}_stats -o s --output-format csv -- python3 bench.py --workload $w --steps 3000 --warmup 500 --no-cpu-baseline > $OUT/${w}_stats.json 2> $OUT/${w}_stats.err || exit 1
   echo "stats $w done"
 done
@@ -24,7 +24,7 @@ fi
 pmc() {  # name, workload, counters...   (one launch per step: 45 dispatches; persistent kernels: 200 + 1000 steps in two)
   local name=$1 w=$2; shift 2
   local steps="--steps 40 --warmup 5"
-  case $w in *_n500_*|*_n300_*|*_n100_*|*_n20_*|*_n70_*|*_b32|*_b8|*_b1|dl_n1000_b1000|pl_n2000_b512) steps="--steps 1000 --warmup 200";; esac  # persistent kernels
+  case $w in *_n500_*|*_n300_*|*_n160_*|*_n257_*|*_n100_*|*_n20_*|*_n70_*|*_b32|*_b8|*_b1|dl_n1000_b1000|pl_n2000_b512) steps="--steps 1000 --warmup 200";; esac  # persistent kernels
   rocprofv3 --pmc "$@" --kernel-trace -d $OUT/${w}_pmc_$name -o pmc --output-format csv -- python3 bench.py --workload $w $steps --repeats 1 --spinup-ms 0 --no-cpu-baseline > $OUT/${w}_pmc_$name.log 2>&1 || exit 1
   echo "pmc $w $name done"
 }
@@ -36,7 +36,7 @@ if [ "${PART}" = classes ]; then
   done
   echo ALL_DONE; exit 0
 fi
-for w in dl_n1000_b1000 pl_n2000_b512 langevin_n500_b1000 mf_n500_b1000 dl_n100_b1000 dl_n1000_b32 dl_n1000_b256 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000 dl_n300_b1000 langevin_n300_b1000; do
+for w in dl_n1000_b1000 pl_n2000_b512 langevin_n500_b1000 mf_n500_b1000 dl_n100_b1000 dl_n1000_b32 dl_n1000_b256 dl_n20_b100 dl_n20_b1000 mf_n20_b1000 langevin_n20_b1000 dl_n70_b1000 dl_n300_b1000 langevin_n300_b1000 dl_n160_b1000 mf_n257_b1000; do
   pmc fetch $w FETCH_SIZE
   pmc write $w WRITE_SIZE
   pmc sq1 $w SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
