@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <map>
+#include <string>
 #include <vector>
 
 __global__ void probe(unsigned* out, int spin) {
@@ -23,7 +24,7 @@ __global__ void probe(unsigned* out, int spin) {
 }
 
 int main() {
-    const int sizes[] = {192, 256, 384, 512, 768};
+    const int sizes[] = {192, 256, 384, 512, 640, 768};
     const int grids[] = {128, 256, 500};
     for (int threads : sizes) {
         for (int grid : grids) {
@@ -65,6 +66,25 @@ int main() {
             for (auto& kv : fullest_hist) std::printf(" %d waves on %d CUs,", kv.first, kv.second);
             std::printf("\n    SIMD of wave w (count over the workgroups, SIMD 0..3):");
             for (int w = 0; w < waves; ++w) std::printf("  w%d: %d/%d/%d/%d", w, hist[w][0], hist[w][1], hist[w][2], hist[w][3]);
+            std::printf("\n");
+            // which waves of a workgroup share a SIMD: the pattern (wave indices per SIMD, SIMDs in the order of their first wave)
+            std::map<std::string, int> patterns;
+            for (int b = 0; b < grid; ++b) {
+                std::vector<std::string> per(4);
+                std::vector<int> first(4, 99);
+                for (int w = 0; w < waves; ++w) {
+                    const int simd = (h[(b * waves + w) * 2] >> 4) & 3;
+                    per[simd] += (per[simd].empty() ? "" : "+") + std::to_string(w);
+                    if (first[simd] == 99) first[simd] = w;
+                }
+                std::string key;
+                for (int f = 0; f < waves; ++f)
+                    for (int sd = 0; sd < 4; ++sd)
+                        if (first[sd] == f) key += "{" + per[sd] + "} ";
+                patterns[key]++;
+            }
+            std::printf("    waves sharing a SIMD:");
+            for (auto& kv : patterns) std::printf("  %s x %d;", kv.first.c_str(), kv.second);
             std::printf("\n");
         }
     }
