@@ -615,9 +615,16 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
         const PersistShape sh = persist_shape(solver, ad, B, N, tun.persist_ru, tun.persist_kh, 4 * chip_of(tun).cus,
                                               tun.persist_pw, tun.persist_rsw, tun.persist_cw);
         if (sh.ncg == 5)
-            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d> grid %d x %d threads (five waves side by side, %d of a wave's %d fragments in LDS), up to %d steps per launch",
-                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr(solver, ad), sh.grid, sh.threads,
-                          8 * sh.nch - persist_wide_kr(solver, ad), 8 * sh.nch, TABLE_STEPS);
+            if (tun.persist_xs == 1 || persist_wide_xs(solver, ad, sh.nch) == 0)
+                std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d> grid %d x %d threads (five waves side by side, %d of a wave's %d fragments in LDS), up to %d steps per launch",
+                              solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr(solver, ad), sh.grid, sh.threads,
+                              8 * sh.nch - persist_wide_kr(solver, ad), 8 * sh.nch, TABLE_STEPS);
+            else
+                std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d, %d> grid %d x %d threads (five waves side by side, K split %d | %d, the long parts' last %d fragments in LDS), up to %d steps per launch",
+                              solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr(solver, ad),
+                              persist_wide_xs(solver, ad, sh.nch), sh.grid, sh.threads, persist_wide_xs(solver, ad, sh.nch),
+                              16 * sh.nch - persist_wide_xs(solver, ad, sh.nch),
+                              16 * sh.nch - persist_wide_xs(solver, ad, sh.nch) - persist_wide_kr(solver, ad), TABLE_STEPS);
         else if (sh.rsw == 2)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);
@@ -750,6 +757,7 @@ int ccvm_dl_run(const float* Q, const float* V, float* c, float* s, int B, int N
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
         pa.cw_override = tun.persist_cw;
+        pa.xs_override = tun.persist_xs;
         pa.simds = 4 * chip_of(tun).cus;
         for (int done = 0; done < nsteps; done += TABLE_STEPS) {
             const int k = std::min(TABLE_STEPS, nsteps - done);
@@ -1038,6 +1046,7 @@ int ccvm_mf_run(const float* Q, const float* V, float* mu, float* sigma, float* 
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
         pa.cw_override = tun.persist_cw;
+        pa.xs_override = tun.persist_xs;
         pa.simds = 4 * chip_of(tun).cus;
         pa.s_cols = s_cols;
         AdamSched asc;
@@ -1364,6 +1373,7 @@ int ccvm_langevin_run(const float* Q, const float* V, float* c, int B, int N, in
         pa.pw_override = tun.persist_pw;
         pa.rsw_override = tun.persist_rsw;
         pa.cw_override = tun.persist_cw;
+        pa.xs_override = tun.persist_xs;
         pa.simds = 4 * chip_of(tun).cus;
         AdamSched asc;
         persist_adam(pa, asc, adam, use_adam);

@@ -74,6 +74,7 @@ struct PersistArgs {
     int pw_override;     // host only: 1 / 2 forces the noise producer waves off / on (tuning), 0 = by shape and batch size
     int rsw_override;    // host only: 1 / 2 forces the row sets per six-wave workgroup (tuning), 0 = by batch size
     int cw_override;     // host only: 32 / 64 forces three 32-column / two 64-column waves side by side at 64 < N <= 96 (tuning)
+    int xs_override;     // host only: 1 / 2 forces equal halves / the unequal K split of the five-waves-side-by-side shape (tuning), 0 = default
     AdamConsts ad;
     unsigned long long* dbg;  // tools/persist_ablate.hip, CCVM_PERSIST_ABL & 16: s_memtime sums, [grid][16]
 };
@@ -175,8 +176,16 @@ constexpr int persist_block_threads(int ncg, int kh, int pw, int rswo) {
 // -- ten waves are three on some SIMD, 168 registers each, and 160 fragments + the working set do not fit; the fragments of a
 // wave's own column, [k / 4][lane][k % 4], read back four at a time (one ds_read_b128 per four MFMAs, conflict-free) a few
 // groups ahead of their MFMAs.
-template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0, int QL = 0>
+// XS > 0 (five waves side by side only): UNEQUAL K split.  The ten waves of a workgroup land {0, 4, 8} {1, 5, 9} {2, 6} {3, 7} on
+// the four SIMDs, in every workgroup (HW_ID of every wave: tools/simd_probe.hip, profiles/r06_simd_probe.txt), and a step
+// costs what the fullest SIMD issues: with equal halves two SIMDs issue three half chains and two SIMDs two.  So the waves
+// that triple up take LESS of K: column groups 0 ... 3 are split [0, XS) | [XS, K) with the short part on waves 0, 1, 4, 5 and
+// the long one on waves 2, 3, 6, 7 (alone in pairs on their SIMDs), column group 4 in equal halves on waves 8, 9 -- every
+// SIMD then issues (2 XS + K / 2) = 2 (K - XS) k-steps + its waves' updates.  The short parts live in registers entirely, the
+// long ones keep KR = K / 2 - QL in registers like the equal halves and K - XS - KR in LDS.
+template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0, int QL = 0, int XS = 0>
 __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void persist_kernel(const PersistArgs a) {
+    static_assert(XS == 0 || (NCG == 5 && KH == 2 && QL > 0 && XS % 4 == 0 && XS <= 8 * NCH - QL), "unequal K split: five side by side, the short part in registers");
     static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 5 && RU == 4), "K split: waves side by side, all four rows in use");
     static_assert(QL == 0 || (KH == 2 && QL % 4 == 0 && PW == 0 && RSWO == 0), "fragments in LDS: K split only, whole groups of four");
     static_assert(PW == 0 || (PW == 1 && NCG * KH <= 4), "producer waves: at most eight waves per workgroup");
@@ -220,7 +229,8 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     // dt, S, has_next (unused here), + the unused words 14, 15; Langevin: all but the pump term
     constexpr unsigned ROW_SAME = (MODE == MODE_DL) ? 0x030u : (MODE == MODE_MF) ? 0xCD8Eu : 0xC0FBu;
     constexpr int PXA = (RSWO ? RSW : 1) * PXF;                // (without RSWO a K-split workgroup is one row set)
-    constexpr int QTF = QL * 64 * NWC;                         // fragments kept in LDS: [consumer wave][k / 4][lane][k % 4]
+    constexpr int QLH = XS ? 16 * NCH - XS - (8 * NCH - QL) : 0; // unequal split: the long parts' fragments in LDS (K - XS - KR)
+    constexpr int QTF = XS ? (4 * QLH + 2 * QL) * 64 : QL * 64 * NWC;  // fragments kept in LDS: [consumer wave][k / 4][lane][k % 4]
     __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXA + NZF + RING + QTF];
     float* const nzl = xs_all + RSW * 2 * ROWS * LDX + PXA;
     float* const ring = nzl + NZF;
@@ -236,8 +246,10 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     const bool producer = PW && ((wave_all >= NWC) != swap_roles);  // (wave-uniform)
     const int wave = (PW && wave_all >= NWC) ? wave_all - NWC : wave_all;  // a producer has its consumer's index and element map
     const int set = wave / (NCG * KH), wis = wave % (NCG * KH);  // row set of the workgroup, wave inside the row set
-    const int cg = wis % NCG;
-    const int kh = (KH == 2) ? wis / NCG : 0;  // K half (wave-uniform)
+    // (unequal split: waves 0 1 4 5 = the short parts of column groups 0 1 2 3, waves 2 3 6 7 their long parts, 8 9 = the halves of 4)
+    const int cg = XS ? (wis < 8 ? ((wis >> 2) * 2 + (wis & 1)) : 4) : wis % NCG;
+    const int kh = XS ? (wis < 8 ? ((wis >> 1) & 1) : (wis & 1)) : (KH == 2) ? wis / NCG : 0;  // K half (wave-uniform)
+    const int role = XS ? (wis < 8 ? kh : 2 + kh) : kh;  // unequal split: 0 short, 1 long, 2 / 3 the equal halves
     float* const xs = xs_all + set * (2 * ROWS * LDX);
     float* const px = xs_all + RSW * 2 * ROWS * LDX + (RSWO ? set : 0) * PXF;
     const int rs = lane / CW;            // row group
@@ -251,23 +263,29 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     // (K split: half kh holds the fragments of k = KSPLIT kh ... KSPLIT kh + KSPLIT - 1, those below KMAX)
     constexpr int KSPLIT = (KH == 2) ? (KMAX / 2 + 3) / 4 * 4 : KMAX;  // k-steps per half, a multiple of 4
     constexpr int KQ = (KH == 2) ? KSPLIT : KMAX;
-    const int koff = kh * KSPLIT;
+    const int koff = XS ? (role == 0 ? 0 : role == 1 ? XS : (role - 2) * KSPLIT) : kh * KSPLIT;
     constexpr int KR = KQ - QL;  // fragments in registers: the first KR k-steps of the wave's range
     static_assert(KR >= 4, "fragments in LDS: some stay in registers");
+    const int nreg = (XS && role == 0) ? XS : KR;                   // (the short parts: all of them)
+    const int nlds = XS ? (role == 0 ? 0 : role == 1 ? QLH : QL) : QL;  // this wave's fragments in LDS
     float qf[KR];
 #pragma unroll
     for (int k = 0; k < KR; ++k) qf[k] = 0.0f;
     if (!producer) {
 #pragma unroll
-        for (int k = 0; k < KR; ++k) qf[k] = (koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+        for (int k = 0; k < KR; ++k) qf[k] = (k < nreg && koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
     }
-    float* const qt = qtail + wave * (QL * 64) + lane * 4;  // this lane's fragments of group g: qt[g * 256 .. + 3]
+    // this lane's fragments of group g: qt[g * 256 .. + 3] (unequal split: the four long parts first, then column group 4's halves)
+    float* const qt = qtail + (XS ? (role == 1 ? ((wis >> 2) * 2 + (wis & 1)) * (QLH * 64) : 4 * (QLH * 64) + (wis & 1) * (QL * 64))
+                                  : wave * (QL * 64)) + lane * 4;
     if constexpr (QL > 0) {
-#pragma unroll
-        for (int g = 0; g < QL / 4; ++g) {
+        constexpr int GMAX = (XS ? (QLH > QL ? QLH : QL) : QL) / 4;
+#pragma unroll 1
+        for (int g = 0; g < GMAX; ++g) {
+            if (4 * g >= nlds) break;
             f32x4v q;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = (koff + KR + 4 * g + j < KMAX) ? a.Q[(size_t)(koff + KR + 4 * g + j) * ld + col] : 0.0f;
+            for (int j = 0; j < 4; ++j) q[j] = (koff + nreg + 4 * g + j < KMAX) ? a.Q[(size_t)(koff + nreg + 4 * g + j) * ld + col] : 0.0f;
             *reinterpret_cast<f32x4v*>(qt + g * 256) = q;  // (read back by this lane only: no barrier)
         }
     }
@@ -462,8 +480,13 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     // H: this wave's K half, a compile-time constant inside (the MFMA's block select is an immediate): the wave-uniform
     // branch is taken once, in front of the whole loop
     auto run_steps = [&](auto h_tag) {
-    constexpr int H = decltype(h_tag)::value;
-    constexpr int K0 = H * KSPLIT, K1 = (K0 + KSPLIT < KMAX) ? K0 + KSPLIT : KMAX;  // this wave's k-steps [K0, K1)
+    constexpr int ROLE = decltype(h_tag)::value;  // (unequal split: 0 short, 1 long, 2 / 3 the equal halves; else the K half)
+    constexpr int H = ROLE & 1;
+    // this wave's k-steps [K0, K1), of which the first KRR have their fragments in registers
+    constexpr int K0 = XS ? (ROLE == 0 ? 0 : ROLE == 1 ? XS : H * KSPLIT) : H * KSPLIT;
+    constexpr int K1 = XS ? (ROLE == 0 ? XS : ROLE == 1 ? KMAX : (H * KSPLIT + KSPLIT < KMAX ? H * KSPLIT + KSPLIT : KMAX))
+                          : (K0 + KSPLIT < KMAX) ? K0 + KSPLIT : KMAX;
+    constexpr int KRR = (XS && ROLE == 0) ? XS : KR;
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
         const Row rcur = rnext;  // (producer waves: unused -- the row comes out of the ring below)
@@ -534,15 +557,16 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
                 if (rem > 8) mfma_chain_at<CBSZ, KC, FULL + 8>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 12) mfma_chain_at<CBSZ, KC, FULL + 12>(af, qf, acc, std::make_integer_sequence<int, 4>{});
             } else if constexpr (KH == 2 && QL > 0) {
-                static_assert(K1 - K0 == KQ, "fragments in LDS: equal halves");
-                constexpr int G = QL / 4, AHEAD = CCVM_PERSIST_QL_AHEAD;  // groups of four k-steps out of LDS, read AHEAD groups ahead of their MFMAs
+                static_assert(XS || K1 - K0 == KQ, "fragments in LDS: equal halves");
+                static_assert((K1 - K0 - KRR) % 4 == 0 && K1 - K0 >= KRR, "fragments in LDS: whole groups of four");
+                constexpr int G = (K1 - K0 - KRR) / 4, AHEAD = CCVM_PERSIST_QL_AHEAD;  // groups of four k-steps out of LDS, read AHEAD groups ahead of their MFMAs
                 f32x4v qb[AHEAD];
 #pragma unroll
                 for (int g = 0; g < AHEAD && g < G; ++g) qb[g] = *reinterpret_cast<const f32x4v*>(qt + g * 256);
-                mfma_chain_half<CBSZ, KC, K0>(af, qf, acc, std::make_integer_sequence<int, KR>{});  // (covers the first reads)
+                mfma_chain_half<CBSZ, KC, K0>(af, qf, acc, std::make_integer_sequence<int, KRR>{});  // (covers the first reads)
                 unroll_indices([&](auto g_tag) {
                     constexpr int g = decltype(g_tag)::value;
-                    mfma_group4<CBSZ, KC, K0, KR + 4 * g>(af, qb[g % AHEAD], acc, std::make_integer_sequence<int, 4>{});
+                    mfma_group4<CBSZ, KC, K0, KRR + 4 * g>(af, qb[g % AHEAD], acc, std::make_integer_sequence<int, 4>{});
                     if constexpr (g + AHEAD < G) {
                         qb[g % AHEAD] = *reinterpret_cast<const f32x4v*>(qt + (g + AHEAD) * 256);
                         __builtin_amdgcn_sched_barrier(0);  // (keeps the reads where they are: hoisted, they would all be live at once)
@@ -678,7 +702,12 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     }
     };  // run_steps
     if constexpr (CCVM_PERSIST_ABL & 16) st_last = persist_stamp();
-    if constexpr (KH == 2) {
+    if constexpr (XS > 0) {
+        if (role == 0) run_steps(std::integral_constant<int, 0>{});
+        else if (role == 1) run_steps(std::integral_constant<int, 1>{});
+        else if (role == 2) run_steps(std::integral_constant<int, 2>{});
+        else run_steps(std::integral_constant<int, 3>{});
+    } else if constexpr (KH == 2) {
         if (kh == 0) run_steps(std::integral_constant<int, 0>{});
         else run_steps(std::integral_constant<int, 1>{});
     } else {

@@ -20,6 +20,18 @@ constexpr int PERSIST_MAX_N = 256;
 constexpr int PERSIST_WIDE_MAX_N = 320;
 constexpr int persist_wide_kr(int solver, bool adam) { return solver == 1 ? (adam ? 0 : 84) : (solver == 2 && adam) ? 92 : 104; }
 constexpr int persist_wide_max_nch(int solver, bool adam) { return solver == 1 ? (adam ? 0 : 17) : (solver == 2 && adam) ? 18 : 20; }
+// the unequal K split's short part (ccvm_persist.h: XS): (12 K - V) / 32 k-steps balance the SIMDs' issue (V: a wave's update,
+// ~350 cycles), a multiple of four, and all of them in registers (<= 104) -- then swept +-4 / 8 around that on the chip
+// (profiles/r06_ab_persist_xs_delta.txt): 96 at 17 K chunks, the cap from 18 on
+// (DL and Langevin without Adam; MF and Langevin + Adam, whose short parts would be capped at their 84 / 92 registers, spill
+// 2-4 registers in that form and keep equal halves: 0)
+#ifndef CCVM_PERSIST_XS_DELTA
+#define CCVM_PERSIST_XS_DELTA 0   // (tuning builds: the short part longer / shorter by this many k-steps)
+#endif
+constexpr int persist_wide_xs(int solver, bool adam, int nch) {
+    const int x = (nch == 17 ? 96 : 104) + CCVM_PERSIST_XS_DELTA;
+    return (solver == 1 || adam) ? 0 : x > 104 ? 104 : x;
+}
 inline bool persist_wide_ok(int solver, bool adam, int N) { return N > PERSIST_MAX_N && (N + 15) / 16 <= persist_wide_max_nch(solver, adam); }
 // its estimate: rounds of one row set (two DL rows, four of a one-stream solver) per CU x the measured round
 inline double persist_wide_us(int solver, bool adam, int B, int N, int cus) {
@@ -269,10 +281,27 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
                     std::fprintf(stderr, "ccvm: no row-owner kernel for N = %d of this solver variant\n", a.N);
                     std::abort();
                 }
-                if constexpr (MAXCH >= 17) { if (nch == 17) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 17, 4, 2, 0, 0, 8 * 17 - KR>), grid, block, 0, st, a); }
-                if constexpr (MAXCH >= 18) { if (nch == 18) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 18, 4, 2, 0, 0, 8 * 18 - KR>), grid, block, 0, st, a); }
-                if constexpr (MAXCH >= 19) { if (nch == 19) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 19, 4, 2, 0, 0, 8 * 19 - KR>), grid, block, 0, st, a); }
-                if constexpr (MAXCH >= 20) { if (nch >= 20) hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, 20, 4, 2, 0, 0, 8 * 20 - KR>), grid, block, 0, st, a); }
+                const bool uneq = a.xs_override != 1;  // (1: equal halves, tuning)
+#define CCVM_WIDE_CASE(NCHV, COND)                                                                                                        \
+    if constexpr (MAXCH >= NCHV) {                                                                                                        \
+        if (COND) {                                                                                                                       \
+            bool launched = false;                                                                                                        \
+            if constexpr (persist_wide_xs(SOLVER, ADAM, NCHV) > 0) {                                                                      \
+                if (uneq) {                                                                                                               \
+                    hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, NCHV, 4, 2, 0, 0, 8 * NCHV - KR, persist_wide_xs(SOLVER, ADAM, NCHV)>), \
+                                       grid, block, 0, st, a);                                                                            \
+                    launched = true;                                                                                                      \
+                }                                                                                                                         \
+            }                                                                                                                             \
+            if (!launched)                                                                                                                \
+                hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, NCHV, 4, 2, 0, 0, 8 * NCHV - KR>), grid, block, 0, st, a);           \
+        }                                                                                                                                 \
+    }
+                CCVM_WIDE_CASE(17, nch == 17)
+                CCVM_WIDE_CASE(18, nch == 18)
+                CCVM_WIDE_CASE(19, nch == 19)
+                CCVM_WIDE_CASE(20, nch >= 20)
+#undef CCVM_WIDE_CASE
             }
             break;
     }

@@ -36,6 +36,7 @@ namespace ccvm {
 //   CCVM_AMD_PERSIST_PW=0|1   its noise producer waves off / on (N <= 128; default: by shape and batch size)
 //   CCVM_AMD_PERSIST_RSW=1|2  row sets per workgroup of its six-wave row sets (128 < N <= 192 with the K split; default: by batch size)
 //   CCVM_AMD_PERSIST_CW=32|64 64 < N <= 96: three 32-column waves side by side (eight rows each) / two 64-column waves
+//   CCVM_AMD_PERSIST_XS=0|1   five waves side by side: equal K halves / the unequal split that balances the SIMDs (default)
 //   CCVM_AMD_PERSIST_WIDE=0   256 < N <= 320 stays on the column-cluster / slab / tile kernels (default: DL and Langevin without
 //                             Adam run the row-owner kernel's five-waves-side-by-side shape there)
 //   CCVM_AMD_SPIN_MS=x        bound of a wait for another workgroup, milliseconds (default: spin_ticks below -- 20 ms or 50
@@ -53,6 +54,7 @@ struct Tuning {
     int persist_pw = 0;  // noise producer waves of the row-owner kernel: 1 off, 2 on, 0: by shape and batch size
     int persist_rsw = 0; // row sets per workgroup where a row set is six waves (128 < N <= 192, K split): 1 / 2, 0: by batch size
     int persist_cw = 0;  // 64 < N <= 96: 32 = three 32-column waves side by side (eight rows each), 64 = two 64-column waves, 0: by policy
+    int persist_xs = 0;  // five waves side by side: 1 equal K halves, 2 the unequal split, 0: default (unequal)
     int persist_wide = -1;  // 256 < N <= 320 on the row-owner kernel (five waves side by side, DL / Langevin without Adam): 0 never, else where it applies
     int cluster_drop = 0;  // fault injection (tests): workgroups left out of a cluster launch
     double spin_ms = 0.0;  // CCVM_AMD_SPIN_MS: > 0 replaces the bound of the cross-workgroup waits

@@ -51,6 +51,8 @@ Tuning read_tuning() {
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_RSW"))
         if (e[0] == '1' || e[0] == '2') t.persist_rsw = e[0] - '0';
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_WIDE")) t.persist_wide = e[0] != '0';
+    if (const char* e = std::getenv("CCVM_AMD_PERSIST_XS"))
+        if (e[0] == '0' || e[0] == '1') t.persist_xs = e[0] - '0' + 1;
     if (const char* e = std::getenv("CCVM_AMD_PERSIST_CW"))
         if (!std::strcmp(e, "32") || !std::strcmp(e, "64")) t.persist_cw = std::atoi(e);
     // CCVM_AMD_FAULT=cluster_drop: the cluster path launches without its last 8 workgroups, so the last member of

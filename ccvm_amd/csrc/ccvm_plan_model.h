@@ -24,10 +24,11 @@ constexpr double CLUSTER_ROUND_US[8][3] = {{7.16, 3.49, 3.37}, {7.9, 4.05, 3.77}
 constexpr double CLUSTER_TWO_SETS = 0.70, CLUSTER_TWO_SETS_SPREAD = 0.80;
 constexpr double CLUSTER_MARGIN = 0.98;  // (the audit: 0.95 kept six cells on the cluster path that one round of 32 x 64 tiles beats by 5-7 %; 1.0 loses Langevin + Adam N = 640, B = 2000 by 9 %)
 // the row-owner kernel's five waves side by side (256 < N <= 320): us per step of a round of one row set per CU, by K chunks
-// 17 ... 20 [DL, Langevin / pumped Langevin] (profiles/r06_ab_persist_wide.txt: flat in the batch up to a row set per CU)
-constexpr double PERSIST_WIDE_ROUND_US[2][4] = {{2.03, 2.05, 2.15, 2.24}, {2.10, 2.11, 2.23, 2.31}};
-// ... MF (17 chunks only: 2.28-2.30), and Langevin + Adam relative to Langevin (17 / 18 chunks: 2.50 / 2.55) -- profiles/r06_ab_persist_wide2.txt
-constexpr double PERSIST_WIDE_ROUND_MF_US = 2.30, PERSIST_WIDE_ADAM = 1.2;
+// 17 ... 20 [DL, Langevin / pumped Langevin], flat in the batch up to a row set per CU (profiles/r06_ab_persist_xs.txt,
+// r06_ab_persist_xs_delta.txt: the unequal K split; with equal halves 2.03 ... 2.24 / 2.10 ... 2.31: r06_ab_persist_wide.txt)
+constexpr double PERSIST_WIDE_ROUND_US[2][4] = {{1.75, 1.84, 1.90, 2.01}, {1.86, 1.94, 2.00, 2.17}};
+// ... MF (17 chunks only: 2.28-2.30), and Langevin + Adam (equal halves) relative to Langevin (17 / 18 chunks: 2.50 / 2.55) -- profiles/r06_ab_persist_wide2.txt
+constexpr double PERSIST_WIDE_ROUND_MF_US = 2.30, PERSIST_WIDE_ADAM = 1.33;
 // a resident round of 32 x 128 tiles, us per step (fits of the regime map: DL 30.9 at N = 1000, 59 at N = 2000)
 constexpr double PTILE_DL_PER_N = 0.0281, PTILE_DL_0 = 2.8, PTILE_ONE_PER_N = 0.0145, PTILE_ONE_0 = 1.4, PTILE_MF_EXTRA = 0.4;
 }  // namespace ccvm

@@ -107,7 +107,7 @@ def test_describe_launch_names_the_instantiation(hip_lib):
         (1, 1000, 500, 0): "ccvm::cluster_kernel<1, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (2, 1000, 500, 1): "ccvm::cluster_kernel<2, true, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
         (0, 1000, 500, 0): "ccvm::cluster_kernel<0, false, 4, false> grid 256 x 512 threads (32 clusters of 8 workgroups)",
-        (0, 1000, 300, 0): "ccvm::persist_kernel<0, false, 64, 5, 19, 4, 2, 0, 0, 48> grid 500 x 640 threads (five waves side by side, 48 of a wave's 152 fragments in LDS)",
+        (0, 1000, 300, 0): "ccvm::persist_kernel<0, false, 64, 5, 19, 4, 2, 0, 0, 48, 104> grid 500 x 640 threads (five waves side by side, K split 104 | 200, the long parts' last 96 fragments in LDS)",
         (1, 1000, 300, 0): "ccvm::cluster_kernel_half<1, false, 3, false> grid 160 x 512 threads (32 clusters of 5 workgroups)",
         (2, 4000, 500, 0): "ccvm::cluster_kernel<2, false, 4, false> grid 256 x 512 threads x 4 launches of at most 32 clusters (125 clusters of 8 workgroups)",
         (0, 4000, 500, 0): "ccvm::step_kernel<0, false, 0, 1, false, 0> grid 500 x 512",

@@ -112,7 +112,7 @@ def test_five_waves_side_by_side_match_oracle(monkeypatch, kind, n, b, t):
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")  # (wherever it applies: the default leaves the smallest batches to the slab kernel)
     d = _describe(kind, b, n)
-    assert re.search(r"persist_kernel<[02], false, 64, 5, (17|18|19|20), 4, 2, 0, 0, (32|40|48|56)> grid \d+ x 640 threads", d), d
+    assert re.search(r"persist_kernel<[02], false, 64, 5, (17|18|19|20), 4, 2, 0, 0, (32|40|48|56)(, \d+)?> grid \d+ x 640 threads", d), d
     _check_against_oracle(kind, n, b, t, None)
 
 
@@ -157,9 +157,9 @@ def test_the_other_variants_stay_on_the_cluster_kernel_between_256_and_320_colum
     # by the estimates: the slab kernel keeps the smallest batches, the cluster kernel a batch its 48-row clusters hold in ONE
     # round where row sets need two (Langevin, B = 1500: 3.35 us per step against 4.5)
     assert "slab_kernel" in _describe("dl", 32, 300) and "persist_kernel" in _describe("dl", 128, 300)
-    assert "slab_kernel" in _describe("langevin", 128, 300) and "persist_kernel" in _describe("langevin", 256, 300)
+    assert "slab_kernel" in _describe("langevin", 32, 300) and "persist_kernel" in _describe("langevin", 128, 300)
     assert "cluster_kernel" in _describe("langevin", 1500, 300) and "persist_kernel" in _describe("langevin", 2000, 300)
-    assert "estimated 4.30 us per step" in _describe("dl", 1000, 300) and "estimated 2.23 us per step" in _describe("langevin", 1000, 300)
+    assert "estimated 3.80 us per step" in _describe("dl", 1000, 300) and "estimated 2.00 us per step" in _describe("langevin", 1000, 300)
     monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "0")
     assert "cluster_kernel" in _describe("dl", 1000, 300) and "slab_kernel" in _describe("dl", 32, 300)
     monkeypatch.delenv("CCVM_AMD_PERSIST_WIDE")

@@ -35,7 +35,8 @@ def _unsharded(kind, n, batch):
 
 @pytest.mark.parametrize("backend,world,kind,n,batch", [
     ("gloo", 2, "dl", 40, 70),      # persistent kernel, even shards
-    ("gloo", 3, "pl", 300, 100),    # tile kernel, uneven shards (34 + 33 + 33): odd row offsets
+    ("gloo", 3, "pl", 300, 1000),   # uneven shards (334 + 333 + 333): odd row offsets; whole batch and shards on the same kernel family
+                                    # (a 100-row batch is on the border between the slab and the row-owner kernel: its shards are not)
     ("gloo", 2, "mf", 130, 33),     # uneven shards of an odd batch
     ("nccl", 1, "dl", 64, 50),      # the device-side collective (RCCL)
 ])
