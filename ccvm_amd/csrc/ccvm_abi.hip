@@ -625,6 +625,9 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
                               persist_wide_xs(solver, ad, sh.nch), sh.grid, sh.threads, persist_wide_xs(solver, ad, sh.nch),
                               16 * sh.nch - persist_wide_xs(solver, ad, sh.nch),
                               16 * sh.nch - persist_wide_xs(solver, ad, sh.nch) - persist_wide_kr(solver, ad), TABLE_STEPS);
+        else if (sh.xs > 0 && tun.persist_xs != 1)
+            std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, 0, %d> grid %d x %d threads (K split %d | %d), up to %d steps per launch",
+                          solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.xs, sh.grid, sh.threads, sh.xs, 16 * sh.nch - sh.xs, TABLE_STEPS);
         else if (sh.rsw == 2)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 2> grid %d x %d threads (two row sets per workgroup), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.grid, sh.threads, TABLE_STEPS);

@@ -185,7 +185,8 @@ constexpr int persist_block_threads(int ncg, int kh, int pw, int rswo) {
 // long ones keep KR = K / 2 - QL in registers like the equal halves and K - XS - KR in LDS.
 template <int MODE, bool ADAM, int CW, int NCG, int NCH, int RU, int KH = 1, int PW = 0, int RSWO = 0, int QL = 0, int XS = 0>
 __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void persist_kernel(const PersistArgs a) {
-    static_assert(XS == 0 || (NCG == 5 && KH == 2 && QL > 0 && XS % 4 == 0 && XS <= 8 * NCH - QL), "unequal K split: five side by side, the short part in registers");
+    static_assert(XS == 0 || (KH == 2 && XS % 4 == 0 && ((NCG == 5 && QL > 0 && XS <= 8 * NCH - QL) || (NCG == 3 && QL == 0 && RSWO == 0 && CW == 64))),
+                  "unequal K split: five side by side (the short part in registers, the long one partly in LDS) or three (six waves, {0, 4} {1, 5} {2} {3}: all in registers)");
     static_assert(KH == 1 || (KH == 2 && NCG >= 2 && NCG <= 5 && RU == 4), "K split: waves side by side, all four rows in use");
     static_assert(QL == 0 || (KH == 2 && QL % 4 == 0 && PW == 0 && RSWO == 0), "fragments in LDS: K split only, whole groups of four");
     static_assert(PW == 0 || (PW == 1 && NCG * KH <= 4), "producer waves: at most eight waves per workgroup");
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     // dt, S, has_next (unused here), + the unused words 14, 15; Langevin: all but the pump term
     constexpr unsigned ROW_SAME = (MODE == MODE_DL) ? 0x030u : (MODE == MODE_MF) ? 0xCD8Eu : 0xC0FBu;
     constexpr int PXA = (RSWO ? RSW : 1) * PXF;                // (without RSWO a K-split workgroup is one row set)
-    constexpr int QLH = XS ? 16 * NCH - XS - (8 * NCH - QL) : 0; // unequal split: the long parts' fragments in LDS (K - XS - KR)
+    constexpr int QLH = (XS && QL) ? 16 * NCH - XS - (8 * NCH - QL) : 0; // unequal split: the long parts' fragments in LDS (K - XS - KR)
     constexpr int QTF = XS ? (4 * QLH + 2 * QL) * 64 : QL * 64 * NWC;  // fragments kept in LDS: [consumer wave][k / 4][lane][k % 4]
     __shared__ __attribute__((aligned(16))) float xs_all[RSW * 2 * ROWS * LDX + PXA + NZF + RING + QTF];
     float* const nzl = xs_all + RSW * 2 * ROWS * LDX + PXA;
@@ -247,9 +248,11 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     const int wave = (PW && wave_all >= NWC) ? wave_all - NWC : wave_all;  // a producer has its consumer's index and element map
     const int set = wave / (NCG * KH), wis = wave % (NCG * KH);  // row set of the workgroup, wave inside the row set
     // (unequal split: waves 0 1 4 5 = the short parts of column groups 0 1 2 3, waves 2 3 6 7 their long parts, 8 9 = the halves of 4)
-    const int cg = XS ? (wis < 8 ? ((wis >> 2) * 2 + (wis & 1)) : 4) : wis % NCG;
-    const int kh = XS ? (wis < 8 ? ((wis >> 1) & 1) : (wis & 1)) : (KH == 2) ? wis / NCG : 0;  // K half (wave-uniform)
-    const int role = XS ? (wis < 8 ? kh : 2 + kh) : kh;  // unequal split: 0 short, 1 long, 2 / 3 the equal halves
+    // (three side by side: waves 0 1 = the short parts of column groups 0 1, waves 2 3 their long parts -- alone on their SIMDs --, 4 5 the halves of 2)
+    constexpr int NUW = 2 * (NCG - 1);  // waves of the unequally split column groups
+    const int cg = XS ? (wis < NUW ? ((wis >> 2) * 2 + (wis & 1)) : NCG - 1) : wis % NCG;
+    const int kh = XS ? (wis < NUW ? ((wis >> 1) & 1) : (wis & 1)) : (KH == 2) ? wis / NCG : 0;  // K half (wave-uniform)
+    const int role = XS ? (wis < NUW ? kh : 2 + kh) : kh;  // unequal split: 0 short, 1 long, 2 / 3 the equal halves
     float* const xs = xs_all + set * (2 * ROWS * LDX);
     float* const px = xs_all + RSW * 2 * ROWS * LDX + (RSWO ? set : 0) * PXF;
     const int rs = lane / CW;            // row group
@@ -266,14 +269,16 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     const int koff = XS ? (role == 0 ? 0 : role == 1 ? XS : (role - 2) * KSPLIT) : kh * KSPLIT;
     constexpr int KR = KQ - QL;  // fragments in registers: the first KR k-steps of the wave's range
     static_assert(KR >= 4, "fragments in LDS: some stay in registers");
-    const int nreg = (XS && role == 0) ? XS : KR;                   // (the short parts: all of them)
+    constexpr int KRL = (XS && !QL) ? KMAX - XS : KR;               // the long parts' fragments in registers (no LDS: all of them)
+    constexpr int QF = KRL > KR ? KRL : KR;                         // fragment registers of the kernel: the largest role's
+    const int nreg = (XS && role == 0) ? XS : (XS && role == 1) ? KRL : KR;  // (the short parts: all of them)
     const int nlds = XS ? (role == 0 ? 0 : role == 1 ? QLH : QL) : QL;  // this wave's fragments in LDS
-    float qf[KR];
+    float qf[QF];
 #pragma unroll
-    for (int k = 0; k < KR; ++k) qf[k] = 0.0f;
+    for (int k = 0; k < QF; ++k) qf[k] = 0.0f;
     if (!producer) {
 #pragma unroll
-        for (int k = 0; k < KR; ++k) qf[k] = (k < nreg && koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
+        for (int k = 0; k < QF; ++k) qf[k] = (k < nreg && koff + k < KMAX) ? a.Q[(size_t)(koff + k) * ld + col] : 0.0f;
     }
     // this lane's fragments of group g: qt[g * 256 .. + 3] (unequal split: the four long parts first, then column group 4's halves)
     float* const qt = qtail + (XS ? (role == 1 ? ((wis >> 2) * 2 + (wis & 1)) * (QLH * 64) : 4 * (QLH * 64) + (wis & 1) * (QL * 64))
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
     constexpr int K0 = XS ? (ROLE == 0 ? 0 : ROLE == 1 ? XS : H * KSPLIT) : H * KSPLIT;
     constexpr int K1 = XS ? (ROLE == 0 ? XS : ROLE == 1 ? KMAX : (H * KSPLIT + KSPLIT < KMAX ? H * KSPLIT + KSPLIT : KMAX))
                           : (K0 + KSPLIT < KMAX) ? K0 + KSPLIT : KMAX;
-    constexpr int KRR = (XS && ROLE == 0) ? XS : KR;
+    constexpr int KRR = (XS && ROLE == 0) ? XS : (XS && ROLE == 1) ? KRL : KR;
     for (int it = 0; it < a.nsteps; ++it) {
         const int step = a.step0 + it;
         const Row rcur = rnext;  // (producer waves: unused -- the row comes out of the ring below)
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(persist_block_threads(NCG, KH, PW, RSWO)) void pers
                 if (rem > 4) mfma_chain_at<CBSZ, KC, FULL + 4>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 8) mfma_chain_at<CBSZ, KC, FULL + 8>(af, qf, acc, std::make_integer_sequence<int, 4>{});
                 if (rem > 12) mfma_chain_at<CBSZ, KC, FULL + 12>(af, qf, acc, std::make_integer_sequence<int, 4>{});
-            } else if constexpr (KH == 2 && QL > 0) {
+            } else if constexpr (KH == 2 && (QL > 0 || XS > 0)) {
                 static_assert(XS || K1 - K0 == KQ, "fragments in LDS: equal halves");
                 static_assert((K1 - K0 - KRR) % 4 == 0 && K1 - K0 >= KRR, "fragments in LDS: whole groups of four");
                 constexpr int G = (K1 - K0 - KRR) / 4, AHEAD = CCVM_PERSIST_QL_AHEAD;  // groups of four k-steps out of LDS, read AHEAD groups ahead of their MFMAs

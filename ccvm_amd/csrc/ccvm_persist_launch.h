@@ -32,6 +32,15 @@ constexpr int persist_wide_xs(int solver, bool adam, int nch) {
     const int x = (nch == 17 ? 96 : 104) + CCVM_PERSIST_XS_DELTA;
     return (solver == 1 || adam) ? 0 : x > 104 ? 104 : x;
 }
+// ... and of three waves side by side x two K halves in ONE six-wave workgroup per CU -- {0, 4} {1, 5} {2} {3} on the SIMDs: the
+// waves alone on theirs take the long parts, all fragments in registers (K / 4 - V / 16, a multiple of four; swept on the
+// chip, profiles/r06_ab_persist_xs3_delta.txt: the table for DL and MF, eight more for Langevin, whose update is the shortest)
+#ifndef CCVM_PERSIST_XS3_DELTA
+#define CCVM_PERSIST_XS3_DELTA 0   // (tuning builds)
+#endif
+constexpr int persist_xs3(int solver, int nch) {
+    return (nch == 9 ? 16 : nch == 10 ? 20 : nch == 11 ? 24 : 28) + (solver == 2 ? 8 : 0) + CCVM_PERSIST_XS3_DELTA;
+}
 inline bool persist_wide_ok(int solver, bool adam, int N) { return N > PERSIST_MAX_N && (N + 15) / 16 <= persist_wide_max_nch(solver, adam); }
 // its estimate: rounds of one row set (two DL rows, four of a one-stream solver) per CU x the measured round
 inline double persist_wide_us(int solver, bool adam, int B, int N, int cus) {
@@ -52,6 +61,7 @@ void persist_launch_lv_adam(const PersistArgs& a, hipStream_t st);
 struct PersistShape {
     int cw, ncg, nch, ru, grid, kh, pw, threads;
     int rsw;        // 2: two six-wave row sets per workgroup (three side by side x two K halves), else 0
+    int xs;         // > 0: the unequal K split's short part (three side by side, one six-wave workgroup per CU: persist_xs3)
     double est_us;  // the variant model's estimate (one wave per row set, N <= 64: ccvm_persist_model.h); five side by side: rounds x
                     // the measured round (ccvm_plan_model.h); else 0
 };
@@ -148,6 +158,10 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         const bool pays = 8 * r2 < 5 * r1 && kh_override != 1 && !(ru_override == 2 || ru_override == 4);
         if (rsw_override == 2 ? (s.kh == 2 || pays) : (rsw_override == 0 && pays)) { s.kh = 2; s.ru = 4; s.rsw = 2; }
     }
+    // (one six-wave workgroup per CU -- the K split, every row set with a CU of its own: the unequal split; with more
+    // workgroups on a CU its 200+ registers would keep the second one out)
+    s.xs = 0;
+    if (s.ncg == 3 && !narrow && s.kh == 2 && s.rsw == 0 && (B + br4 - 1) / br4 <= simds / 4) s.xs = persist_xs3(solver, s.nch);
     if (s.ncg == 5) { s.kh = 2; s.ru = 4; }  // five side by side: the K split only (ten waves, fragments partly in LDS)
     const double wide_est = s.ncg == 5 ? persist_wide_us(solver, adam, B, N, simds / 4) : 0.0;
     // Noise producer waves (ccvm_persist.h, PW).
@@ -225,6 +239,13 @@ void launch_persist_shape(const PersistArgs& a, hipStream_t st) {
     if constexpr (NCG == 3 && !NARROW && !(MODE == MODE_MF && ADAM && NCH >= 11)) {  // (MF + Adam from 11 K chunks: > 168 VGPRs, persist_shape)
         if (sh.kh == 2 && sh.rsw == 2) {  // two row sets of six waves
             hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 0, 2>), dim3(sh.grid), block, 0, st, a);
+            return;
+        }
+    }
+    if constexpr (NCG == 3 && !NARROW) {
+        if (sh.kh == 2 && sh.rsw == 0 && sh.xs > 0 && a.xs_override != 1) {  // one six-wave workgroup per CU: the unequal K split
+            hipLaunchKernelGGL((persist_kernel<MODE, ADAM, CW, NCG, NCH, 4, 2, 0, 0, 0, persist_xs3(MODE == MODE_DL ? 0 : MODE == MODE_MF ? 1 : 2, NCH)>),
+                               dim3(sh.grid), block, 0, st, a);
             return;
         }
     }

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _kh(kind, b, n, adam=False):
-    return int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, \d+, \d+, (\d)(?:, \d)?(?:, \d)?>", _describe(kind, b, n, adam)).group(1))
+    return int(re.search(r"persist_kernel<\d, \w+, \d+, \d+, \d+, \d+, (\d)(?:, \d+)*>", _describe(kind, b, n, adam)).group(1))
 
 
 @pytest.mark.parametrize("kh", [1, 2])

@@ -195,7 +195,7 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
     (profiles/r06_ab_persist_ncg3.txt, r06_ab_persist_kh_small.txt) -- up to N = 224: from 15 K chunks on the unsplit kernel's
     registers turn the comparison around."""
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
-    shape = re.compile(r"persist_kernel<\d, \w+, 64, (\d), (\d+), (\d), (\d)(?:, \d)?(?:, \d)?> grid (\d+) x (\d+) threads")
+    shape = re.compile(r"persist_kernel<\d, \w+, 64, (\d), (\d+), (\d), (\d)(?:, \d+)*> grid (\d+) x (\d+) threads")
 
     def plan(solver, b, n, adam=0):
         m = shape.search(_describe(hip_lib, solver, b, n, adam))
@@ -300,6 +300,35 @@ def test_row_owners_between_256_and_320_columns(hip_lib, clean_env):
 
     ten = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<[012], \w+, 64, 5, ", k["name"])]
     assert len(ten) == 19 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] and k["lds"] <= 160 * 1024 for k in ten), ten
+
+
+def test_unequal_k_split_of_six_wave_workgroups(hip_lib, clean_env):
+    """Round 6: three waves side by side x two K halves in ONE six-wave workgroup per CU land {0, 4} {1, 5} {2} {3} on the SIMDs
+    (tools/simd_probe.hip); the waves alone on a SIMD take the long parts of an UNEQUAL K split (profiles/r06_ab_persist_xs3.txt:
+    -12 ... -17 %).  Only while every row set has a CU of its own: the long parts' 180-250 registers let no second workgroup in."""
+    import os
+    import sys
+
+    clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
+    xs = lambda solver, b, n, adam=0: re.search(r"persist_kernel<\d, \w+, 64, 3, \d+, 4, 2, 0, 0, 0, (\d+)> grid (\d+) x 384 threads \(K split (\d+) \| (\d+)\)",
+                                                _describe(hip_lib, solver, b, n, adam))
+    assert xs(0, 512, 144).groups() == ("16", "256", "16", "128") and xs(0, 300, 192).groups() == ("28", "150", "28", "164")
+    assert xs(2, 1000, 144).groups() == ("24", "250", "24", "120") and xs(1, 1024, 176).groups() == ("24", "256", "24", "152")
+    assert xs(1, 1000, 160, 1) and xs(2, 600, 130, 1)
+    assert not xs(0, 256, 144) and not xs(2, 512, 144)      # the two-rows rule's range: whole chains
+    assert not xs(0, 513, 144) and not xs(2, 1025, 144)     # more row sets than CUs: twelve-wave workgroups / whole chains
+    assert not xs(0, 512, 200) and not xs(0, 512, 128)      # three side by side only
+    clean_env.setenv("CCVM_AMD_PERSIST_XS", "0")
+    assert not xs(0, 512, 144) and "64, 3, 9, 4, 2> grid 256 x 384" in _describe(hip_lib, 0, 512, 144)
+    clean_env.delenv("CCVM_AMD_PERSIST_XS")
+    clean_env.setenv("CCVM_AMD_PERSIST_KH", "2")            # forced at a small batch: the same shape
+    assert xs(0, 33, 129)
+    clean_env.delenv("CCVM_AMD_PERSIST_KH")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+
+    six = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<\d, \w+, 64, 3, \d+, 4, 2, 0, 0, 0, [1-9]\d*>", k["name"])]
+    assert len(six) == 20 and all(k["vgpr"] + k["agpr"] <= 256 and not k["spill"] for k in six), six
 
 
 def test_every_row_owner_shape_the_policy_picks_is_in_the_library(hip_lib, clean_env):
