@@ -621,10 +621,10 @@ int describe_plan(int solver, int B, int N, int adam, int per_variable_s, char* 
                               8 * sh.nch - persist_wide_kr(solver, ad), 8 * sh.nch, TABLE_STEPS);
             else
                 std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, %d, %d> grid %d x %d threads (five waves side by side, K split %d | %d, the long parts' last %d fragments in LDS), up to %d steps per launch",
-                              solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr(solver, ad),
+                              solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, 8 * sh.nch - persist_wide_kr_xs(solver, ad),
                               persist_wide_xs(solver, ad, sh.nch), sh.grid, sh.threads, persist_wide_xs(solver, ad, sh.nch),
                               16 * sh.nch - persist_wide_xs(solver, ad, sh.nch),
-                              16 * sh.nch - persist_wide_xs(solver, ad, sh.nch) - persist_wide_kr(solver, ad), TABLE_STEPS);
+                              16 * sh.nch - persist_wide_xs(solver, ad, sh.nch) - persist_wide_kr_xs(solver, ad), TABLE_STEPS);
         else if (sh.xs > 0 && tun.persist_xs != 1)
             std::snprintf(buf, buf_len, "ccvm::persist_kernel<%d, %s, %d, %d, %d, %d, %d, 0, 0, 0, %d> grid %d x %d threads (K split %d | %d), up to %d steps per launch",
                           solver, ad ? "true" : "false", sh.cw, sh.ncg, sh.nch, sh.ru, sh.kh, sh.xs, sh.grid, sh.threads, sh.xs, 16 * sh.nch - sh.xs, TABLE_STEPS);

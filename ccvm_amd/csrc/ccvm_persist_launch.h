@@ -23,14 +23,15 @@ constexpr int persist_wide_max_nch(int solver, bool adam) { return solver == 1 ?
 // the unequal K split's short part (ccvm_persist.h: XS): (12 K - V) / 32 k-steps balance the SIMDs' issue (V: a wave's update,
 // ~350 cycles), a multiple of four, and all of them in registers (<= 104) -- then swept +-4 / 8 around that on the chip
 // (profiles/r06_ab_persist_xs_delta.txt): 96 at 17 K chunks, the cap from 18 on
-// (DL and Langevin without Adam; MF and Langevin + Adam, whose short parts would be capped at their 84 / 92 registers, spill
-// 2-4 registers in that form and keep equal halves: 0)
+// (MF and Langevin + Adam: the unequal form keeps four fragments fewer in registers -- 80 / 88 -- than their equal halves, and
+// their short parts are all of those)
 #ifndef CCVM_PERSIST_XS_DELTA
 #define CCVM_PERSIST_XS_DELTA 0   // (tuning builds: the short part longer / shorter by this many k-steps)
 #endif
+constexpr int persist_wide_kr_xs(int solver, bool adam) { return solver == 1 ? (adam ? 0 : 80) : (solver == 2 && adam) ? 88 : 104; }
 constexpr int persist_wide_xs(int solver, bool adam, int nch) {
-    const int x = (nch == 17 ? 96 : 104) + CCVM_PERSIST_XS_DELTA;
-    return (solver == 1 || adam) ? 0 : x > 104 ? 104 : x;
+    const int x = (nch == 17 ? 96 : 104) + CCVM_PERSIST_XS_DELTA, cap = persist_wide_kr_xs(solver, adam);
+    return x > cap ? cap : x;
 }
 // ... and of three waves side by side x two K halves in ONE six-wave workgroup per CU -- {0, 4} {1, 5} {2} {3} on the SIMDs: the
 // waves alone on theirs take the long parts, all fragments in registers (K / 4 - V / 16, a multiple of four; swept on the
@@ -309,7 +310,8 @@ void launch_persist(const PersistArgs& a, hipStream_t st) {
             bool launched = false;                                                                                                        \
             if constexpr (persist_wide_xs(SOLVER, ADAM, NCHV) > 0) {                                                                      \
                 if (uneq) {                                                                                                               \
-                    hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, NCHV, 4, 2, 0, 0, 8 * NCHV - KR, persist_wide_xs(SOLVER, ADAM, NCHV)>), \
+                    hipLaunchKernelGGL((persist_kernel<MODE, ADAM, 64, 5, NCHV, 4, 2, 0, 0, 8 * NCHV - persist_wide_kr_xs(SOLVER, ADAM),          \
+                                                       persist_wide_xs(SOLVER, ADAM, NCHV)>),                                              \
                                        grid, block, 0, st, a);                                                                            \
                     launched = true;                                                                                                      \
                 }                                                                                                                         \

@@ -27,8 +27,9 @@ constexpr double CLUSTER_MARGIN = 0.98;  // (the audit: 0.95 kept six cells on t
 // 17 ... 20 [DL, Langevin / pumped Langevin], flat in the batch up to a row set per CU (profiles/r06_ab_persist_xs.txt,
 // r06_ab_persist_xs_delta.txt: the unequal K split; with equal halves 2.03 ... 2.24 / 2.10 ... 2.31: r06_ab_persist_wide.txt)
 constexpr double PERSIST_WIDE_ROUND_US[2][4] = {{1.75, 1.84, 1.90, 2.01}, {1.86, 1.94, 2.00, 2.17}};
-// ... MF (17 chunks only: 2.28-2.30), and Langevin + Adam (equal halves) relative to Langevin (17 / 18 chunks: 2.50 / 2.55) -- profiles/r06_ab_persist_wide2.txt
-constexpr double PERSIST_WIDE_ROUND_MF_US = 2.30, PERSIST_WIDE_ADAM = 1.33;
+// ... MF (17 chunks only: 2.27; 2.30-2.34 with equal halves), and Langevin + Adam relative to Langevin (17 / 18 chunks: 2.27 / 2.39;
+// 2.50 / 2.56 with equal halves) -- profiles/r06_ab_persist_wide2.txt, r06_ab_persist_xs2.txt
+constexpr double PERSIST_WIDE_ROUND_MF_US = 2.27, PERSIST_WIDE_ADAM = 1.23;
 // a resident round of 32 x 128 tiles, us per step (fits of the regime map: DL 30.9 at N = 1000, 59 at N = 2000)
 constexpr double PTILE_DL_PER_N = 0.0281, PTILE_DL_0 = 2.8, PTILE_ONE_PER_N = 0.0145, PTILE_ONE_0 = 1.4, PTILE_MF_EXTRA = 0.4;
 }  // namespace ccvm

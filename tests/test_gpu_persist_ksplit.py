@@ -122,12 +122,12 @@ def test_five_waves_side_by_side_match_oracle(monkeypatch, kind, n, b, t):
     ("pl", 273, 7, 12, "second_moment"),
 ])
 def test_five_waves_side_by_side_of_mf_and_langevin_with_adam_match_oracle(monkeypatch, kind, n, b, t, adam):
-    """... and where their larger working sets leave room: MF up to N = 272 (84 fragments of a wave in registers, 52 in LDS),
-    Langevin + Adam up to N = 288 (92 / 44 ... 52)."""
+    """... and where their larger working sets leave room: MF up to N = 272 (80 fragments of a wave in registers), Langevin +
+    Adam up to N = 288 (88) -- the unequal K split, its short parts all of those registers."""
     monkeypatch.delenv("CCVM_AMD_KERNEL", raising=False)
     monkeypatch.setenv("CCVM_AMD_PERSIST_WIDE", "1")
     d = _describe(kind, b, n, adam is not None)
-    assert re.search(r"persist_kernel<[12], \w+, 64, 5, (17|18), 4, 2, 0, 0, (44|52)> grid \d+ x 640 threads", d), d
+    assert re.search(r"persist_kernel<[12], \w+, 64, 5, (17|18), 4, 2, 0, 0, (48|56), (80|88)> grid \d+ x 640 threads", d), d
     _check_against_oracle(kind, n, b, t, adam)
 
 

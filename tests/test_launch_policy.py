@@ -266,14 +266,14 @@ def test_row_owners_between_256_and_320_columns(hip_lib, clean_env):
         assert m and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (nch, ql, 250), (n, m and m.groups())
         # MF keeps 84 fragments of a wave in registers and reaches N = 272, Langevin + Adam 92 and N = 288, MF + Adam nothing
         assert (wide(1, 1000, n) is not None) == (n <= 272) and (wide(2, 1000, n, 1) is not None) == (n <= 288) and not wide(1, 1000, n, 1)
-    assert wide(1, 1000, 272).groups()[:3] == ("17", "52", "250") and wide(2, 1000, 288, 1).groups()[:3] == ("18", "52", "250")
-    assert float(wide(1, 1000, 260).group(4)) == 2.30 and abs(float(wide(2, 1000, 260, 1).group(4)) - 2.47) < 0.011
+    assert wide(1, 1000, 272).groups()[:3] == ("17", "56", "250") and wide(2, 1000, 288, 1).groups()[:3] == ("18", "56", "250")
+    assert float(wide(1, 1000, 260).group(4)) == 2.27 and abs(float(wide(2, 1000, 260, 1).group(4)) - 2.29) < 0.011
     assert not wide(0, 1000, 256) and not wide(0, 1000, 321)
     # by estimate: rounds of one row set (two DL rows / four rows) per CU x the round -- against slab, cluster, tiles
     assert float(wide(0, 512, 300).group(4)) == 1.90 and float(wide(0, 513, 300).group(4)) == 3.80 and float(wide(2, 1024, 320).group(4)) == 2.17
     # DL and Langevin without Adam: the UNEQUAL K split (the waves that share a SIMD in threes take the short part)
     assert ", 0, 0, 48, 104> grid" in _describe(hip_lib, 0, 1000, 300) and "K split 104 | 200" in _describe(hip_lib, 0, 1000, 300)
-    assert ", 0, 0, 32, 96> grid" in _describe(hip_lib, 2, 1000, 257) and ", 0, 0, 52> grid" in _describe(hip_lib, 1, 1000, 257)
+    assert ", 0, 0, 32, 96> grid" in _describe(hip_lib, 2, 1000, 257) and ", 0, 0, 56, 80> grid" in _describe(hip_lib, 1, 1000, 257)
     assert "slab_kernel" in _describe(hip_lib, 0, 32, 300) and wide(0, 128, 300)            # DL: the slab kernel up to a few dozen rows
     assert "slab_kernel" in _describe(hip_lib, 2, 32, 300) and wide(2, 128, 300)           # Langevin: up to ~100
     assert "cluster_kernel" in _describe(hip_lib, 2, 1500, 300) and wide(2, 2000, 300)     # 48-row clusters: 1536 rows in ONE round
@@ -299,7 +299,7 @@ def test_row_owners_between_256_and_320_columns(hip_lib, clean_env):
     import kernel_resources
 
     ten = [k for k in kernel_resources.kernels() if re.search(r"persist_kernel<[012], \w+, 64, 5, ", k["name"])]
-    assert len(ten) == 19 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] and k["lds"] <= 160 * 1024 for k in ten), ten
+    assert len(ten) == 22 and all(k["vgpr"] + k["agpr"] <= 168 and not k["spill"] and k["lds"] <= 160 * 1024 for k in ten), ten
 
 
 def test_unequal_k_split_of_six_wave_workgroups(hip_lib, clean_env):
