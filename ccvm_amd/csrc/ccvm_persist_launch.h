@@ -136,7 +136,10 @@ inline PersistShape persist_shape(int solver, bool adam, int B, int N, int ru_ov
         // 1.04, + Adam 1.54 / 1.25; one row set more than CUs: 1.49 -- and from N = 241 the unsplit kernel's registers
         // turn it around, N = 256: 1.42 / 1.59: profiles/r06_ab_persist_kh_small.txt).
         const int sets2 = (B + br4 / 2 - 1) / (br4 / 2);
-        const bool two_rows_alone = s.ncg >= 3 && s.nch <= 14 && sets2 <= simds / 4 && ru_override != 4;
+        // (three side by side, DL and Langevin: the six-wave workgroup's unequal K split below is 3 % faster still -- DL N = 144
+        // 0.88 -> 0.86, Langevin 0.92 -> 0.89 -- and MF 2 % slower: 1.04 / 1.06; profiles/r06_ab_persist_xs3.txt)
+        const bool two_rows_alone = s.ncg >= 3 && s.nch <= 14 && sets2 <= simds / 4 && ru_override != 4 &&
+                                    !(s.ncg == 3 && solver != 1 && !ru_override && kh_override != 1);
         if (two_rows_alone) { s.kh = 1; s.ru = 2; }
         if (kh_override == 1) s.kh = 1;
         if (kh_override == 2) s.kh = 2;

@@ -179,9 +179,12 @@ def test_default_takes_the_split_where_it_costs_fewer_rounds_or_fills_lone_waves
     assert _kh("dl", 1500, 192) == 1 and _kh("dl", 500, 192) == 2 and _kh("langevin", 1000, 256) == 2  # 128 < N <= 256: same rule ...
     assert _kh("dl", 4000, 256) == 2 and _kh("mf", 4000, 176) == 2 and _kh("langevin", 2000, 208) == 1  # ... unless a SIMD holds one unsplit wave
     # small batches, N > 128 (round 6): whole chains over TWO rows while every such row set has a CU of its own
-    assert _kh("dl", 256, 144) == 1 and _kh("dl", 257, 144) == 2 and _kh("langevin", 512, 200) == 1 and _kh("langevin", 513, 200) == 2
+    # (three side by side: MF; DL and Langevin take the six-wave workgroup's unequal K split there, 3 % faster still)
+    assert _kh("mf", 512, 144) == 1 and _kh("mf", 513, 144) == 2 and _kh("langevin", 512, 200) == 1 and _kh("langevin", 513, 200) == 2
+    assert _kh("dl", 256, 144) == 2 and _kh("dl", 256, 200) == 1
     assert _kh("mf", 512, 224, adam=True) == 1 and _kh("mf", 512, 256) == 2 and _kh("dl", 100, 240) == 2  # (N <= 224: the unsplit kernel's registers)
-    assert "persist_kernel<0, false, 64, 3, 9, 2, 1> grid 256 x 192 threads" in _describe("dl", 256, 144)
+    assert "persist_kernel<1, false, 64, 3, 9, 2, 1> grid 256 x 192 threads" in _describe("mf", 512, 144)
+    assert "persist_kernel<0, false, 64, 3, 9, 4, 2, 0, 0, 0, 16> grid 128 x 384 threads (K split 16 | 128)" in _describe("dl", 256, 144)
     # more row sets than CUs, three waves side by side: two six-wave row sets per workgroup where that is fewer rounds x 1.6
     assert "64, 3, 9, 4, 2, 0, 2> grid 250 x 768 threads" in _describe("dl", 1000, 144) and _kh("dl", 1500, 144) == 1
     assert "0, 2> grid 150 x 768" in _describe("dl", 600, 160) and "0, 2> grid 250 x 768" in _describe("langevin", 2000, 176)

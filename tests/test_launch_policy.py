@@ -203,13 +203,15 @@ def test_row_owner_shapes_above_128_columns(hip_lib, clean_env):
 
     for n, ncg in ((129, 3), (160, 3), (192, 3), (193, 4), (256, 4)):
         assert plan(0, 1000, n)[0] == ncg and plan(2, 4000, n)[0] == ncg
-    # workgroups: three waves (whole chains), six (K split); four / eight above N = 192
-    assert plan(0, 256, 144) == (3, 9, 2, 1, 256, 192) and plan(0, 257, 144) == (3, 9, 4, 2, 129, 384)
+    # workgroups: three waves (whole chains over two rows: MF; DL and Langevin take the six-wave workgroup's unequal K split
+    # instead, test_unequal_k_split_of_six_wave_workgroups), six (K split); four / eight above N = 192
+    assert plan(1, 512, 144) == (3, 9, 2, 1, 256, 192) and plan(1, 513, 144) == (3, 9, 4, 2, 129, 384)
+    assert plan(0, 256, 144) == (3, 9, 4, 2, 128, 384) and plan(0, 257, 144) == (3, 9, 4, 2, 129, 384)
     assert plan(2, 512, 200) == (4, 13, 2, 1, 256, 256) and plan(2, 513, 200) == (4, 13, 4, 2, 129, 512)
     assert plan(1, 512, 224, 1)[2:4] == (2, 1) and plan(1, 512, 240)[2:4] == (4, 2) and plan(0, 64, 256)[2:4] == (4, 2)
     # half the chip: half the batch
     clean_env.setenv("CCVM_AMD_GEOMETRY", "128,4")
-    assert plan(0, 128, 144)[2:4] == (2, 1) and plan(0, 129, 144)[2:4] == (4, 2)
+    assert plan(1, 256, 144)[2:4] == (2, 1) and plan(1, 257, 144)[2:4] == (4, 2) and plan(0, 128, 200)[2:4] == (2, 1)
     clean_env.setenv("CCVM_AMD_GEOMETRY", "256,8")
     # the overrides still pin their dimension
     clean_env.setenv("CCVM_AMD_PERSIST_KH", "2")
@@ -315,7 +317,8 @@ def test_unequal_k_split_of_six_wave_workgroups(hip_lib, clean_env):
     assert xs(0, 512, 144).groups() == ("16", "256", "16", "128") and xs(0, 300, 192).groups() == ("28", "150", "28", "164")
     assert xs(2, 1000, 144).groups() == ("24", "250", "24", "120") and xs(1, 1024, 176).groups() == ("24", "256", "24", "152")
     assert xs(1, 1000, 160, 1) and xs(2, 600, 130, 1)
-    assert not xs(0, 256, 144) and not xs(2, 512, 144)      # the two-rows rule's range: whole chains
+    assert xs(0, 256, 144) and xs(2, 512, 144) and xs(0, 1, 130)   # DL / Langevin: from one row on (3 % ahead of whole chains over two rows)
+    assert not xs(1, 512, 144) and xs(1, 513, 144)                 # MF: whole chains over two rows while every such set has a CU
     assert not xs(0, 513, 144) and not xs(2, 1025, 144)     # more row sets than CUs: twelve-wave workgroups / whole chains
     assert not xs(0, 512, 200) and not xs(0, 512, 128)      # three side by side only
     clean_env.setenv("CCVM_AMD_PERSIST_XS", "0")

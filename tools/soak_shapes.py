@@ -21,8 +21,8 @@ TWO_ROWS = ({"CCVM_AMD_PERSIST_KH": "1", "CCVM_AMD_PERSIST_RU": "4"}, {})
 WIDE = ({"CCVM_AMD_PERSIST_WIDE": "1"}, {"CCVM_AMD_PERSIST_WIDE": "1", "SOAK_CHUNK": "1234"})
 CASES = (("dl", 70, 1000, 100000, None, NARROW), ("langevin", 96, 2000, 50000, None, NARROW), ("pl", 80, 1000, 100000, ADAM, NARROW_ADAM),
          ("mf", 65, 777, 100000, ADAM, NARROW_ADAM), ("dl", 144, 1000, 60000, None, TWO_SETS), ("dl", 192, 4000, 20000, None, TWO_SETS),
-         ("mf", 176, 2000, 40000, None, TWO_SETS), ("langevin", 160, 2000, 40000, ADAM, TWO_SETS), ("dl", 144, 256, 100000, None, TWO_ROWS),
-         ("mf", 224, 512, 50000, ADAM, TWO_ROWS), ("langevin", 130, 500, 100000, None, TWO_ROWS),
+         ("mf", 176, 2000, 40000, None, TWO_SETS), ("langevin", 160, 2000, 40000, ADAM, TWO_SETS), ("mf", 144, 512, 100000, None, TWO_ROWS), ("dl", 200, 256, 60000, None, TWO_ROWS),
+         ("mf", 224, 512, 50000, ADAM, TWO_ROWS), ("mf", 130, 500, 100000, ADAM, TWO_ROWS),
          ("dl", 300, 1000, 40000, None, WIDE), ("langevin", 320, 2000, 30000, None, WIDE), ("pl", 257, 333, 60000, None, WIDE))
 for kind, n, b, t, adam, (old, new) in CASES:
     finals, shapes = [], []
