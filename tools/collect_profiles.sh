@@ -19,9 +19,9 @@ pmc mf_n500_b1000 mf_n500_b1000 'cluster_kernel<1' 600 "ccvm::cluster_kernel<1, 
 pmc dl_n100_b1000 dl_n100_b1000 'persist_kernel<0, false, 64, 2, 7, 4, 2, 1>' 600 "ccvm::persist_kernel<0, false, 64, 2, 7, 4, 2, 1> = DL, N=100, B=1000: K split + noise producer waves $PERS"
 pmc dl_n70_b1000 dl_n70_b1000 'persist_kernel<0, false, 32, 3, 5, 4, 1, 1' 600 "ccvm::persist_kernel<0, false, 32, 3, 5, 4, 1, 1> = DL, N=70, B=1000: three 32-column waves of eight rows + noise producer waves $PERS"
 pmc dl_n160_b1000 dl_n160_b1000 'persist_kernel<0, false, 64, 3, 10, 4, 2, 0, 2' 600 "ccvm::persist_kernel<0, false, 64, 3, 10, 4, 2, 0, 2, 0> = DL, N=160, B=1000: three waves side by side x two K halves, two row sets per twelve-wave workgroup $PERS"
-pmc mf_n257_b1000 mf_n257_b1000 'persist_kernel<1, false, 64, 5, 17' 600 "ccvm::persist_kernel<1, false, 64, 5, 17, 4, 2, 0, 0, 52> = MF, N=257, B=1000: five waves side by side, 52 of a wave's 136 Q fragments in LDS $PERS"
-pmc dl_n300_b1000 dl_n300_b1000 'persist_kernel<0, false, 64, 5, 19' 600 "ccvm::persist_kernel<0, false, 64, 5, 19, 4, 2, 0, 0, 48> = DL, N=300, B=1000: five waves side by side x two K halves, 48 of a wave's 152 Q fragments in LDS $PERS"
-pmc langevin_n300_b1000 langevin_n300_b1000 'persist_kernel<2, false, 64, 5, 19' 600 "ccvm::persist_kernel<2, false, 64, 5, 19, 4, 2, 0, 0, 48> = Langevin, N=300, B=1000: the same $PERS"
+pmc mf_n257_b1000 mf_n257_b1000 'persist_kernel<1, false, 64, 5, 17' 600 "ccvm::persist_kernel<1, false, 64, 5, 17, 4, 2, 0, 0, 56, 80> = MF, N=257, B=1000: five waves side by side, K split 80 | 192, the long parts' last 112 fragments in LDS $PERS"
+pmc dl_n300_b1000 dl_n300_b1000 'persist_kernel<0, false, 64, 5, 19' 600 "ccvm::persist_kernel<0, false, 64, 5, 19, 4, 2, 0, 0, 48, 104> = DL, N=300, B=1000: five waves side by side, K split 104 | 200, the long parts' last 96 fragments in LDS $PERS"
+pmc langevin_n300_b1000 langevin_n300_b1000 'persist_kernel<2, false, 64, 5, 19' 600 "ccvm::persist_kernel<2, false, 64, 5, 19, 4, 2, 0, 0, 48, 104> = Langevin, N=300, B=1000: the same $PERS"
 pmc dl_n20_b1000 dl_n20_b1000 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (tuningH020-100-0), B=1000: one wave per row set + noise producer waves $PERS"
 pmc dl_n20_b100 dl_n20_b100 'persist_kernel<0, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<0, false, 32, 1, 2, 2, 1, 1> = DL, N=20 (test020-100-10), B=100: BASELINE config 1 $PERS"
 pmc mf_n20_b1000 mf_n20_b1000 'persist_kernel<1, false, 32, 1, 2, 2, 1, 1>' 600 "ccvm::persist_kernel<1, false, 32, 1, 2, 2, 1, 1> = MF, N=20, B=1000 $PERS"

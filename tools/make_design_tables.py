@@ -31,7 +31,7 @@ ROWS = [
     ("pl_n20_b1000", "the same instance, pumped Langevin (`examples/pumped_langevin_boxqp.py`)", "8 N + 4 N²/B"),
     ("dl_n70_b1000", "the largest shipped size (synthetic N = 70)", "16 N + 4 N²/B"),
     ("dl_n160_b1000", "128 < N ≤ 192: three waves side by side × two K halves, two row sets per twelve-wave workgroup (round 6; 1.84 µs before)", "16 N + 4 N²/B"),
-    ("mf_n257_b1000", "MF just above 256: five waves side by side, 52 of a wave's 136 Q fragments in LDS (round 6; the cluster kernel before: 3.52 µs)", "16 N + 4 N²/B"),
+    ("mf_n257_b1000", "MF just above 256: five waves side by side, unequal K split, part of Q in LDS (round 6; the cluster kernel before: 3.52 µs)", "16 N + 4 N²/B"),
     ("dl_n1000_b2000", "config 4 per GPU on 4 GPUs (strong scaling)", "16 N + 4 N²/B"),
     ("dl_n1000_b4000", "config 4 per GPU on 2 GPUs", "16 N + 4 N²/B"),
     ("pl_n2000_b1024", "config 5 per GPU on 4 GPUs", "8 N + 4 N²/B"),
